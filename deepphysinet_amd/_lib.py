@@ -1,0 +1,79 @@
+"""ctypes binding of libdpn_hip.so (include/dpn_hip.h).  There is no CPU fallback: if the
+library is missing or no MI355X is visible, every point-path call raises."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdpn_hip.so')
+
+NETS = 6
+PREC_BF16 = 1       # bf16 MFMA operands, fp32 accumulate
+PREC_BF16X2 = 2     # bf16 hi+lo split operands (3 MFMAs per product), fp32-class accuracy
+PREC_NAMES = {'bf16': PREC_BF16, 'bf16x2': PREC_BF16X2, 1: PREC_BF16, 2: PREC_BF16X2}
+
+_NET_FIELDS = ('w1b1', 'w2b2', 'evec', 'Wd', 'bd', 'W1', 'bf1', 'W2', 'bf2', 'wo', 'bo')
+
+
+class DpnNetPtrs(Structure):
+    _fields_ = [(n, c_void_p) for n in _NET_FIELDS]
+
+
+class DpnNetGradPtrs(Structure):
+    _fields_ = [(n, c_void_p) for n in _NET_FIELDS]
+
+
+class DpnGeometry(Structure):
+    _fields_ = [('dx', c_float), ('dy', c_float), ('lon_m1', c_float), ('lat_m1', c_float), ('pred_t_span', c_float)]
+
+
+class DpnPhysics(Structure):
+    _fields_ = [('mean', c_float * NETS), ('std', c_float * NETS), ('clip_lo', c_float * NETS), ('clip_hi', c_float * NETS),
+                ('clip_on', c_int * NETS), ('factor', c_float * NETS)]
+
+
+class DpnSizes(Structure):
+    _fields_ = [('n_pad', c_int64), ('packed', c_int64), ('saved', c_int64), ('operands', c_int64), ('partials', c_int64),
+                ('k_splits', c_int32)]
+
+
+EXPORTS = {
+    'dpn_version': (c_int, []),
+    'dpn_sizes': (c_int, [c_int64, c_int, POINTER(DpnSizes)]),
+    'dpn_pack_weights': (c_int, [POINTER(DpnNetPtrs), c_int, c_void_p, c_void_p]),
+    'dpn_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
+                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_residual': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(DpnGeometry), POINTER(DpnPhysics), c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p]),
+    'dpn_residual_finish': (c_int, [c_void_p, c_int64, POINTER(DpnPhysics), c_void_p, c_void_p]),
+    'dpn_bwd_points': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_wgrad': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_wgrad_finish': (c_int, [POINTER(DpnNetPtrs), c_void_p, c_int64, c_int, c_void_p, POINTER(DpnNetGradPtrs), c_void_p]),
+    'dpn_smooth_l1': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'dpn_selftest': (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libdpn_hip.so and declare every prototype; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('deepphysinet_amd: %s is missing. Build it with `python -m deepphysinet_amd.build` '
+                           '(hipcc --offload-arch=gfx950). There is no CPU fallback for the point path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError('libdpn_hip: %s failed with code %d' % (what, code))

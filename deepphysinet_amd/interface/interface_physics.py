@@ -1,0 +1,224 @@
+"""InterfacePhysics: the reference's training-interface surface for the physics-informed step
+(interface/interface_physics.py:32-332 and the step bodies :443-515 / :990-1065).
+
+Hot methods (`place_one_batch`, `data_loss`, `training_step`) run the fused HIP point path.  The six
+`*_equation` methods and `gradient` keep the reference's signatures and formulas as plain torch expressions, for
+callers that hold autograd-connected fields of their own.  File I/O, visualisation and the epoch loops of the
+reference are out of scope.
+"""
+import os
+import shutil
+
+import torch
+import torch.nn as nn
+
+from ..losses.builder import builder_loss
+from ..model.physics_net import PhysicsNet
+from ..point_path import LOSS_ORDER, OBS_ORDER, PointConfig, pde_losses, smooth_l1_data_loss
+from ..utils.position_encoding import SineCosPE
+from .. import _lib as L
+
+
+class InterfacePhysics(nn.Module):
+    def __init__(self, meta_cfg: dict, net_cfg: dict, obs_norm_cfg: dict, variable_cfg: dict, train_cfg: dict, test_cfg=None,
+                 inference_cfg: dict = None, precision='bf16x2', **kwargs):
+        super().__init__()
+        self.net_cfg, self.obs_norm_cfg, self.variable_cfg = net_cfg, obs_norm_cfg, variable_cfg
+        self.train_cfg, self.test_cfg, self.inference_cfg = train_cfg, test_cfg, inference_cfg
+        self.physics_net = PhysicsNet(meta_cfg, net_cfg)
+        self.pe = SineCosPE(3, include_input=False)
+        img_size = self.train_cfg['img_size']
+        if isinstance(img_size, (int, float)):
+            self.lat_size, self.lon_size = img_size, img_size
+        elif isinstance(img_size, (list, tuple)) and len(img_size) == 2:
+            self.lat_size, self.lon_size = img_size
+        else:
+            raise NotImplementedError
+        # attributes the reference only sets inside its training loops (:339-342, :412-418, :438)
+        self.dx = float(train_cfg.get('dx', 27000.0))
+        self.dy = float(train_cfg.get('dy', 27000.0))
+        self.dt = 3600.0 * float(train_cfg.get('lable_time_step', 1))
+        td = train_cfg.get('train_data', {})
+        self.pred_t_span = float(td.get('input_time_step', 6)) * float(td.get('input_time_step_nums', 4)) * 3600.0
+        self.with_clip = True
+        self.precision = L.PREC_NAMES[precision]
+        self._cfg_cache = None
+
+    # ------------------------------------------------------------------ configuration of the HIP path
+    def point_config(self, loss_factor=None) -> PointConfig:
+        for k in OBS_ORDER:
+            c = self.obs_norm_cfg[k]
+            if not c.get('use_norm', True) or c.get('norm_type', 'mean_norm').lower() == 'min_max':
+                raise NotImplementedError('only mean/std de-normalisation is implemented (the shipped config, cfg:64-76)')
+        lf = loss_factor or self.train_cfg['losses']['loss_factor']
+        key = (self.dx, self.dy, self.lon_size, self.lat_size, self.pred_t_span, bool(self.with_clip), self.precision,
+               tuple(float(lf[k]) for k in LOSS_ORDER))
+        if self._cfg_cache is None or self._cfg_cache[0] != key:
+            cfg = PointConfig(dx=self.dx, dy=self.dy, lon_size=self.lon_size, lat_size=self.lat_size, pred_t_span=self.pred_t_span,
+                              mean=tuple(self.obs_norm_cfg[k]['norm_factor'][0] for k in OBS_ORDER),
+                              std=tuple(self.obs_norm_cfg[k]['norm_factor'][1] for k in OBS_ORDER),
+                              clip_lo=tuple(self.obs_norm_cfg[k]['bound'][0] for k in OBS_ORDER),
+                              clip_hi=tuple(self.obs_norm_cfg[k]['bound'][1] for k in OBS_ORDER),
+                              with_clip=bool(self.with_clip), factors=key[-1], prec=self.precision)
+            self._cfg_cache = (key, cfg)
+        self.physics_net.point_cfg = self._cfg_cache[1]
+        return self._cfg_cache[1]
+
+    # ------------------------------------------------------------------ checkpoints (:53-88)
+    def save_model(self, checkpoint_path, epoch, global_step, prefix='physics', **kwargs):
+        checkpoint_file = os.path.join(checkpoint_path, '%s_%d.pth' % (prefix, epoch))
+        state_dict = {'model': self.physics_net.state_dict(), 'epoch': epoch, 'gobal_step': global_step}
+        state_dict.update(kwargs)
+        torch.save(state_dict, checkpoint_file)
+        shutil.copy(checkpoint_file, os.path.join(checkpoint_path, '%s_latest.pth' % prefix))
+
+    def load_model(self, checkpoint_path, current_epoch=None, prefix='downscale', map_location='cpu'):
+        if os.path.isfile(checkpoint_path):
+            model_file = checkpoint_path
+        elif current_epoch is None:
+            model_file = os.path.join(checkpoint_path, '%s_latest.pth' % prefix)
+        else:
+            model_file = os.path.join(checkpoint_path, '%s_%d.pth' % (prefix, current_epoch))
+        if not os.path.exists(model_file):
+            print('warning:%s does not exist!' % model_file)
+            return None, 0, 0
+        state_dict = torch.load(model_file, map_location=map_location)
+        glob_step = state_dict.pop('gobal_step', 0)
+        epoch = state_dict.pop('epoch', 0)
+        # checkpoints written under DDP carry a 'module.' prefix (:1397 via :56); accept both
+        if 'model' in state_dict and any(k.startswith('module.') for k in state_dict['model']):
+            state_dict['model'] = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in state_dict['model'].items()}
+        return state_dict, epoch + 1, glob_step
+
+    # ------------------------------------------------------------------ generic torch expressions (reference formulas)
+    def gradient(self, y, x):
+        return torch.autograd.grad(y, x, grad_outputs=torch.ones_like(y), create_graph=True, only_inputs=True, allow_unused=False)[0]
+
+    def montion_equation_u(self, x, y, t, u, v, p, rio, f, loss, factor=1e-6):
+        lhs = self.gradient(u, t) + u * self.gradient(u, x) + v * self.gradient(u, y) + self.gradient(p, x) / rio
+        return loss(lhs, f * v).float() * factor
+
+    def montion_equation_v(self, x, y, t, u, v, p, rio, f, loss, factor=1e-6):
+        lhs = self.gradient(v, t) + u * self.gradient(v, x) + v * self.gradient(v, y) + self.gradient(p, y) / rio
+        return loss(lhs, -f * u).float() * factor
+
+    def continuous_equation(self, x, y, t, u, v, rio, loss, factor=1e-6):
+        lhs = (self.gradient(rio, t) + u * self.gradient(rio, x) + v * self.gradient(rio, y)
+               + rio * self.gradient(u, x) + rio * self.gradient(v, y))
+        return loss(lhs, torch.zeros_like(lhs).float()).float() * factor
+
+    def _advect(self, a, x, y, t, u, v):
+        return self.gradient(a, t) + u * self.gradient(a, x) + v * self.gradient(a, y)
+
+    def energy_equation(self, x, y, t, u, v, p, T, rio, q, loss, factor=1e-6, c_p=1005, L=2.5e6):
+        lhs = c_p * self._advect(T, x, y, t, u, v) + (-self._advect(p, x, y, t, u, v) / (rio + 1e-6)) + L * self._advect(q, x, y, t, u, v)
+        return loss(lhs, torch.zeros_like(lhs).float()).float() * factor
+
+    def get_qs(self, p, T):
+        tc = T - 273.15
+        e_s = 6.112 * torch.exp(17.67 * tc / (tc + 243.5)) * 100
+        return 0.622 * e_s / (p - 0.378 * e_s)
+
+    def vapor_equation(self, x, y, t, u, v, p, T, q, loss, factor=1e-5, c_p=1005, L=2.5e6, R_v=461.5, R_d=287):
+        omega = self._advect(p, x, y, t, u, v)
+        q_adv = self._advect(q, x, y, t, u, v)
+        q_s = torch.maximum(self.get_qs(p, T).detach(), torch.full_like(p, 1e-6))
+        delta = ((omega < 0) & (q >= q_s)).to(p.dtype).detach()
+        R = (1 + 0.608 * q) * R_d
+        Fv = (((L * R - c_p * R_v * T) / (c_p * R_v + T * T + L * L * q_s)) * q_s * T).detach()
+        lhs = -omega * delta * Fv / (p + 1e-6) + q_adv
+        return loss(lhs, torch.zeros_like(lhs).float()).float() * factor
+
+    def gas_equation(self, p, T, rio, q, loss, factor=1e-5, R_d=287):
+        return loss(p, rio * (1 + 0.608 * q) * R_d * T).float() * factor
+
+    def inverse_norm(self, u, v, P, T, q, rio, obs_norm_cfg, with_clip=False):
+        """:232-262 -- like the reference, clipping follows self.with_clip and never applies to u, v."""
+        out = []
+        for k, (val, name) in enumerate(zip((u, v, P, T, q, rio), OBS_ORDER)):
+            c = obs_norm_cfg[name]
+            if c['use_norm']:
+                if c['norm_type'].lower() == 'min_max':
+                    raise NotImplementedError('min_max de-normalisation is unused by the shipped config')
+                val = val * c['norm_factor'][1] + c['norm_factor'][0]
+                if k >= 2 and self.with_clip:
+                    val = torch.clip(val, c['bound'][0], c['bound'][1])
+            out.append(val)
+        return tuple(out)
+
+    def calc_rio(self, p, T, q, R_d=287):
+        return ((1 + 0.608 * q) * R_d * T / p).detach()
+
+    def encoding_coord(self, x, y, t, pred_t_span):
+        x = x / self.dx / (self.lon_size - 1)
+        y = y / self.dy / (self.lat_size - 1)
+        t = t / pred_t_span
+        pts = torch.stack([x, y, t], dim=1) if x.dim() == 1 else torch.cat([x, y, t], dim=1)
+        return self.pe(pts)
+
+    # ------------------------------------------------------------------ fused HIP path
+    def _check_pde_criterion(self, criterion):
+        if not (isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean'):
+            raise NotImplementedError('the fused residual kernel implements nn.MSELoss(reduction="mean") (cfg:137); got %r' % (criterion,))
+
+    def pde_loss_terms(self, x, y, t, f, field_data, input_data, forecast_h, loss_factor=None, use_cache=False):
+        """The six scaled residual losses as a [6] tensor (motion_u, motion_v, continuous, energy, vapor, gas)."""
+        cfg = self.point_config(loss_factor)
+        w1b1, w2b2, evec, statics = self.physics_net.field_weights(field_data, forecast_h, use_cache=use_cache)
+        return pde_losses(cfg, x, y, t, f, input_data, w1b1, w2b2, evec, statics)
+
+    def place_one_batch(self, x, y, t, f, field_data, input_data, forecast_h, criterion, loss_factor, global_step, local_rank, device,
+                        summary=None, prefix='inter', log_step=100, use_cache=False):
+        """:271-320.  Same arguments and return value; the fields, the Jacobian, the residuals and their backward run in HIP."""
+        self._check_pde_criterion(criterion)
+        f, x, y, t = f.to(device), x.to(device), y.to(device), t.to(device)
+        terms = self.pde_loss_terms(x, y, t, f, field_data, input_data, forecast_h, loss_factor, use_cache=use_cache)
+        mu, mv, co, en, va, ga = terms.unbind(0)
+        train_loss = mu + mv + en + co + va + ga                  # reference order of the additions (:301)
+        if summary is not None and global_step % log_step == 1 and local_rank == 0:
+            names = ('montion_u_loss', 'montion_v_loss', 'continous_loss', 'energy_loss', 'vapor_loss', 'gas_loss')
+            vals = terms.detach().cpu().tolist()
+            summary.add_scalar('%s/total_loss' % prefix, float(train_loss.detach()), global_step)
+            for n_, v_ in zip(names, vals):
+                summary.add_scalar('%s/%s' % (prefix, n_), v_, global_step)
+            print('%s:' % prefix + ','.join('%s:%f' % (n_, v_) for n_, v_ in zip(names, vals)))
+        return train_loss.float()
+
+    def data_loss(self, x, y, t, field_data, input_data, labels, forecast_h, margin_factor=None, beta=0.1, use_cache=False):
+        """Data ("margin") loss of the step body (:464-474): mean SmoothL1(beta) over [N,6] times margin_factor."""
+        self.point_config()
+        if margin_factor is None:
+            margin_factor = self.train_cfg['losses']['loss_factor']['margin_factor']
+        fields = self.physics_net.forward_xyt(field_data, x, y, t, input_data, forecast_h, use_cache=use_cache)
+        return smooth_l1_data_loss(torch.cat(fields, dim=1), labels, beta=beta, factor=1.0).float() * margin_factor
+
+    def training_step(self, batch: dict, optimizer, with_pde=True, max_norm=2.5e7, grad_sync=None):
+        """One step body (:443-515 / :990-1065): data loss on the margin points, PDE losses on interior and margin points,
+        backward, clip_grad_norm_(2.5e7), optimizer step.  `batch` holds device tensors: field_data [1,159,2405],
+        forecast_h [1,1,1], margin_{x,y,t,f} [N,1], margin_data [N,6], margin_input_data [N,6], inter_{x,y,t,f} [M,1],
+        inter_data [M,6].  The encoder runs once (the reference runs it three times on identical inputs)."""
+        lf = self.train_cfg['losses']['loss_factor']
+        self.physics_net.clear_field_cache()
+        b = batch
+        loss = self.data_loss(b['margin_x'], b['margin_y'], b['margin_t'], b['field_data'], b['margin_input_data'], b['margin_data'],
+                              b['forecast_h'], lf['margin_factor'], use_cache=True)
+        parts = {'margin_loss': loss}
+        if with_pde:
+            crit = nn.MSELoss()
+            parts['inter_pde_loss'] = self.place_one_batch(b['inter_x'], b['inter_y'], b['inter_t'], b['inter_f'], b['field_data'],
+                                                           b['inter_data'], b['forecast_h'], crit, lf, 0, 0, b['field_data'].device,
+                                                           use_cache=True)
+            parts['margin_pde_loss'] = self.place_one_batch(b['margin_x'], b['margin_y'], b['margin_t'], b['margin_f'], b['field_data'],
+                                                            b['margin_input_data'], b['forecast_h'], crit, lf, 0, 0,
+                                                            b['field_data'].device, prefix='margin', use_cache=True)
+        train_loss = 0
+        for v in parts.values():
+            train_loss = train_loss + v
+        optimizer.zero_grad()
+        train_loss.backward()
+        self.physics_net.clear_field_cache()
+        if grad_sync is not None:
+            grad_sync(self.physics_net.parameters())
+        gnorm = torch.nn.utils.clip_grad_norm_(self.physics_net.parameters(), max_norm=max_norm)
+        optimizer.step()
+        return train_loss.detach(), {k: v.detach() for k, v in parts.items()}, gnorm

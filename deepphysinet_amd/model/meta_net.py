@@ -1,0 +1,167 @@
+"""Grid encoder ("MetaNet") with the reference's module tree and state_dict names.
+
+Reference: model/meta_net.py:13-20, model/transformer_net.py:17-44,47-72,95-129, model/embed.py:16-64,
+model/attn.py:43-68,161-196.  Same parameters, same math, different execution: the whole encoder is <2 % of the
+step's FLOPs, so it runs on library GEMMs (rocBLAS/hipBLASLt through torch) with the attention, the 1x1
+convolutions and the layer norms issued as fused torch ops, and its output is cached across the calls of one
+training step (the model has no dropout, so the three forwards the reference does per step are identical).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..utils.position_encoding import SineCosPE
+
+
+class PositionalEmbedding(nn.Module):
+    """Fixed sinusoid table; persistent buffer `pe` [1, max_len, d_model] (embed.py:16-33)."""
+
+    def __init__(self, d_model, max_len=5000):
+        super().__init__()
+        pos = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
+        inv = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / d_model))
+        table = torch.zeros(max_len, d_model, dtype=torch.float32)
+        table[:, 0::2] = torch.sin(pos * inv)
+        table[:, 1::2] = torch.cos(pos * inv)
+        self.register_buffer('pe', table.unsqueeze(0))
+
+    def forward(self, x):
+        return self.pe[:, :x.size(1)]
+
+
+class TokenEmbedding(nn.Module):
+    """Circular Conv1d(c_in -> d_model, k=3) along the token axis (embed.py:36-48)."""
+
+    def __init__(self, c_in, d_model):
+        super().__init__()
+        self.tokenConv = nn.Conv1d(c_in, d_model, kernel_size=3, padding=1, padding_mode='circular')
+        nn.init.kaiming_normal_(self.tokenConv.weight, mode='fan_in', nonlinearity='leaky_relu')
+
+    def forward(self, x):
+        return self.tokenConv(x.permute(0, 2, 1)).transpose(1, 2)
+
+
+class DataEmbedding(nn.Module):
+    def __init__(self, c_in, d_model):
+        super().__init__()
+        self.value_embedding = TokenEmbedding(c_in, d_model)
+        self.position_embedding = PositionalEmbedding(d_model)
+        self.time_embending = SineCosPE(input_dim=1, include_input=False, N_freqs=d_model // 2)   # (sic) embed.py:58
+
+    def forward(self, x, forecast_h, learnable_token):
+        x = torch.cat([learnable_token, self.value_embedding(x)], dim=1)
+        return x + self.position_embedding(x) + self.time_embending(forecast_h)
+
+
+class FullAttention(nn.Module):
+    """softmax(q k^T / sqrt(E)) v, no mask, no dropout (attn.py:43-68 with mask_flag=False)."""
+
+    def __init__(self, mask_flag=False, scale=None, output_attention=False):
+        super().__init__()
+        if mask_flag:
+            raise NotImplementedError('the shipped config never masks (transformer_net.py:112)')
+        self.scale = scale
+        self.output_attention = output_attention
+
+    def forward(self, queries, keys, values, attn_mask=None):
+        # [B, L, H, E] -> fused SDPA on [B, H, L, E]
+        q, k, v = (z.transpose(1, 2) for z in (queries, keys, values))
+        out = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+        return out.transpose(1, 2).contiguous(), None
+
+
+class AttentionLayer(nn.Module):
+    def __init__(self, attention, d_model, n_heads, d_keys=None, d_values=None, mix=False):
+        super().__init__()
+        d_keys = d_keys or d_model // n_heads
+        d_values = d_values or d_model // n_heads
+        self.inner_attention = attention
+        self.query_projection = nn.Linear(d_model, d_keys * n_heads)
+        self.key_projection = nn.Linear(d_model, d_keys * n_heads)
+        self.value_projection = nn.Linear(d_model, d_values * n_heads)
+        self.out_projection = nn.Linear(d_values * n_heads, d_model)
+        self.n_heads = n_heads
+        self.mix = mix
+
+    def forward(self, queries, keys, values, attn_mask=None):
+        B, L, _ = queries.shape
+        S, H = keys.shape[1], self.n_heads
+        q = self.query_projection(queries).view(B, L, H, -1)
+        k = self.key_projection(keys).view(B, S, H, -1)
+        v = self.value_projection(values).view(B, S, H, -1)
+        out, attn = self.inner_attention(q, k, v, attn_mask)
+        if self.mix:
+            out = out.transpose(2, 1).contiguous()
+        return self.out_projection(out.reshape(B, L, -1)), attn
+
+
+class EncoderLayer(nn.Module):
+    """x = LN1(x + attn(x)); out = LN2(x + conv2(act(conv1(x)))) with 1x1 convs (transformer_net.py:17-44)."""
+
+    def __init__(self, attention, d_model, d_ff=None, activation='relu'):
+        super().__init__()
+        d_ff = d_ff or 4 * d_model
+        self.attention = attention
+        self.conv1 = nn.Conv1d(d_model, d_ff, kernel_size=1)
+        self.conv2 = nn.Conv1d(d_ff, d_model, kernel_size=1)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.activation = F.relu if activation == 'relu' else F.gelu
+
+    def forward(self, x, attn_mask=None):
+        new_x, attn = self.attention(x, x, x, attn_mask=attn_mask)
+        x = self.norm1(x + new_x)
+        # kernel-size-1 convolutions over the token axis are per-token linear maps: run them as GEMMs
+        y = self.activation(F.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias))
+        y = F.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias)
+        return self.norm2(x + y), attn
+
+
+class Encoder(nn.Module):
+    def __init__(self, attn_layers, conv_layers=None, norm_layer=None):
+        super().__init__()
+        if conv_layers is not None:
+            raise NotImplementedError('distilling conv layers are never used by the reference model')
+        self.attn_layers = nn.ModuleList(attn_layers)
+        self.conv_layers = None
+        self.norm = norm_layer
+
+    def forward(self, x, attn_mask=None):
+        attns = []
+        for layer in self.attn_layers:
+            x, a = layer(x, attn_mask=attn_mask)
+            attns.append(a)
+        if self.norm is not None:
+            x = self.norm(x)
+        return x, attns
+
+
+class TransformerNet(nn.Module):
+    def __init__(self, enc_in, c_out, d_model=512, n_heads=8, e_layers=6, d_ff=512, activation='gelu',
+                 learnable_token_num=128, output_attention=False, **kwargs):
+        super().__init__()
+        self.output_attention = output_attention
+        self.enc_embedding = DataEmbedding(enc_in, d_model)
+        self.learnable_token = nn.Parameter(torch.rand([1, learnable_token_num, d_model]), requires_grad=True)
+        self.encoder = Encoder(
+            [EncoderLayer(AttentionLayer(FullAttention(False, output_attention=output_attention), d_model, n_heads, mix=False),
+                          d_model, d_ff, activation=activation) for _ in range(e_layers)],
+            norm_layer=nn.LayerNorm(d_model))
+        self.projection = nn.Linear(d_model, c_out, bias=True)
+
+    def forward(self, x_enc, forecast_h, enc_self_mask=None):
+        enc_out = self.enc_embedding(x_enc, forecast_h, self.learnable_token)
+        enc_out, _ = self.encoder(enc_out, attn_mask=enc_self_mask)
+        return self.projection(enc_out)
+
+
+class MetaNet(nn.Module):
+    def __init__(self, meta_cfg):
+        super().__init__()
+        self.meta_cfg = meta_cfg
+        self.model = TransformerNet(**{k: v for k, v in meta_cfg.items() if k != 'name'})
+
+    def forward(self, x, forecast_h):
+        return self.model(x, forecast_h)

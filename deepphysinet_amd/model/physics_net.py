@@ -1,0 +1,83 @@
+"""PhysicsNet = MetaNet + six VariableNets, with the reference's constructor / attributes / forward
+(model/physics_net.py:17-60).  The six per-point MLPs run as one fused HIP launch per pass."""
+import torch
+import torch.nn as nn
+
+from .meta_net import MetaNet
+from .variable_net import VariableNet
+
+# output order of forward(): U, V, P, T, q, rio  (physics_net.py:49-55); registration order keeps the reference's
+# state_dict order U, V, P, T, rio, q (physics_net.py:25-30)
+OUTPUT_ORDER = ('U_net', 'V_net', 'P_net', 'T_net', 'q_net', 'rio_net')
+
+
+class PhysicsNet(nn.Module):
+    def __init__(self, meta_cfg: dict, net_cfg: dict):
+        super().__init__()
+        in_channels = net_cfg['in_channels']
+        hidden_channels = net_cfg['hidden_channels']
+        token_num = net_cfg['learnable_token_num']
+        self.meta_net = MetaNet(meta_cfg)
+        self.U_net = VariableNet(token_num, in_channels, hidden_channels)
+        self.V_net = VariableNet(token_num, in_channels, hidden_channels)
+        self.P_net = VariableNet(token_num, in_channels, hidden_channels)
+        self.T_net = VariableNet(token_num, in_channels, hidden_channels)
+        self.rio_net = VariableNet(token_num, in_channels, hidden_channels)
+        self.q_net = VariableNet(token_num, in_channels, hidden_channels)
+        self.tanh = nn.Tanh()
+        self.net_dict = {'u': self.U_net, 'v': self.V_net, 'p': self.P_net, 'T': self.T_net, 'q': self.q_net, 'rio': self.rio_net}
+        self.point_cfg = None            # set by InterfacePhysics; default PointConfig() otherwise
+        self._meta_cache = None
+
+    # ---- per-field part ---------------------------------------------------------------------------
+    def nets_in_output_order(self):
+        return [getattr(self, n) for n in OUTPUT_ORDER]
+
+    def encode_field(self, field_x, forecast_h, use_cache=False):
+        """MetaNet output [1,287,256].  With use_cache the result is reused while (field, lead time, parameters) are unchanged
+        inside one training step (the reference recomputes it three times per step with identical inputs)."""
+        if use_cache and self._meta_cache is not None:
+            key, val = self._meta_cache
+            if key == (field_x.data_ptr(), field_x._version, forecast_h.data_ptr(), forecast_h._version, torch.is_grad_enabled()):
+                return val
+        val = self.meta_net(field_x, forecast_h)
+        if use_cache:
+            self._meta_cache = ((field_x.data_ptr(), field_x._version, forecast_h.data_ptr(), forecast_h._version,
+                                 torch.is_grad_enabled()), val)
+        return val
+
+    def clear_field_cache(self):
+        self._meta_cache = None
+
+    def field_weights(self, field_x, forecast_h, use_cache=False):
+        """Everything the point kernels need for one field sample: (w1b1 [6,256,193], w2b2 [6,256,257], evec [6,256], statics[48])."""
+        meta_out = self.encode_field(field_x, forecast_h, use_cache=use_cache)
+        nets = self.nets_in_output_order()
+        hw = [n.hyper_weights(meta_out, forecast_h) for n in nets]
+        w1b1 = torch.stack([h[0] for h in hw])
+        w2b2 = torch.stack([h[1] for h in hw])
+        evec = torch.stack([h[2] for h in hw])
+        statics = [p for n in nets for p in n.static_params()]
+        return w1b1, w2b2, evec, statics
+
+    def _cfg(self):
+        from ..point_path import PointConfig
+        return self.point_cfg or PointConfig()
+
+    # ---- reference surface ------------------------------------------------------------------------
+    def forward(self, field_x, coord_x, coord_data, forecast_h):
+        """coord_x: [N,192] coordinates already encoded by SineCosPE(3) (interface_physics.py:322-332)."""
+        from ..point_path import point_fields
+        w1b1, w2b2, evec, statics = self.field_weights(field_x, forecast_h)
+        out = point_fields(self._cfg(), coord_data, w1b1, w2b2, evec, statics, pe_in=coord_x)
+        return tuple(out[:, k:k + 1] for k in range(6))
+
+    def forward_xyt(self, field_x, x, y, t, coord_data, forecast_h, use_cache=False):
+        """Same fields from raw coordinates; the encoding happens inside the kernel (fast path)."""
+        from ..point_path import point_fields
+        w1b1, w2b2, evec, statics = self.field_weights(field_x, forecast_h, use_cache=use_cache)
+        out = point_fields(self._cfg(), coord_data, w1b1, w2b2, evec, statics, x=x, y=y, t=t)
+        return tuple(out[:, k:k + 1] for k in range(6))
+
+    def forward_single(self, variable_name, field_x, coord_x):
+        raise NotImplementedError('dead code in the reference as well (model/physics_net.py:57-60 calls MetaNet with one argument)')

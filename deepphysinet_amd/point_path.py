@@ -1,0 +1,276 @@
+"""Host side of the HIP point path: buffers, pointer tables and the two autograd entry points.
+
+`point_fields`  : six VariableNets evaluated at N collocation points (PhysicsNet.forward's hot part,
+                  reference model/physics_net.py:49-54), differentiable w.r.t. all weights.
+`pde_losses`    : place_one_batch's hot part (reference interface/interface_physics.py:278-301): fields,
+                  6x3 coordinate Jacobian, inverse_norm (+clip), six residual losses; backward gives every
+                  weight gradient without building an autograd graph over the points.
+
+PyTorch is used for device memory, the current HIP stream and autograd bookkeeping only; all arithmetic on
+points happens in libdpn_hip.so (deepphysinet_amd/csrc/dpn_kernels.hip).  There is no CPU path.
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+# configs/DeepPhysiNet_NCEP_cfg.py:64-76 -- order u10, v10, pres, t2, q2, rio (network output order)
+OBS_ORDER = ('u10', 'v10', 'pres', 't2', 'q2', 'rio')
+LOSS_ORDER = ('motion_u_factor', 'motion_v_factor', 'continuous_factor', 'energy_factor', 'vapor_factor', 'gas_factor')
+STATIC_NAMES = ('Wd', 'bd', 'W1', 'bf1', 'W2', 'bf2', 'wo', 'bo')      # per-net parameter tensors, in this order
+STATIC_SHAPES = ((256, 192), (256,), (256, 256), (256,), (256, 256), (256,), (1, 256), (1,))
+
+
+@dataclass
+class PointConfig:
+    """Geometry + physics constants of one InterfacePhysics instance."""
+    dx: float = 27000.0
+    dy: float = 27000.0
+    lon_size: int = 257
+    lat_size: int = 145
+    pred_t_span: float = 86400.0
+    mean: Sequence[float] = (0.14507186950562942, -0.17325370241478535, 89741.36105771353, 283.58054561520305,
+                             0.007909478276582905, 1.0966503643401704)
+    std: Sequence[float] = (3.0050219075895894, 3.006602165591562, 13296.749084125422, 15.583177935722373,
+                            0.006304067969976075, 0.15166081218127583)
+    clip_lo: Sequence[float] = (-500.0, -500.0, 10000.0, 50.0, 1e-6, 1e-6)
+    clip_hi: Sequence[float] = (500.0, 500.0, 500000.0, 500.0, 10.0, 10.0)
+    with_clip: bool = True
+    factors: Sequence[float] = (1.e3, 1.e3, 1.e10, 1e1, 1.e14, 1.e-7)
+    prec: int = L.PREC_BF16X2
+
+    def geometry(self) -> L.DpnGeometry:
+        return L.DpnGeometry(float(self.dx), float(self.dy), float(self.lon_size - 1), float(self.lat_size - 1), float(self.pred_t_span))
+
+    def physics(self) -> L.DpnPhysics:
+        ph = L.DpnPhysics()
+        for k in range(L.NETS):
+            ph.mean[k], ph.std[k] = float(self.mean[k]), float(self.std[k])
+            ph.clip_lo[k], ph.clip_hi[k] = float(self.clip_lo[k]), float(self.clip_hi[k])
+            ph.clip_on[k] = int(bool(self.with_clip) and k >= 2)       # u, v are never clipped (interface_physics.py:256-257)
+            ph.factor[k] = float(self.factors[k])
+        return ph
+
+
+_freq_cache = {}
+
+
+def _freqs(device):
+    key = str(device)
+    if key not in _freq_cache:
+        f32 = 2.0 ** torch.linspace(0.0, 4.0, steps=32)       # fp32, exactly utils/position_encoding.py:27
+        f16 = 2.0 ** torch.linspace(0.0, 4.0, steps=16)
+        _freq_cache[key] = torch.cat([f32, f16]).to(device=device, dtype=torch.float32).contiguous()
+    return _freq_cache[key]
+
+
+def _require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError('deepphysinet_amd point path needs HIP device tensors (%s is on %s); there is no CPU fallback' % (name, t.device))
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _net_ptrs(w1b1, w2b2, evec, statics):
+    arr = (L.DpnNetPtrs * L.NETS)()
+    for k in range(L.NETS):
+        arr[k].w1b1 = w1b1.data_ptr() + k * 256 * 193 * 4
+        arr[k].w2b2 = w2b2.data_ptr() + k * 256 * 257 * 4
+        arr[k].evec = evec.data_ptr() + k * 256 * 4
+        for j, nm in enumerate(STATIC_NAMES):
+            setattr(arr[k], nm, statics[k * 8 + j].data_ptr())
+    return arr
+
+
+class _Workspace:
+    """Buffers of one forward call that its backward needs again."""
+
+    def __init__(self, n, prec, device):
+        lib = L.load()
+        self.sizes = L.DpnSizes()
+        L.check(lib.dpn_sizes(n, prec, ctypes.byref(self.sizes)), 'dpn_sizes')
+        self.n, self.prec, self.device = n, prec, device
+        self.packed = torch.empty(self.sizes.packed, dtype=torch.uint8, device=device)
+        self.saved = None
+
+    def alloc_saved(self):
+        self.saved = torch.empty(self.sizes.saved, dtype=torch.uint8, device=self.device)
+
+
+def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, want_jac, want_saved):
+    lib = L.load()
+    n = coord_data.shape[0]
+    dev = coord_data.device
+    L.check(lib.dpn_pack_weights(nets, cfg.prec, _ptr(ws.packed), _stream()), 'dpn_pack_weights')
+    out_n = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    jac_n = torch.empty((n, 6, 3), dtype=torch.float32, device=dev) if want_jac else None
+    if want_saved:
+        ws.alloc_saved()
+    geo = cfg.geometry()
+    L.check(lib.dpn_fwd(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), n, _ptr(_freqs(dev)), ctypes.byref(geo),
+                        _ptr(ws.packed), cfg.prec, _ptr(out_n), _ptr(jac_n), _ptr(ws.saved), _stream()), 'dpn_fwd')
+    return out_n, jac_n
+
+
+def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics):
+    """Weight gradients from per-point cotangents.  Returns (g_w1b1, g_w2b2, g_evec, [48 static grads])."""
+    lib = L.load()
+    n = coord_data.shape[0]
+    dev = coord_data.device
+    operands = torch.empty(ws.sizes.operands, dtype=torch.uint8, device=dev)
+    partials = torch.empty(ws.sizes.partials, dtype=torch.uint8, device=dev)
+    geo = cfg.geometry()
+    L.check(lib.dpn_bwd_points(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), n, _ptr(_freqs(dev)), ctypes.byref(geo),
+                               _ptr(ws.packed), cfg.prec, _ptr(g_out), _ptr(g_jxi), _ptr(ws.saved), _ptr(operands), _stream()),
+            'dpn_bwd_points')
+    L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
+    g_w1b1 = torch.empty((6, 256, 193), dtype=torch.float32, device=dev)
+    g_w2b2 = torch.empty((6, 256, 257), dtype=torch.float32, device=dev)
+    g_evec = torch.empty((6, 256), dtype=torch.float32, device=dev)
+    g_stat = [torch.empty(STATIC_SHAPES[j], dtype=torch.float32, device=dev) for _ in range(6) for j in range(8)]
+    garr = (L.DpnNetGradPtrs * L.NETS)()
+    for k in range(L.NETS):
+        garr[k].w1b1 = g_w1b1.data_ptr() + k * 256 * 193 * 4
+        garr[k].w2b2 = g_w2b2.data_ptr() + k * 256 * 257 * 4
+        garr[k].evec = g_evec.data_ptr() + k * 256 * 4
+        for j, nm in enumerate(STATIC_NAMES):
+            setattr(garr[k], nm, g_stat[k * 8 + j].data_ptr())
+    L.check(lib.dpn_wgrad_finish(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, _stream()), 'dpn_wgrad_finish')
+    return g_w1b1, g_w2b2, g_evec, g_stat
+
+
+class _PointFieldsFn(torch.autograd.Function):
+    """out_n [N,6] = six VariableNets at N points.  First-order differentiable w.r.t. the weights."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, y, t, pe_in, coord_data, w1b1, w2b2, evec, *statics):
+        for nm, v in (('coord_data', coord_data), ('w1b1', w1b1)):
+            _require_gpu(v, nm)
+        tens = [None if v is None else _f32c(v) for v in (x, y, t, pe_in, coord_data, w1b1, w2b2, evec)]
+        x_, y_, t_, pe_, cd_, w1_, w2_, ev_ = tens
+        st = [_f32c(s) for s in statics]
+        need_grad = any(v.requires_grad for v in (w1b1, w2b2, evec) + tuple(statics))
+        ws = _Workspace(cd_.shape[0], cfg.prec, cd_.device)
+        nets = _net_ptrs(w1_, w2_, ev_, st)
+        out_n, _ = _forward_points(cfg, ws, nets, x_, y_, t_, pe_, cd_, want_jac=False, want_saved=need_grad)
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.keep = (x_, y_, t_, pe_, cd_, w1_, w2_, ev_, st)
+        return out_n
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_, y_, t_, pe_, cd_, w1_, w2_, ev_, st = ctx.keep
+        nets = _net_ptrs(w1_, w2_, ev_, st)
+        g = _f32c(g_out)
+        gw1, gw2, gev, gst = _backward_points(ctx.cfg, ctx.ws, nets, x_, y_, t_, pe_, cd_, g, None, st)
+        return (None, None, None, None, None, None, gw1, gw2, gev, *gst)
+
+
+class _PdeLossFn(torch.autograd.Function):
+    """losses [6] = (motion_u, motion_v, continuous, energy, vapor, gas), each already scaled by its factor."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, y, t, f, coord_data, w1b1, w2b2, evec, *statics):
+        for nm, v in (('x', x), ('coord_data', coord_data), ('w1b1', w1b1)):
+            _require_gpu(v, nm)
+        lib = L.load()
+        x_, y_, t_, f_, cd_, w1_, w2_, ev_ = [_f32c(v).reshape(-1) if i < 4 else _f32c(v) for i, v in
+                                              enumerate((x, y, t, f, coord_data, w1b1, w2b2, evec))]
+        st = [_f32c(s) for s in statics]
+        n = cd_.shape[0]
+        dev = cd_.device
+        need_grad = any(v.requires_grad for v in (w1b1, w2b2, evec) + tuple(statics))
+        ws = _Workspace(n, cfg.prec, dev)
+        nets = _net_ptrs(w1_, w2_, ev_, st)
+        out_n, jac_n = _forward_points(cfg, ws, nets, x_, y_, t_, None, cd_, want_jac=True, want_saved=need_grad)
+        sums = torch.zeros(6, dtype=torch.float64, device=dev)
+        losses = torch.empty(6, dtype=torch.float32, device=dev)
+        geo, ph = cfg.geometry(), cfg.physics()
+        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, _ptr(sums),
+                                 None, None, _stream()), 'dpn_residual')
+        L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses), _stream()), 'dpn_residual_finish')
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.keep = (x_, y_, t_, f_, cd_, w1_, w2_, ev_, st, out_n, jac_n)
+        ctx.fields = (out_n, jac_n)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g_losses):
+        lib = L.load()
+        cfg = ctx.cfg
+        x_, y_, t_, f_, cd_, w1_, w2_, ev_, st, out_n, jac_n = ctx.keep
+        n = cd_.shape[0]
+        dev = cd_.device
+        gl = _f32c(g_losses)
+        g_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
+        g_jxi = torch.empty((n, 6, 3), dtype=torch.float32, device=dev)
+        geo, ph = cfg.geometry(), cfg.physics()
+        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), _ptr(gl), None,
+                                 _ptr(g_out), _ptr(g_jxi), _stream()), 'dpn_residual(grad)')
+        nets = _net_ptrs(w1_, w2_, ev_, st)
+        gw1, gw2, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st)
+        return (None, None, None, None, None, None, gw1, gw2, gev, *gst)
+
+
+def point_fields(cfg: PointConfig, coord_data, w1b1, w2b2, evec, statics, x=None, y=None, t=None, pe_in=None):
+    """Normalised fields [N,6].  Give either raw (x,y,t) [N] or caller-encoded coordinates pe_in [N,192]."""
+    if (pe_in is None) == (x is None):
+        raise ValueError('give exactly one of (x,y,t) or pe_in')
+    if x is not None:
+        x, y, t = (v.reshape(-1) for v in (x, y, t))
+    return _PointFieldsFn.apply(cfg, x, y, t, pe_in, coord_data, w1b1, w2b2, evec, *statics)
+
+
+def pde_losses(cfg: PointConfig, x, y, t, f, coord_data, w1b1, w2b2, evec, statics):
+    """The six scaled residual losses [6] of place_one_batch."""
+    return _PdeLossFn.apply(cfg, x, y, t, f, coord_data, w1b1, w2b2, evec, *statics)
+
+
+def pde_fields_and_jacobian(cfg: PointConfig, x, y, t, coord_data, w1b1, w2b2, evec, statics):
+    """No-grad helper: normalised fields [N,6] and d(fields_n)/d(x,y,t) [N,6,3] straight from the forward kernel."""
+    with torch.no_grad():
+        x_, y_, t_ = (_f32c(v).reshape(-1) for v in (x, y, t))
+        cd_, w1_, w2_, ev_ = (_f32c(v) for v in (coord_data, w1b1, w2b2, evec))
+        st = [_f32c(s) for s in statics]
+        ws = _Workspace(cd_.shape[0], cfg.prec, cd_.device)
+        return _forward_points(cfg, ws, _net_ptrs(w1_, w2_, ev_, st), x_, y_, t_, None, cd_, want_jac=True, want_saved=False)
+
+
+def smooth_l1_data_loss(out_n, labels, beta=0.1, factor=1.0):
+    """mean(SmoothL1(beta)) * factor as a differentiable torch scalar (losses/weights_loss.py:17-20); HIP kernel for both passes."""
+    return _SmoothL1Fn.apply(out_n, labels, float(beta), float(factor))
+
+
+class _SmoothL1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out_n, labels, beta, factor):
+        _require_gpu(out_n, 'out_n')
+        lib = L.load()
+        o, l = _f32c(out_n), _f32c(labels)
+        n = o.shape[0]
+        s = torch.zeros(1, dtype=torch.float64, device=o.device)
+        g = torch.empty_like(o)
+        L.check(lib.dpn_smooth_l1(_ptr(o), _ptr(l), n, beta, factor / (6.0 * n), _ptr(s), _ptr(g), _stream()), 'dpn_smooth_l1')
+        ctx.save_for_backward(g)
+        return ((s[0] / (6.0 * n)).float() * factor)
+
+    @staticmethod
+    def backward(ctx, gl):
+        (g,) = ctx.saved_tensors
+        return g * gl, None, None, None

@@ -1,0 +1,130 @@
+/* libdpn_hip.so -- C ABI of the MI355X (gfx950) point path of the DeepPhysiNet physics-informed step.
+ *
+ * The reference has no FFI layer: its hot path is Python calling torch ops
+ * (DeepPhysiNet/model/variable_net.py:49-87, model/physics_net.py:41-55,
+ * interface/interface_physics.py:90-185,232-332).  These entry points are what a
+ * ctypes binding on the reference side would call instead;
+ * plain device pointers and sizes, no torch types.  All pointers are DEVICE pointers
+ * unless said otherwise; `stream` is a hipStream_t.  Every call only enqueues work on
+ * `stream` (no allocation, no synchronisation: hipGraph-capturable).  Return value:
+ * 0 on success, otherwise a hipError_t (launch/configuration errors) or -1 (bad argument).
+ *
+ * Precision modes (`prec`): 1 = bf16 MFMA operands, fp32 accumulate ("bf16");
+ *                           2 = bf16 hi+lo split operands, 3 MFMAs per product ("bf16x2", fp32-class).
+ * Everything that is not a GEMM operand (coordinates, positional features, de-normalisation,
+ * residuals, reductions) is fp32 (loss sums fp64) in both modes.
+ */
+#ifndef DPN_HIP_H
+#define DPN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPN_NETS 6          /* u, v, P, T, q, rho   (physics_net.py:49-54) */
+#define DPN_HIDDEN 256
+#define DPN_PE 192
+
+/* Per-VariableNet fp32 tensors of ONE field sample (device pointers).
+ * w1b1 / w2b2 are the hyper-network heads' outputs (variable_net.py:59-65), evec is
+ * fore_h_fc(PE(forecast_h)) (variable_net.py:75-78); the rest are the module's own parameters. */
+typedef struct DpnNetPtrs {
+    const float* w1b1;   /* [256][193]  rows: [w1 (192) | b1]            */
+    const float* w2b2;   /* [256][257]  rows: [w2 (256) | b2]            */
+    const float* evec;   /* [256]                                         */
+    const float* Wd;     /* [256][192]  data_input_fc.weight             */
+    const float* bd;     /* [256]       data_input_fc.bias               */
+    const float* W1;     /* [256][256]  cat_fc1.fc.0.weight              */
+    const float* bf1;    /* [256]       cat_fc1.fc.0.bias                */
+    const float* W2;     /* [256][256]  cat_fc1.fc.2.weight              */
+    const float* bf2;    /* [256]       cat_fc1.fc.2.bias                */
+    const float* wo;     /* [256]       out_fc.weight                    */
+    const float* bo;     /* [1]         out_fc.bias                      */
+} DpnNetPtrs;
+
+/* Gradient destinations, same shapes as DpnNetPtrs (written, not accumulated). */
+typedef struct DpnNetGradPtrs {
+    float* w1b1; float* w2b2; float* evec; float* Wd; float* bd; float* W1; float* bf1; float* W2; float* bf2; float* wo; float* bo;
+} DpnNetGradPtrs;
+
+/* Grid constants of encoding_coord (interface_physics.py:322-332). */
+typedef struct DpnGeometry {
+    float dx, dy;            /* metres                                     */
+    float lon_m1, lat_m1;    /* lon_size-1, lat_size-1                     */
+    float pred_t_span;       /* seconds                                    */
+} DpnGeometry;
+
+/* De-normalisation, clip bounds and loss factors (configs/DeepPhysiNet_NCEP_cfg.py:64-76,139-148). */
+typedef struct DpnPhysics {
+    float mean[DPN_NETS], std[DPN_NETS];
+    float clip_lo[DPN_NETS], clip_hi[DPN_NETS];
+    int   clip_on[DPN_NETS];              /* with_clip && bounds apply to this field (u,v: never)  */
+    float factor[DPN_NETS];               /* motion_u, motion_v, continuous, energy, vapor, gas     */
+} DpnPhysics;
+
+/* Byte sizes of the caller-allocated work buffers for n_points collocation points. */
+typedef struct DpnSizes {
+    int64_t n_pad;           /* points padded to the tile size                              */
+    int64_t packed;          /* packed bf16 weight fragments + fp32 vectors, all 6 nets     */
+    int64_t saved;           /* per-point state saved by dpn_fwd for the backward pass      */
+    int64_t operands;        /* per-point operands written by dpn_bwd_points                */
+    int64_t partials;        /* split-K partial weight gradients                            */
+    int32_t k_splits;        /* number of point ranges dpn_wgrad splits the reduction into  */
+} DpnSizes;
+
+int dpn_version(void);
+int dpn_sizes(int64_t n_points, int prec, DpnSizes* out);
+
+/* fp32 tables: freq32 = 2**linspace(0,4,32), freq16 = 2**linspace(0,4,16) formed in fp32 exactly as
+ * utils/position_encoding.py:27 does.  Copied to the device by the caller (8 + 4 = 48 floats: [32 | 16]). */
+
+/* Weight preparation: fp32 tensors -> MFMA-fragment-ordered bf16 (hi/lo) + permuted fp32 vectors + u = W2^T wo. */
+int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, void* stream);
+
+/* Forward + coordinate Jacobian (replaces PhysicsNet.forward's six VariableNet calls, physics_net.py:49-54,
+ * and the 18 unique autograd.grad derivatives of interface_physics.py:90-95).
+ *   x,y,t [N] raw coordinates (metres, metres, seconds), OR pe_in [N][192]: coordinates already encoded by the
+ *   caller in the reference's SineCosPE channel order (then x,y,t and jac_n must be NULL);
+ *   coord_data [N][6]; freqs [48]; out_n [N][6] normalised fields;
+ *   jac_n [N][6][3] = d out_n / d(x,y,t)  (may be NULL: value-only);
+ *   saved: state for the backward pass (may be NULL: inference only). */
+int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n_points,
+            const float* freqs, const DpnGeometry* geo, const void* packed, int prec,
+            float* out_n, float* jac_n, void* saved, void* stream);
+
+/* inverse_norm + six residual losses (interface_physics.py:97-185,232-262).
+ *   loss_sums [6] fp64: sum over points of residual^2 (un-normalised; the caller zeroes it);
+ *   losses    [6] fp32: factor_i * loss_sums_i / N, written by dpn_residual_finish;
+ *   when g_out != NULL also writes d(sum_i gl_i * loss_i)/d out_n  [N][6] and
+ *   d(...)/d J_xi [N][6][3] (cotangent of the Jacobian w.r.t. the NORMALISED coordinates xi). */
+int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t n_points, const DpnGeometry* geo,
+                 const DpnPhysics* phys, const float* gl /*[6] or NULL*/, double* loss_sums,
+                 float* g_out, float* g_jxi, void* stream);
+int dpn_residual_finish(const double* loss_sums, int64_t n_points, const DpnPhysics* phys, float* losses, void* stream);
+
+/* Backward, stage 1: per-point cotangent streams -> the operands of the weight-gradient reductions.
+ *   g_out [N][6]; g_jxi [N][6][3] or NULL (value-only loss, e.g. the data loss). */
+int dpn_bwd_points(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n_points,
+                   const float* freqs, const DpnGeometry* geo, const void* packed, int prec,
+                   const float* g_out, const float* g_jxi, const void* saved, void* operands, void* stream);
+
+/* Backward, stage 2: weight-gradient reductions over points (split-K partial sums). */
+int dpn_wgrad(int64_t n_points, int prec, const float* g_out, const void* saved, const void* operands, void* partials, void* stream);
+
+/* Backward, stage 3: reduce the partial sums, undo the fragment permutations and assemble every
+ * gradient of DpnNetPtrs (incl. the rank-1 cat_fc1.fc.2 gradients). */
+int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n_points, int prec,
+                     const void* partials, const DpnNetGradPtrs grads[DPN_NETS], void* stream);
+
+/* SmoothL1(beta) data loss on the normalised fields (losses/weights_loss.py:17-20): sum -> loss_sum[0] (fp64),
+ * g_out = gl * factor/(6N) * dSmoothL1 (may be NULL). */
+int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, float beta, float scale,
+                  double* loss_sum, float* g_out, void* stream);
+
+/* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
+int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
