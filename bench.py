@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""Benchmark of the physics-informed training step on MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg2"): one field sample on the 0.25 degree grid (257 x 145 =
+37 265 collocation points, every grid node, t drawn per point), all six primitive-equation residual losses.
+One step = place_one_batch (encoder + hyper-network heads + fused HIP forward/Jacobian + residuals) + backward to
+all 155 parameter tensors + clip_grad_norm_(2.5e7) + Adam step; inputs are resident in HBM.  With N > 1 every rank
+runs its own field sample (weak scaling, as the reference's DistributedSampler does) and gradients are averaged with
+one RCCL all-reduce per step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+ALG_FLOP_FWD_JAC = 11_218_944          # algorithmic FLOP per collocation point, fwd + Jacobian
+ALG_FLOP_STEP = 31_887_360             # fwd + Jacobian + bwd
+EXEC_MAC_FWD = 409_600                 # MACs per point per net actually issued by dpn_fwd_kernel
+MFMA_PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def synth_batch(n_points, device, seed, lon=257, lat=145, dx=27000.0, dy=27000.0):
+    """SURVEY.md 8(d) synthetic inputs; points = grid nodes in row-major order (all of them when n_points = lon*lat)."""
+    g = torch.Generator().manual_seed(seed)
+    field = torch.randn(1, 159, 2405, generator=g)
+    field[:, 155:, :] = torch.rand(1, 4, 2405, generator=g)
+    idx = torch.arange(n_points) % (lon * lat)
+    x = (idx % lon).float() * dx
+    y = (idx // lon).float() * dy
+    t = torch.randint(0, 25, (n_points,), generator=g).float() * 3600.0
+    f = 2.0 * 7.29e-5 * torch.sin((18.0 + y / dy * 0.25) * torch.pi / 180.0)
+    cd = torch.randn(n_points, 6, generator=g)
+    fh = torch.full((1, 1, 1), 24.0 / 360.0)
+    b = dict(field_data=field, forecast_h=fh, x=x.reshape(-1, 1), y=y.reshape(-1, 1), t=t.reshape(-1, 1), f=f.reshape(-1, 1).float(),
+             coord_data=cd)
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def cpu_baseline(sample_points, seed):
+    """The CPU oracle (reference-faithful: 28 autograd.grad calls + double backward) on a bounded sample of the same workload."""
+    from oracle import dpn_oracle as O
+    torch.manual_seed(seed)
+    from deepphysinet_amd.configs import ncep_config
+    from deepphysinet_amd.interface import builder_models
+    m = builder_models(**ncep_config())
+    st = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith('.pe')) for k, v in m.physics_net.state_dict().items()}
+    b = synth_batch(sample_points, 'cpu', seed)
+    geo = O.Geometry()
+    names = O.param_names(st)
+    best = None
+    for it in range(3):
+        x, y, t = (b[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
+        t0 = time.perf_counter()
+        tot = O.place_one_batch(st, x, y, t, b['f'], b['field_data'], b['coord_data'], b['forecast_h'], geo)
+        torch.autograd.grad(tot, [st[n] for n in names])
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = dt if best is None else min(best, dt)
+    return sample_points / best, best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--points', type=int, default=257 * 145)
+    ap.add_argument('--prec', default=os.environ.get('DPN_PREC', 'bf16'), choices=['bf16', 'bf16x2'])
+    ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=2048)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
+    ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
+    args = ap.parse_args()
+
+    from deepphysinet_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the point path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    from deepphysinet_amd.configs import ncep_config
+    from deepphysinet_amd.interface import builder_models
+
+    def build(prec):
+        torch.manual_seed(1)                      # identical random-init weights on every rank
+        m = builder_models(**ncep_config(), precision=prec).to(dev)
+        opt = torch.optim.Adam(m.physics_net.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True, fused=True)
+        return m, opt
+
+    batch = synth_batch(args.points, dev, seed=1 + rank)
+    crit = torch.nn.MSELoss()
+    sync = D.GradientAllReduce() if world > 1 else None
+
+    def make_step(m, opt):
+        lf = m.train_cfg['losses']['loss_factor']
+        params = list(m.physics_net.parameters())
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = m.place_one_batch(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'],
+                                     batch['forecast_h'], crit, lf, 0, 0, dev)
+            loss.backward()
+            if sync is not None:
+                sync(params)
+            torch.nn.utils.clip_grad_norm_(params, max_norm=2.5e7, foreach=True)
+            opt.step()
+            return loss
+        return step
+
+    def run(prec, steps, warmup, use_graph):
+        m, opt = build(prec)
+        step = make_step(m, opt)
+        graph = None
+        if use_graph and world == 1:
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(2):
+                        step()
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_loss = step()
+            except Exception as e:                 # noqa
+                if rank == 0:
+                    print('[bench] hipGraph capture failed (%s: %s); running eager' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+                m, opt = build(prec)
+                step = make_step(m, opt)
+        fn = graph.replay if graph is not None else step
+        for _ in range(warmup):
+            fn()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return m, dt, graph is not None
+
+    m, dt, graphed = run(args.prec, args.steps, args.warmup, not args.no_graph)
+    ms_per_step = dt / args.steps * 1e3
+    pts_per_s = args.points * world * args.steps / dt
+
+    out = {
+        'metric': 'collocation-points/sec (fwd+PDE-Jacobian+bwd)', 'value': pts_per_s, 'unit': 'points/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate' if args.prec == 'bf16' else 'bf16x2 (hi+lo split bf16 MFMA operands), fp32 accumulate',
+        'data': 'synthetic',
+        'config': {'workload': 'configs[1]: 0.25deg grid 257x145 = %d collocation points/GPU/step, one field sample, six PDE residual losses, '
+                               'encoder+hyper-net+fwd+Jacobian+bwd+clip+Adam' % args.points,
+                   'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world},
+        'algorithmic_tflops_step': pts_per_s * ALG_FLOP_STEP / 1e12,
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (dpn_fwd_kernel: fused forward + Jacobian), HIP events on the launch stream
+        import ctypes
+        from deepphysinet_amd import _lib as L
+        from deepphysinet_amd import point_path as PP
+        cfg = m.point_config()
+        with torch.no_grad():
+            heads, evec, statics = m.physics_net.field_weights(batch['field_data'], batch['forecast_h'])
+            x_, y_, t_ = (PP._f32c(batch[k]).reshape(-1) for k in ('x', 'y', 't'))
+            cd_ = PP._f32c(batch['coord_data'])
+            st = [PP._f32c(s) for s in statics]
+            ws = PP._Workspace(args.points, cfg.prec, dev)
+            nets = PP._net_ptrs(PP._f32c(heads), PP._f32c(evec), st)
+            PP._forward_points(cfg, ws, nets, x_, y_, t_, None, cd_, True, True)       # packs weights, allocates saved
+            lib = L.load()
+            out_n = torch.empty((args.points, 6), device=dev)
+            jac_n = torch.empty((args.points, 6, 3), device=dev)
+            geo = cfg.geometry()
+
+            def launch():
+                L.check(lib.dpn_fwd(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), args.points, PP._ptr(PP._freqs(dev)),
+                                    ctypes.byref(geo), PP._ptr(ws.packed), cfg.prec, PP._ptr(out_n), PP._ptr(jac_n), PP._ptr(ws.saved),
+                                    PP._stream()), 'dpn_fwd')
+            for _ in range(3):
+                launch()
+            reps = 20
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                launch()
+            e1.record()
+            torch.cuda.synchronize()
+            k_ms = e0.elapsed_time(e1) / reps
+        ach = args.points * ALG_FLOP_FWD_JAC / (k_ms * 1e-3)
+        nsplit = 3 if args.prec == 'bf16x2' else 1
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'dpn_fwd_kernel<%d>' % (2 if args.prec == 'bf16x2' else 1),
+                           'achieved': ach / 1e12, 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_BF16,
+                           'traffic': None, 'kernel_ms': k_ms,
+                           'algorithmic_flop_per_point': ALG_FLOP_FWD_JAC,
+                           'executed_mfma_tflops': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / 1e12,
+                           'step_frac_of_peak': pts_per_s / world * ALG_FLOP_STEP / MFMA_PEAK_BF16}
+        if not args.no_alt and world == 1:
+            alt = 'bf16x2' if args.prec == 'bf16' else 'bf16'
+            del m
+            torch.cuda.empty_cache()
+            _, dt2, _ = run(alt, max(5, args.steps // 3), 3, not args.no_graph)
+            st2 = max(5, args.steps // 3)
+            out['other_precision_mode'] = {'mode': alt, 'value': args.points * st2 / dt2, 'ms_per_step': dt2 / st2 * 1e3}
+        if not args.no_cpu_baseline and world == 1:
+            torch.set_num_threads(args.cpu_threads or min(32, os.cpu_count() or 1))   # more threads only add OpenMP overhead on these small ops
+            v, secs = cpu_baseline(args.cpu_sample, seed=1)
+            out['cpu_baseline'] = {'value': v, 'unit': 'points/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                   'sample': 'oracle place_one_batch + backward (fp32, 28 autograd.grad calls) on %d points of the same '
+                                             'synthetic field; best of 2 after 1 warm-up, %.1f s per pass' % (args.cpu_sample, secs)}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

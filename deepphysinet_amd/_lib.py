@@ -16,11 +16,11 @@ _NET_FIELDS = ('w1b1', 'w2b2', 'evec', 'Wd', 'bd', 'W1', 'bf1', 'W2', 'bf2', 'wo
 
 
 class DpnNetPtrs(Structure):
-    _fields_ = [(n, c_void_p) for n in _NET_FIELDS]
+    _fields_ = [(n, c_void_p) for n in _NET_FIELDS] + [('ld_w1b1', c_int64), ('ld_w2b2', c_int64)]
 
 
 class DpnNetGradPtrs(Structure):
-    _fields_ = [(n, c_void_p) for n in _NET_FIELDS]
+    _fields_ = [(n, c_void_p) for n in _NET_FIELDS] + [('ld_w1b1', c_int64), ('ld_w2b2', c_int64)]
 
 
 class DpnGeometry(Structure):
@@ -51,6 +51,8 @@ EXPORTS = {
     'dpn_wgrad': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_wgrad_finish': (c_int, [POINTER(DpnNetPtrs), c_void_p, c_int64, c_int, c_void_p, POINTER(DpnNetGradPtrs), c_void_p]),
     'dpn_smooth_l1': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'dpn_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                          c_void_p]),
     'dpn_selftest': (c_int, [c_void_p, c_void_p]),
 }
 

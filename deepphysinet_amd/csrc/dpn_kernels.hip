@@ -33,29 +33,40 @@ typedef unsigned short u16;
 #define DEV __device__ __forceinline__
 
 // ------------------------------------------------------------------------------------------------ small helpers
-DEV u16 f2bf(float x) {                       // round-to-nearest-even, finite inputs
+typedef unsigned int u32;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) u32 u32x4;
+
+DEV u16 f2bf(float x) {                       // round-to-nearest-even, finite inputs (pack kernel)
     unsigned u = __float_as_uint(x);
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (u16)(u >> 16);
 }
 DEV float bf2f(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
+DEV u32 pack2(float a, float b) {             // one v_cvt_pk_bf16_f32
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(u32, __builtin_convertvector(v, bf16x2));
+}
+DEV float bf_lo(u32 w) { return __uint_as_float(w << 16); }
+DEV float bf_hi(u32 w) { return __uint_as_float(w & 0xFFFF0000u); }
 
 template <int NS>
-struct Frag {                                 // one k-step operand fragment (8 bf16 per lane), hi [+ lo]
-    bf16x8 v[NS];
+struct Frag {                                 // one k-step operand fragment: 8 bf16 per lane as 4 packed words, hi [+ lo]
+    u32x4 w[NS];
 };
-
+DEV bf16x8 as_bf(u32x4 w) { return __builtin_bit_cast(bf16x8, w); }
 template <int NS>
-DEV void frag_set(Frag<NS>& f, const int e, float x) {
-    const __bf16 hi = (__bf16)x;
-    f.v[0][e] = hi;
-    if constexpr (NS == 2) f.v[1][e] = (__bf16)(x - (float)hi);
+DEV void frag_set2(Frag<NS>& f, const int p, float a, float b) {      // elements 2p, 2p+1
+    const u32 hi = pack2(a, b);
+    f.w[0][p] = hi;
+    if constexpr (NS == 2) f.w[1][p] = pack2(a - bf_lo(hi), b - bf_hi(hi));
 }
 
 DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-// Bounded-argument sincos: theta in [0, ~40].  Cody-Waite reduction by pi/2 + minimax polynomials, |err| ~1e-7.
-DEV void sincos_bounded(float th, float& s, float& c) {
+// Cody-Waite reduction by pi/2 + minimax polynomials, |err| ~1e-7 for |theta| up to a few hundred.
+DEV void sincos_precise(float th, float& s, float& c) {
     const float k = rintf(th * 0.63661977236758134f);
     float r = fmaf(k, -1.5707963705062866f, th);               // float(pi/2); the fma keeps k*hi exact
     r = fmaf(k, 4.371138828673793e-08f, r);                     // pi/2 - float(pi/2)
@@ -74,6 +85,12 @@ DEV void sincos_bounded(float th, float& s, float& c) {
     s = (q & 2) ? -ss : ss;
     c = ((q + 1) & 2) ? -cc : cc;
 }
+// NS == 1 (plain bf16 operands): the features are rounded to 8 mantissa bits anyway -> hardware v_sin/v_cos
+template <int NS>
+DEV void sincos_t(float th, float& s, float& c) {
+    if constexpr (NS == 1) { s = __sinf(th); c = __cosf(th); }
+    else sincos_precise(th, s, c);
+}
 
 // ------------------------------------------------------------------------------------------------ weight packing
 struct PackArgs {
@@ -86,11 +103,12 @@ DEV float pack_src(const DpnNetPtrs& P, int kb, int lane, int e) {
     const int i = lane & 31, h = lane >> 5;
     if (kb < kS1) {                                   // S0: w1, rows o, K = PE3 slots
         const int T = kb / 12, ks = kb % 12;
-        return P.w1b1[(32 * T + i) * kW1Stride + pe3_ch(ks, h, e)];
-    } else if (kb < kS2) {                            // S1: w2 | Wd interleaved per tile
-        const int rel = kb - kS1, T = rel / 28, k28 = rel % 28;
-        if (k28 < 16) return P.w2b2[(32 * T + i) * kW2Stride + chain_ch(k28, h, e)];
-        return P.Wd[(32 * T + i) * kPe + pe6_ch(k28 - 16, h, e)];
+        return P.w1b1[(32 * T + i) * P.ld_w1b1 + pe3_ch(ks, h, e)];
+    } else if (kb < kS2) {                            // S1: w2 (8 tiles x 16 k-steps), then Wd (8 tiles x 12 k-steps)
+        const int rel = kb - kS1;
+        if (rel < 128) return P.w2b2[(32 * (rel / 16) + i) * P.ld_w2b2 + chain_ch(rel % 16, h, e)];
+        const int r2 = rel - 128;
+        return P.Wd[(32 * (r2 / 12) + i) * kPe + pe6_ch(r2 % 12, h, e)];
     } else if (kb < kS3) {                            // S2: W1 rows o
         const int rel = kb - kS2, T = rel / 16, ks = rel % 16;
         return P.W1[(32 * T + i) * kHidden + chain_ch(ks, h, e)];
@@ -99,10 +117,10 @@ DEV float pack_src(const DpnNetPtrs& P, int kb, int lane, int e) {
         return P.W1[chain_ch(ks, h, e) * kHidden + (32 * T + i)];
     } else if (kb < kS5) {                            // S4: w2^T rows i, K over o
         const int rel = kb - kS4, T = rel / 16, ks = rel % 16;
-        return P.w2b2[chain_ch(ks, h, e) * kW2Stride + (32 * T + i)];
+        return P.w2b2[chain_ch(ks, h, e) * P.ld_w2b2 + (32 * T + i)];
     } else {                                          // S5: w1^T rows rho (PE slots), K over o
         const int rel = kb - kS5, T = rel / 16, ks = rel % 16;
-        return P.w1b1[chain_ch(ks, h, e) * kW1Stride + gpe_row_to_pe3_ch(32 * T + i)];
+        return P.w1b1[chain_ch(ks, h, e) * P.ld_w1b1 + gpe_row_to_pe3_ch(32 * T + i)];
     }
 }
 
@@ -141,8 +159,8 @@ __global__ __launch_bounds__(256) void dpn_pack_vectors_kernel(PackArgs a) {
     const int ch = 32 * T + drow32(r, h);
     float u = 0.f;
     for (int o = 0; o < kHidden; ++o) u = fmaf(P.wo[o], P.W2[o * kHidden + ch], u);
-    vec[kVecB1 * 256 + idx] = P.w1b1[ch * kW1Stride + kPe];
-    vec[kVecCvec * 256 + idx] = P.w2b2[ch * kW2Stride + kHidden] + P.bd[ch] + P.evec[ch];
+    vec[kVecB1 * 256 + idx] = P.w1b1[ch * P.ld_w1b1 + kPe];
+    vec[kVecCvec * 256 + idx] = P.w2b2[ch * P.ld_w2b2 + kHidden] + P.bd[ch] + P.evec[ch];
     vec[kVecBf1 * 256 + idx] = P.bf1[ch];
     vec[kVecU * 256 + idx] = u;
     vec[kVecWo * 256 + idx] = P.wo[ch];
@@ -178,38 +196,33 @@ struct Pipe {
         for (int i = 0; i < NK * NS / 4; ++i) stg[i] = g[i * 256 + threadIdx.x];
         g += NK * NS * 64;
     }
-    template <int NK> DEV void commit(int which) {
-        uint4* d = reinterpret_cast<uint4*>(lds + which * kBufBytes);
+    template <int NK> DEV void commit() {
+        uint4* d = reinterpret_cast<uint4*>(lds + (cur ^ 1) * kBufBytes);
 #pragma unroll
         for (int i = 0; i < NK * NS / 4; ++i) d[i * 256 + threadIdx.x] = stg[i];
     }
-    template <int NK> DEV void prime() { fetch<NK>(); commit<NK>(0); __syncthreads(); cur = 0; }
+    template <int NK> DEV void prime() { cur = 1; fetch<NK>(); commit<NK>(); __syncthreads(); cur = 0; }
+    DEV void flip() { __syncthreads(); cur ^= 1; }
     DEV const char* cur_buf() const { return lds + cur * kBufBytes; }
 };
 
-template <int NS, int NK>
+// SWAP = false: Out[channel][point] (+)= W[channel][k] * Act[k][point]   (weights as A, chained layout)
+// SWAP = true : Out[point][channel] (+)= Act[point][k] * W[channel][k]   (same packed weights as B: the result lands
+//               channel-per-lane / points-in-registers, which is the K-operand layout of the weight-gradient GEMMs)
+template <int NS, int NK, bool SWAP>
 DEV void mma_chunk(const char* buf, const Frag<NS>* act, f32x16& acc) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-        const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(buf + ((ks * NS) * 64 + lane) * 16);
+        const bf16x8 whi = *reinterpret_cast<const bf16x8*>(buf + ((ks * NS) * 64 + lane) * 16);
         if constexpr (NS == 2) {
-            const bf16x8 alo = *reinterpret_cast<const bf16x8*>(buf + ((ks * NS + 1) * 64 + lane) * 16);
-            acc = mfma(ahi, act[ks].v[1], acc);
-            acc = mfma(alo, act[ks].v[0], acc);
+            const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(buf + ((ks * NS + 1) * 64 + lane) * 16);
+            if constexpr (SWAP) { acc = mfma(as_bf(act[ks].w[1]), whi, acc); acc = mfma(as_bf(act[ks].w[0]), wlo, acc); }
+            else { acc = mfma(whi, as_bf(act[ks].w[1]), acc); acc = mfma(wlo, as_bf(act[ks].w[0]), acc); }
         }
-        acc = mfma(ahi, act[ks].v[0], acc);
+        if constexpr (SWAP) acc = mfma(as_bf(act[ks].w[0]), whi, acc);
+        else acc = mfma(whi, as_bf(act[ks].w[0]), acc);
     }
-}
-
-// one pipeline step: prefetch the next chunk (NKN k-steps, 0 = none), multiply the current one (NK k-steps)
-template <int NS, int NK, int NKN>
-DEV void step(Pipe<NS>& p, const Frag<NS>* act, f32x16& acc) {
-    if constexpr (NKN > 0) p.template fetch<NKN>();
-    mma_chunk<NS, NK>(p.cur_buf(), act, acc);
-    if constexpr (NKN > 0) p.template commit<NKN>(p.cur ^ 1);
-    __syncthreads();
-    p.cur ^= 1;
 }
 
 // ------------------------------------------------------------------------------------------------ per-lane context
@@ -220,6 +233,7 @@ struct Lane {
     float xi[3];       // normalised coordinates
     float fr32[16];    // freq32[8*(m>>2) + 4h + (m&3)]
     float fr16[8];     // freq16[8*(m>>2) + 4h + (m&3)]
+    u32x4 idA, idB;       // identity B-operand fragments for the MFMA transposes (columns 0..15 / 16..31)
 };
 
 DEV void lane_init(Lane& L, const float* x, const float* y, const float* t, int64_t n, const float* freqs, const DpnGeometry& geo,
@@ -240,9 +254,17 @@ DEV void lane_init(Lane& L, const float* x, const float* y, const float* t, int6
     for (int m = 0; m < 16; ++m) L.fr32[m] = freqs[8 * (m >> 2) + 4 * L.h + (m & 3)];
 #pragma unroll
     for (int m = 0; m < 8; ++m) L.fr16[m] = freqs[32 + 8 * (m >> 2) + 4 * L.h + (m & 3)];
+    // identity: column jj of a 32-column tile <- k-slot (h = (jj>>3)&1, e = jj&7) of k-step (jj>>4)
+    const int mine = (((L.j >> 3) & 1) == L.h) ? (L.j & 7) : -1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const u32 v = ((mine == 2 * p) ? 0x3F80u : 0u) | ((mine == 2 * p + 1) ? 0x3F800000u : 0u);
+        L.idA[p] = (L.j < 16) ? v : 0u;
+        L.idB[p] = (L.j >= 16) ? v : 0u;
+    }
 }
 
-// coordinate PE fragments; with (g, gj) != 0 builds Z0 = g*pe + sum_c gj[c] * dpe/dxi_c instead (backward stream)
+// coordinate PE fragments; BWD builds Z0 = g*pe + sum_c gj[c] * dpe/dxi_c instead (backward stream)
 template <int NS, bool BWD>
 DEV void build_pe3(const Lane& L, Frag<NS>* act, float g, const float* gj) {
 #pragma unroll
@@ -252,14 +274,12 @@ DEV void build_pe3(const Lane& L, Frag<NS>* act, float g, const float* gj) {
         for (int p = 0; p < 4; ++p) {
             const float fr = L.fr32[4 * (ks & 3) + p];
             float s, co;
-            sincos_bounded(L.xi[c] * fr, s, co);
+            sincos_t<NS>(L.xi[c] * fr, s, co);
             if constexpr (BWD) {
                 const float gf = gj[c] * fr;
-                frag_set<NS>(act[ks], 2 * p, fmaf(g, s, gf * co));
-                frag_set<NS>(act[ks], 2 * p + 1, fmaf(g, co, -gf * s));
+                frag_set2<NS>(act[ks], p, fmaf(g, s, gf * co), fmaf(g, co, -gf * s));
             } else {
-                frag_set<NS>(act[ks], 2 * p, s);
-                frag_set<NS>(act[ks], 2 * p + 1, co);
+                frag_set2<NS>(act[ks], p, s, co);
             }
         }
     }
@@ -271,10 +291,10 @@ DEV void load_pe3(const float* row, int h, Frag<NS>* act, float g) {
 #pragma unroll
     for (int ks = 0; ks < 12; ++ks)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) frag_set<NS>(act[ks], e, g * row[pe3_ch(ks, h, e)]);
+        for (int p = 0; p < 4; ++p) frag_set2<NS>(act[ks], p, g * row[pe3_ch(ks, h, 2 * p)], g * row[pe3_ch(ks, h, 2 * p + 1)]);
 }
 
-// data PE fragments (SineCosPE(6,16) of coord_data, variable_net.py:73), optionally scaled by g
+// data PE fragments (SineCosPE(6,16) of coord_data, variable_net.py:73), scaled by g
 template <int NS>
 DEV void build_pe6(const Lane& L, const float* cd6, Frag<NS>* act, float g) {
 #pragma unroll
@@ -282,70 +302,97 @@ DEV void build_pe6(const Lane& L, const float* cd6, Frag<NS>* act, float g) {
         const float v = cd6[ks >> 1];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const float fr = L.fr16[4 * (ks & 1) + p];
-            const float th = v * fr;
-            // coord_data is N(0,1)-like but unbounded: fall back to the library for large arguments
             float s, co;
-            if (fabsf(th) < 40.f) sincos_bounded(fabsf(th), s, co), s = (th < 0.f) ? -s : s;
-            else sincosf(th, &s, &co);
-            frag_set<NS>(act[ks], 2 * p, g * s);
-            frag_set<NS>(act[ks], 2 * p + 1, g * co);
+            sincos_t<NS>(v * L.fr16[4 * (ks & 1) + p], s, co);
+            frag_set2<NS>(act[ks], p, g * s, g * co);
         }
     }
 }
 
+DEV void acc_init_vec(f32x16& acc, const float* vec_lds, int which, int h, int T, float scale) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(vec_lds + which * 256 + h * 128 + T * 16 + 4 * q);
+        acc[4 * q] = scale * b.x; acc[4 * q + 1] = scale * b.y; acc[4 * q + 2] = scale * b.z; acc[4 * q + 3] = scale * b.w;
+    }
+}
 DEV float4 ld_vec4(const float* vec_lds, int which, int h, int T, int q4) {
     return *reinterpret_cast<const float4*>(vec_lds + which * 256 + h * 128 + T * 16 + 4 * q4);
 }
 
+// ------------------------------------------------------------------------------------------------ K-layout operand matrices
+// Every matrix the points-reduction GEMMs consume is stored "channel-per-lane": for each 32-point tile and each 32-column
+// tile, lane (col = lane&31, h = lane>>5) owns 16 bf16 = the values of its column at points drow32(r,h), r = 0..15, i.e.
+// exactly the A/B fragments of v_mfma_f32_32x32x16_bf16 with K = points (k-step a = registers 8a..8a+7).  Columns are in
+// SLOT order (column 32*ct + jj <-> k-step 2ct + (jj>>4), slot (h=(jj>>3)&1, e=jj&7)).
+// A matrix held point-per-lane (as chained fragments) is brought into this layout by multiplying with an identity B
+// operand: one extra MFMA per 16 channels instead of an LDS round trip.
+struct KMat {
+    char* base;
+    int64_t tiles32;
+    int ct_per_tile;      // column tiles: 8 (256 columns) or 6 (192)
+};
+DEV char* kmat_ptr(const KMat& m, int net, int ns, int s, int64_t tile32, int ct, int lane) {
+    return m.base + (((((int64_t)net * ns + s) * m.tiles32 + tile32) * m.ct_per_tile + ct) * 64 + lane) * 32;
+}
+DEV void store_d_as_k(char* dst, const f32x16& d) {
+    uint4 a, b;
+    a.x = pack2(d[0], d[1]); a.y = pack2(d[2], d[3]); a.z = pack2(d[4], d[5]); a.w = pack2(d[6], d[7]);
+    b.x = pack2(d[8], d[9]); b.y = pack2(d[10], d[11]); b.z = pack2(d[12], d[13]); b.w = pack2(d[14], d[15]);
+    reinterpret_cast<uint4*>(dst)[0] = a;
+    reinterpret_cast<uint4*>(dst)[1] = b;
+}
+// transpose-store the two fragments (k-steps 2ct, 2ct+1) that make up column tile ct; zero rows of invalid points
+template <int NS, int NSTORE>
+DEV void store_tile_k(const KMat& m, int net, int64_t tile32, int ct, const Lane& L, const Frag<NS>& f0, const Frag<NS>& f1, bool partial) {
+#pragma unroll
+    for (int s = 0; s < NSTORE; ++s) {
+        u32x4 a0 = f0.w[s], a1 = f1.w[s];
+        if (partial && !L.valid) { a0 = (u32x4)0u; a1 = (u32x4)0u; }
+        f32x16 d = (f32x16)0.f;
+        d = mfma(as_bf(a0), as_bf(L.idA), d);
+        d = mfma(as_bf(a1), as_bf(L.idB), d);
+        store_d_as_k(kmat_ptr(m, net, NSTORE, s, tile32, ct, L.lane), d);
+    }
+}
+
 // saved-state / operand addressing ---------------------------------------------------------------------------
 struct SavedView {       // written by dpn_fwd
-    char* V;             // [6][NS][n_pad][256] bf16, slot-ordered columns
-    char* T1;            // same
+    KMat V, T1;          // [6][NS] x 256 columns
+    KMat M2;             // [6][1]  x 256 columns, relu-2 mask as bf16 0/1
     uint4* m1;           // [6][tiles32][64] lane-format bits of relu mask 1
-    unsigned* m2k;       // [6][tiles32][256] point-bits per SLOT of relu mask 2
 };
 DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
     SavedView s;
     char* b = reinterpret_cast<char*>(base);
     const int64_t mat = (int64_t)kNets * ns * n_pad * 512;
-    s.V = b; s.T1 = b + mat;
-    s.m1 = reinterpret_cast<uint4*>(b + 2 * mat);
-    s.m2k = reinterpret_cast<unsigned*>(b + 2 * mat + (int64_t)kNets * n_pad * 32);
+    const int64_t tiles32 = n_pad / 32;
+    s.V = KMat{b, tiles32, 8};
+    s.T1 = KMat{b + mat, tiles32, 8};
+    s.M2 = KMat{b + 2 * mat, tiles32, 8};
+    s.m1 = reinterpret_cast<uint4*>(b + 2 * mat + (int64_t)kNets * n_pad * 512);
     return s;
 }
-static int64_t saved_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + 2 * (int64_t)kNets * n_pad * 32; }
+static int64_t saved_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 512 + (int64_t)kNets * n_pad * 32; }
 
 struct OperandView {     // written by dpn_bwd_points
-    char* Z1;            // [6][NS][n_pad][256]
-    char* Z;             // [6][NS][n_pad][256]
-    char* Z0;            // [6][NS][n_pad][192]
-    char* G6;            // [6][NS][n_pad][192]   gout * pe6
+    KMat Z1, Z;          // [6][NS] x 256
+    KMat Z0, G6;         // [6][NS] x 192   (G6 = gout * pe6)
+    float* gnet;         // [6][n_pad]  per-net cotangent of the normalised field, zero for padding points
 };
 DEV OperandView operand_view(void* base, int64_t n_pad, int ns) {
     OperandView o;
     char* b = reinterpret_cast<char*>(base);
     const int64_t m256 = (int64_t)kNets * ns * n_pad * 512, m192 = (int64_t)kNets * ns * n_pad * 384;
-    o.Z1 = b; o.Z = b + m256; o.Z0 = b + 2 * m256; o.G6 = b + 2 * m256 + m192;
+    const int64_t tiles32 = n_pad / 32;
+    o.Z1 = KMat{b, tiles32, 8};
+    o.Z = KMat{b + m256, tiles32, 8};
+    o.Z0 = KMat{b + 2 * m256, tiles32, 6};
+    o.G6 = KMat{b + 2 * m256 + m192, tiles32, 6};
+    o.gnet = reinterpret_cast<float*>(b + 2 * m256 + 2 * m192);
     return o;
 }
-static int64_t operand_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + 2 * (int64_t)kNets * ns * n_pad * 384; }
-
-// store NKS fragments of one point row: column (slot) 16*ks + 8*h + e
-template <int NS, int NKS>
-DEV void store_row_frags(char* mat, int net, int64_t n_pad, int64_t row, int h, const Frag<NS>* act, bool zero) {
-    constexpr int kRowBytes = NKS * 32;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        char* p = mat + (((int64_t)net * NS + s) * n_pad + row) * kRowBytes + h * 16;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            bf16x8 v = act[ks].v[s];
-            if (zero) v = (bf16x8)(__bf16)0.f;
-            *reinterpret_cast<bf16x8*>(p + ks * 32) = v;
-        }
-    }
-}
+static int64_t operand_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + 2 * (int64_t)kNets * ns * n_pad * 384 + (int64_t)kNets * n_pad * 4; }
 
 // ------------------------------------------------------------------------------------------------ forward + Jacobian
 struct FwdArgs {
@@ -357,6 +404,17 @@ struct FwdArgs {
     float* jac_n;
     void* saved;
 };
+
+// One pipeline step on output tile T: prefetch the next chunk (NKN k-steps, 0 = none), multiply the current one, run the
+// epilogue of the PREVIOUS tile in the shadow of these MFMAs (it only touches that tile's accumulator), publish the prefetch.
+#define DPN_STEP(NK, NKN, SWAP, ACT, ACC, EPI_PREV)                                  \
+    do {                                                                             \
+        if constexpr ((NKN) > 0) pipe.template fetch<(NKN)>();                       \
+        mma_chunk<NS, (NK), (SWAP)>(pipe.cur_buf(), (ACT), (ACC));                   \
+        EPI_PREV;                                                                    \
+        if constexpr ((NKN) > 0) pipe.template commit<(NKN)>();                      \
+        pipe.flip();                                                                 \
+    } while (0)
 
 template <int NS>
 __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
@@ -374,65 +432,48 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     Lane L;
     lane_init(L, a.x, a.y, a.t, a.n, a.freqs, a.geo, tile32);
     const int h = L.h;
+    const bool partial = (tile32 * 32 + 32 > a.n);
     const int64_t pc = L.valid ? L.pt : (a.n - 1);
     float cd6[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) cd6[c] = a.coord_data[pc * 6 + c];
     const float ref_data = a.coord_data[pc * 6 + net];
+    SavedView sv = saved_view(a.saved, a.n_pad, NS);
+    const bool save = a.saved != nullptr;
 
     Pipe<NS> pipe;
     pipe.init(pk, lds_w);
-    pipe.template prime<12>();          // first chunk: w1 tile 0 (also publishes lds_vec)
+    pipe.template prime<12>();          // first chunk: w1 tile 0 (the barrier inside also publishes lds_vec)
 
     f32x16 acc[8];
-    unsigned m1w[4] = {0, 0, 0, 0};
+    u32 m1w[4] = {0u, 0u, 0u, 0u};
+    Frag<NS> actA[16], actB[16];
 
-    // ---------------- L1: pre1 = w1 . pe + b1 ; h1 = relu
-    Frag<NS> actA[16];
+    // ---------------- L1: pre1 = w1 . pe + b1 ; h1 = relu -> actA ; relu mask -> m1w
+    auto epi1 = [&](const int T) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float p0 = acc[T][r], p1 = acc[T][r + 1];
+            m1w[T >> 1] |= ((p0 > 0.f) ? (1u << (16 * (T & 1) + r)) : 0u) | ((p1 > 0.f) ? (2u << (16 * (T & 1) + r)) : 0u);
+            frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, fmaxf(p0, 0.f), fmaxf(p1, 0.f));
+        }
+    };
     {
         Frag<NS> pe[12];
         if (a.pe_in) load_pe3<NS>(a.pe_in + pc * kPe, h, pe, 1.0f);     // caller-encoded coordinates (PhysicsNet.forward surface)
         else build_pe3<NS, false>(L, pe, 0.f, nullptr);
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = ld_vec4(lds_vec, kVecB1, h, T, q);
-                acc[T][4 * q] = b.x; acc[T][4 * q + 1] = b.y; acc[T][4 * q + 2] = b.z; acc[T][4 * q + 3] = b.w;
-            }
-            if (T < 7) step<NS, 12, 12>(pipe, pe, acc[T]);
-            else step<NS, 12, 16>(pipe, pe, acc[T]);        // next: w2 tile 0
+            acc_init_vec(acc[T], lds_vec, kVecB1, h, T, 1.0f);
+            if (T == 0) DPN_STEP(12, 12, false, pe, acc[T], (void)0);
+            else if (T < 7) DPN_STEP(12, 12, false, pe, acc[T], epi1(T - 1));
+            else DPN_STEP(12, 16, false, pe, acc[T], epi1(T - 1));          // next: w2 tile 0
         }
+        epi1(7);
     }
-#pragma unroll
-    for (int T = 0; T < 8; ++T) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pre = acc[T][r];
-            const bool on = pre > 0.f;
-            if (on) m1w[T >> 1] |= 1u << (16 * (T & 1) + r);
-            frag_set<NS>(actA[2 * T + (r >> 3)], r & 7, on ? pre : 0.f);
-        }
-    }
-    // ---------------- L2 + data: c = w2 . h1 + Wd . pe6 + (b2 + bd + e)
+    // ---------------- L2 + data: c = w2 . h1 + Wd . pe6 + (b2 + bd + e) -> actB ; cdot = wo . c
     float cdot = 0.f;
-    Frag<NS> actB[16];
-    {
-        Frag<NS> pe6[12];
-        build_pe6<NS>(L, cd6, pe6, 1.0f);
-#pragma unroll
-        for (int T = 0; T < 8; ++T) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = ld_vec4(lds_vec, kVecCvec, h, T, q);
-                acc[T][4 * q] = b.x; acc[T][4 * q + 1] = b.y; acc[T][4 * q + 2] = b.z; acc[T][4 * q + 3] = b.w;
-            }
-            step<NS, 16, 12>(pipe, actA, acc[T]);                       // next: Wd tile T
-            step<NS, 12, 16>(pipe, pe6, acc[T]);                        // next: w2 tile T+1, or W1 tile 0
-        }
-    }
-#pragma unroll
-    for (int T = 0; T < 8; ++T) {
+    auto epi2 = [&](const int T) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 w = ld_vec4(lds_vec, kVecWo, h, T, q);
@@ -440,107 +481,116 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
             cdot = fmaf(w.z, acc[T][4 * q + 2], cdot); cdot = fmaf(w.w, acc[T][4 * q + 3], cdot);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) frag_set<NS>(actB[2 * T + (r >> 3)], r & 7, acc[T][r]);
-    }
-    // ---------------- fc1: pre2 = W1 . c + bf1 ; a = relu ; out = u.a + 2 wo.c + const
+        for (int r = 0; r < 16; r += 2) frag_set2<NS>(actB[2 * T + (r >> 3)], (r & 7) >> 1, acc[T][r], acc[T][r + 1]);
+    };
+    {
+        // pass A: all eight tiles of w2 . h1 (h1 = actA dies here); pass B: + Wd . pe6, epilogue one tile late
 #pragma unroll
-    for (int T = 0; T < 8; ++T) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b = ld_vec4(lds_vec, kVecBf1, h, T, q);
-            acc[T][4 * q] = b.x; acc[T][4 * q + 1] = b.y; acc[T][4 * q + 2] = b.z; acc[T][4 * q + 3] = b.w;
+        for (int T = 0; T < 8; ++T) {
+            acc_init_vec(acc[T], lds_vec, kVecCvec, h, T, 1.0f);
+            if (T < 7) DPN_STEP(16, 16, false, actA, acc[T], (void)0);
+            else DPN_STEP(16, 12, false, actA, acc[T], (void)0);               // next: Wd tile 0
         }
-        step<NS, 16, 16>(pipe, actB, acc[T]);                           // next: W1 tile T+1, or W1^T tile 0
-    }
-    float adot = 0.f;
-    unsigned m2own[4] = {0, 0, 0, 0};          // lane L' = 8T + 2g + h' owns the point-bit words of slots 4L'..4L'+3
+        Frag<NS> pe6[12];
+        build_pe6<NS>(L, cd6, pe6, 1.0f);
 #pragma unroll
-    for (int T = 0; T < 8; ++T) {
+        for (int T = 0; T < 8; ++T) {
+            if (T == 0) DPN_STEP(12, 12, false, pe6, acc[T], (void)0);
+            else if (T < 7) DPN_STEP(12, 12, false, pe6, acc[T], epi2(T - 1));
+            else DPN_STEP(12, 16, false, pe6, acc[T], epi2(T - 1));            // next: W1 tile 0
+        }
+        epi2(7);
+    }
+    // ---------------- fc1: pre2 = W1 . c + bf1 ; a = relu ; out = u.a + 2 wo.c + const ; t2 = m2 (.) u -> actA ; M2 -> saved
+    float adot = 0.f;
+    auto epi3 = [&](const int T) __attribute__((always_inline)) {
+        Frag<1> mk0, mk1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 u4 = ld_vec4(lds_vec, kVecU, h, T, q);
             const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; i += 2) {
                 const int r = 4 * q + i;
-                const float pre = acc[T][r];
-                const bool on = (pre > 0.f) && L.valid;
-                adot = fmaf(on ? pre : 0.f, uu[i], adot);
-                frag_set<NS>(actA[2 * T + (r >> 3)], r & 7, on ? uu[i] : 0.f);     // t2 = m2 (.) u
-                const unsigned long long bal = __ballot(on);
-                // channel 32T + 8q + 4h' + i  ->  slot 32T + 16(q>>1) + 8h' + 4(q&1) + i ; owner lane = slot>>2, word = i
-                const int own0 = 8 * T + 4 * (q >> 1) + (q & 1);                    // h' = 0
-                if (L.lane == own0) m2own[i] = (unsigned)bal;
-                if (L.lane == own0 + 2) m2own[i] = (unsigned)(bal >> 32);           // h' = 1: slot + 8 -> lane + 2
+                const float p0 = acc[T][r], p1 = acc[T][r + 1];
+                const bool on0 = p0 > 0.f, on1 = p1 > 0.f;
+                adot = fmaf(fmaxf(p0, 0.f), uu[i], adot);
+                adot = fmaf(fmaxf(p1, 0.f), uu[i + 1], adot);
+                frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, on0 ? uu[i] : 0.f, on1 ? uu[i + 1] : 0.f);
+                const u32 mw = (on0 ? 0x3F80u : 0u) | (on1 ? 0x3F800000u : 0u);
+                if (r < 8) mk0.w[0][(r & 7) >> 1] = mw; else mk1.w[0][(r & 7) >> 1] = mw;
             }
         }
+        if (save) store_tile_k<1, 1>(sv.M2, net, tile32, T, L, mk0, mk1, partial);
+    };
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        acc_init_vec(acc[T], lds_vec, kVecBf1, h, T, 1.0f);
+        if (T == 0) DPN_STEP(16, 16, false, actB, acc[T], (void)0);            // next: W1 tile T+1, or W1^T tile 0
+        else DPN_STEP(16, 16, false, actB, acc[T], epi3(T - 1));
     }
+    epi3(7);
     {
         float o = adot + 2.0f * cdot;
         o += __shfl_xor(o, 32);
         if (L.valid && h == 0) a.out_n[L.pt * 6 + net] = o + lds_vec[kNumVecs * 256] + ref_data;   // + ref_data (variable_net.py:86)
     }
-    SavedView sv;
-    if (a.saved) {
-        sv = saved_view(a.saved, a.n_pad, NS);
-        const int64_t tiles32 = a.n_pad / 32;
-        sv.m1[((int64_t)net * tiles32 + tile32) * 64 + L.lane] = make_uint4(m1w[0], m1w[1], m1w[2], m1w[3]);
-        reinterpret_cast<uint4*>(sv.m2k)[((int64_t)net * tiles32 + tile32) * 64 + L.lane] = make_uint4(m2own[0], m2own[1], m2own[2], m2own[3]);
-    }
-    if (!a.saved && !a.jac_n) return;
-    // ---------------- reverse sweep: v = W1^T t2 + 2 wo
+    if (save) sv.m1[((int64_t)net * (a.n_pad / 32) + tile32) * 64 + L.lane] = make_uint4(m1w[0], m1w[1], m1w[2], m1w[3]);
+    if (!save && !a.jac_n) return;
+    // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> actB (+ saved V)
+    auto epiv = [&](const int T) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) frag_set2<NS>(actB[2 * T + (r >> 3)], (r & 7) >> 1, acc[T][r], acc[T][r + 1]);
+        if (save) store_tile_k<NS, NS>(sv.V, net, tile32, T, L, actB[2 * T], actB[2 * T + 1], partial);
+    };
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 w = ld_vec4(lds_vec, kVecWo, h, T, q);
-            acc[T][4 * q] = 2.f * w.x; acc[T][4 * q + 1] = 2.f * w.y; acc[T][4 * q + 2] = 2.f * w.z; acc[T][4 * q + 3] = 2.f * w.w;
-        }
-        step<NS, 16, 16>(pipe, actA, acc[T]);                           // next: W1^T tile T+1, or w2^T tile 0
+        acc_init_vec(acc[T], lds_vec, kVecWo, h, T, 2.0f);
+        if (T == 0) DPN_STEP(16, 16, false, actA, acc[T], (void)0);            // next: W1^T tile T+1, or w2^T tile 0
+        else DPN_STEP(16, 16, false, actA, acc[T], epiv(T - 1));
     }
+    epiv(7);
+    // ---------------- y = w2^T v ; t1 = m1 (.) y -> actA (+ saved T1)
+    auto epiy = [&](const int T) __attribute__((always_inline)) {
 #pragma unroll
-    for (int T = 0; T < 8; ++T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) frag_set<NS>(actB[2 * T + (r >> 3)], r & 7, acc[T][r]);
-    if (a.saved) store_row_frags<NS, 16>(sv.V, net, a.n_pad, tile32 * 32 + L.j, h, actB, !L.valid);
-    // ---------------- y = w2^T v ; t1 = m1 (.) y
+        for (int r = 0; r < 16; r += 2) {
+            const u32 bits = m1w[T >> 1] >> (16 * (T & 1) + r);
+            frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, (bits & 1u) ? acc[T][r] : 0.f, (bits & 2u) ? acc[T][r + 1] : 0.f);
+        }
+        if (save) store_tile_k<NS, NS>(sv.T1, net, tile32, T, L, actA[2 * T], actA[2 * T + 1], partial);
+    };
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         acc[T] = (f32x16)0.f;
-        if (T < 7) step<NS, 16, 16>(pipe, actB, acc[T]);
-        else if (a.jac_n) step<NS, 16, 16>(pipe, actB, acc[T]);        // next: w1^T tile 0
-        else step<NS, 16, 0>(pipe, actB, acc[T]);
+        if (T == 0) DPN_STEP(16, 16, false, actB, acc[T], (void)0);
+        else if (T < 7) DPN_STEP(16, 16, false, actB, acc[T], epiy(T - 1));
+        else if (a.jac_n) DPN_STEP(16, 16, false, actB, acc[T], epiy(T - 1));  // next: w1^T tile 0
+        else DPN_STEP(16, 0, false, actB, acc[T], epiy(T - 1));
     }
-#pragma unroll
-    for (int T = 0; T < 8; ++T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool on = (m1w[T >> 1] >> (16 * (T & 1) + r)) & 1u;
-            frag_set<NS>(actA[2 * T + (r >> 3)], r & 7, on ? acc[T][r] : 0.f);
-        }
-    if (a.saved) store_row_frags<NS, 16>(sv.T1, net, a.n_pad, tile32 * 32 + L.j, h, actA, !L.valid);
+    epiy(7);
     if (!a.jac_n) return;
     // ---------------- gpe = w1^T t1 (6 tiles), contracted with d(pe)/d(xi) in registers
-#pragma unroll
-    for (int T = 0; T < 6; ++T) {
-        acc[T] = (f32x16)0.f;
-        if (T < 5) step<NS, 16, 16>(pipe, actA, acc[T]);
-        else step<NS, 16, 0>(pipe, actA, acc[T]);
-    }
     float jc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int T = 0; T < 6; ++T) {
+    auto epij = [&](const int T) __attribute__((always_inline)) {
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {                // register pair (sin, cos) of one angle
             const int r = 2 * rp;
             const int ks = 2 * T + (r >> 3), p = (r & 7) >> 1, c = ks >> 2;
             const float fr = L.fr32[4 * (ks & 3) + p];
             float s, co;
-            sincos_bounded(L.xi[c] * fr, s, co);
+            sincos_t<NS>(L.xi[c] * fr, s, co);
             jc[c] = fmaf(acc[T][r], fr * co, jc[c]);
             jc[c] = fmaf(acc[T][r + 1], -fr * s, jc[c]);
         }
+    };
+#pragma unroll
+    for (int T = 0; T < 6; ++T) {
+        acc[T] = (f32x16)0.f;
+        if (T == 0) DPN_STEP(16, 16, false, actA, acc[T], (void)0);
+        else if (T < 5) DPN_STEP(16, 16, false, actA, acc[T], epij(T - 1));
+        else DPN_STEP(16, 0, false, actA, acc[T], epij(T - 1));
     }
+    epij(5);
 #pragma unroll
     for (int c = 0; c < 3; ++c) jc[c] += __shfl_xor(jc[c], 32);
     if (L.valid && h == 0) {
@@ -698,7 +748,7 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
     float cd6[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) cd6[c] = a.coord_data[pc * 6 + c];
-    const float g = L.valid ? a.g_out[pc * 6 + net] : 0.f;
+    const float g = L.valid ? a.g_out[pc * 6 + net] : 0.f;         // padding points carry a zero cotangent: every operand row is zero
     float gj[3] = {0.f, 0.f, 0.f};
     if (a.g_jxi && L.valid) {
 #pragma unroll
@@ -708,8 +758,15 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
     const int64_t tiles32 = a.n_pad / 32;
     const uint4 m1v = sv.m1[((int64_t)net * tiles32 + tile32) * 64 + L.lane];
-    const unsigned m1w[4] = {m1v.x, m1v.y, m1v.z, m1v.w};
-    const int64_t row = tile32 * 32 + L.j;
+    const u32 m1w[4] = {m1v.x, m1v.y, m1v.z, m1v.w};
+    if (h == 0) ov.gnet[(int64_t)net * a.n_pad + tile32 * 32 + L.j] = g;
+    // cotangents of the 16 points this lane holds in the channel-per-lane (SWAP) accumulator layout
+    float g16[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t p = tile32 * 32 + drow32(r, h);
+        g16[r] = (p < a.n) ? a.g_out[p * 6 + net] : 0.f;
+    }
 
     Pipe<NS> pipe;
     pipe.init(pk, lds_w);
@@ -717,61 +774,79 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 
     f32x16 acc[8];
     Frag<NS> actA[16];
-    {   // Z0 = g * pe + sum_c gJ_c * dpe/dxi_c ; Z1 = m1 (.) (w1 Z0 + g b1)
+    // ---------------- Z0 = g * pe + sum_c gJ_c * dpe/dxi_c ; Z1 = m1 (.) (w1 Z0 + g b1)
+    auto epi1 = [&](const int T) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const u32 bits = m1w[T >> 1] >> (16 * (T & 1) + r);
+            frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, (bits & 1u) ? acc[T][r] : 0.f, (bits & 2u) ? acc[T][r + 1] : 0.f);
+        }
+        store_tile_k<NS, NS>(ov.Z1, net, tile32, T, L, actA[2 * T], actA[2 * T + 1], false);
+    };
+    {
         Frag<NS> z0[12];
         if (a.pe_in) load_pe3<NS>(a.pe_in + pc * kPe, h, z0, g);
         else build_pe3<NS, true>(L, z0, g, gj);
-        store_row_frags<NS, 12>(ov.Z0, net, a.n_pad, row, h, z0, false);
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) store_tile_k<NS, NS>(ov.Z0, net, tile32, ct, L, z0[2 * ct], z0[2 * ct + 1], false);
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = ld_vec4(lds_vec, kVecB1, h, T, q);
-                acc[T][4 * q] = g * b.x; acc[T][4 * q + 1] = g * b.y; acc[T][4 * q + 2] = g * b.z; acc[T][4 * q + 3] = g * b.w;
-            }
-            if (T < 7) step<NS, 12, 12>(pipe, z0, acc[T]);
-            else step<NS, 12, 16>(pipe, z0, acc[T]);
+            acc_init_vec(acc[T], lds_vec, kVecB1, h, T, g);
+            if (T == 0) DPN_STEP(12, 12, false, z0, acc[T], (void)0);
+            else if (T < 7) DPN_STEP(12, 12, false, z0, acc[T], epi1(T - 1));
+            else DPN_STEP(12, 16, false, z0, acc[T], epi1(T - 1));
         }
+        epi1(7);
     }
-#pragma unroll
-    for (int T = 0; T < 8; ++T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool on = (m1w[T >> 1] >> (16 * (T & 1) + r)) & 1u;
-            frag_set<NS>(actA[2 * T + (r >> 3)], r & 7, on ? acc[T][r] : 0.f);
-        }
-    store_row_frags<NS, 16>(ov.Z1, net, a.n_pad, row, h, actA, false);
-    {   // Z = w2 Z1 + Wd (g pe6) + g (b2 + bd + e)
+    // ---------------- Z = w2 Z1 + Wd (g pe6) + g (b2 + bd + e), computed channel-per-lane (SWAP) and stored as is
+    {
         Frag<NS> g6[12];
         build_pe6<NS>(L, cd6, g6, g);
-        store_row_frags<NS, 12>(ov.G6, net, a.n_pad, row, h, g6, false);
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) store_tile_k<NS, NS>(ov.G6, net, tile32, ct, L, g6[2 * ct], g6[2 * ct + 1], false);
+        // natural-order read of cvec for channel 32T + j from the [h][T][r] permuted vector
+        const int w = L.j, rr = (w & 3) + 4 * (w >> 3), hh = (w >> 2) & 1;
+        auto epiz = [&](const int T) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                f32x16 d = acc[T];
+                if (s == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const u32 hi = pack2(acc[T][r], acc[T][r + 1]);
+                        d[r] = acc[T][r] - bf_lo(hi); d[r + 1] = acc[T][r + 1] - bf_hi(hi);
+                    }
+                }
+                store_d_as_k(kmat_ptr(ov.Z, net, NS, s, tile32, T, L.lane), d);
+            }
+        };
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
+            const float cv = lds_vec[kVecCvec * 256 + hh * 128 + T * 16 + rr];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = ld_vec4(lds_vec, kVecCvec, h, T, q);
-                acc[T][4 * q] = g * b.x; acc[T][4 * q + 1] = g * b.y; acc[T][4 * q + 2] = g * b.z; acc[T][4 * q + 3] = g * b.w;
-            }
-            step<NS, 16, 12>(pipe, actA, acc[T]);
-            if (T < 7) step<NS, 12, 16>(pipe, g6, acc[T]);
-            else step<NS, 12, 0>(pipe, g6, acc[T]);
+            for (int r = 0; r < 16; ++r) acc[T][r] = g16[r] * cv;
+            if (T < 7) DPN_STEP(16, 16, true, actA, acc[T], (void)0);
+            else DPN_STEP(16, 12, true, actA, acc[T], (void)0);
         }
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            if (T == 0) DPN_STEP(12, 12, true, g6, acc[T], (void)0);
+            else if (T < 7) DPN_STEP(12, 12, true, g6, acc[T], epiz(T - 1));
+            else DPN_STEP(12, 0, true, g6, acc[T], epiz(T - 1));
+        }
+        epiz(7);
     }
-    Frag<NS> actB[16];
-#pragma unroll
-    for (int T = 0; T < 8; ++T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) frag_set<NS>(actB[2 * T + (r >> 3)], r & 7, acc[T][r]);
-    store_row_frags<NS, 16>(ov.Z, net, a.n_pad, row, h, actB, false);
 }
 
 // ------------------------------------------------------------------------------------------------ backward, stage 2
 // Points-reduction GEMMs  D[so][si] = sum_pt X[pt][so] * Y[pt][si]  for the four products of a net:
 //   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q = Z^T 1
-//   P1: dw2  = V^T  Z1   (256x256)  + gcvec = V^T g
+//   P1: dw2  = V^T  Z1   (256x256)  + gcvec = V^T g, sum g
 //   P2: dWd  = V^T  G6   (256x192)
 //   P3: dw1  = T1^T Z0   (256x192)  + db1 = T1^T g
-// grid = (k_splits, 4 products, 6 nets); each workgroup owns the whole output of its product for its point range.
+// grid = (k_splits, 4 products, 6 nets); each workgroup owns the whole output of its product for its range of 32-point
+// tiles.  Operands are already MFMA fragments in global memory (K-layout): every wave loads its A/B fragments straight
+// into registers, one 16-byte load per fragment, no LDS, no barrier; the next k-step's loads are in flight under the MFMAs.
 constexpr int kPartFloats = 65536 * 2 + 49152 * 2 + 5 * 256;       // per (split, net)
 DPN_HD int part_off(int prod) { return prod == 0 ? 0 : prod == 1 ? 65536 : prod == 2 ? 131072 : 180224; }
 constexpr int kPartVec = 229376;                                    // mvec, q, gcvec, db1, [sum g]
@@ -779,159 +854,158 @@ constexpr int kPartVec = 229376;                                    // mvec, q, 
 struct WgradArgs {
     int64_t n, n_pad;
     int k_splits;
-    const float* g_out;
     void* saved;
     void* operands;
     float* partials;
 };
 
-template <int NS, int NCOL>   // NCOL = 256 or 192 output columns
-DEV void wgrad_body(const WgradArgs& a, int net, int prod, int64_t c0, int64_t c1, char* lds) {
-    // LDS: X tile [NSX][64][256] bf16, Y tile [NS][64][NCOL] bf16, g [64] f32
-    constexpr int NT_N = NCOL / 64;              // 32-col tiles per wave in N (wave grid 2x2): 4 or 3
-    const bool x_is_mask = (prod == 0);
+
+// one workgroup = 8 waves (2 x 4): wave (wm, wn) owns rows 128wm.. and columns 64wn.. of the product.  Per 32-point tile the
+// workgroup stages the X and Y fragments once in LDS (double-buffered, register-staged prefetch) and every wave reads its
+// 4 + 2 fragments per k-step from there: each operand byte is fetched from HBM/L2 exactly once per product.
+template <int NS>
+__global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
+    constexpr int kBuf = NS * 32768;                                   // X: NS x 16 KB, Y: NS x 16 KB
+    __shared__ __attribute__((aligned(16))) char lds[2 * kBuf];
+    const int prod = blockIdx.y, net = blockIdx.z;
+    const int ncol = prod < 2 ? 256 : 192, nct = ncol / 32;
+    const int64_t tiles = a.n_pad / 32;
+    const int64_t per = (tiles + a.k_splits - 1) / a.k_splits;
+    const int64_t t0 = (int64_t)blockIdx.x * per;
+    int64_t t1 = t0 + per < tiles ? t0 + per : tiles;
+    if (t1 < t0) t1 = t0;
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;
     const int i = lane & 31, h = lane >> 5;
+    const bool active = wn * 2 < nct;                                   // 192-column products leave the wn = 3 waves idle
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
-    const char* Xg = (prod == 3) ? sv.T1 : sv.V;
-    const char* Yg = (prod == 0) ? ov.Z : (prod == 1) ? ov.Z1 : (prod == 2) ? ov.G6 : ov.Z0;
-    constexpr int YROW = NCOL * 2;
-    char* ldsX = lds;                               // NS * 64 * 512
-    char* ldsY = lds + NS * 64 * 512;               // NS * 64 * YROW
-    float* ldsG = reinterpret_cast<float*>(lds + NS * 64 * 512 + NS * 64 * YROW);
-    unsigned* ldsM = reinterpret_cast<unsigned*>(ldsG + 64);   // [2][256] point-bit words (P0)
+    const char* xb = (prod == 0) ? sv.M2.base : (prod == 3) ? sv.T1.base : sv.V.base;           // 8 column tiles
+    const char* yb = (prod == 0) ? ov.Z.base : (prod == 1) ? ov.Z1.base : (prod == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
+    const int nsx = (prod == 0) ? 1 : NS;                               // the 0/1 mask has no lo part
+    const float* gnet = ov.gnet + (int64_t)net * a.n_pad;
+    const int xunits = nsx * 1024, yunits_s = nct * 128, total_units = xunits + NS * yunits_s;
 
-    f32x16 acc[4][NT_N];
+    uint4 stg[NS * 4];
+    auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int q = 0; q < NS * 4; ++q) {
+            int u = threadIdx.x + 512 * q;
+            u = u < total_units ? u : total_units - 1;                  // clamp: the surplus loads are simply not committed
+            const char* src;
+            if (u < xunits) src = xb + ((((int64_t)net * nsx + (u >> 10)) * tiles + tile) * 8) * 2048 + (u & 1023) * 16;
+            else { const int v = u - xunits, s2 = v / yunits_s, w = v - s2 * yunits_s; src = yb + ((((int64_t)net * NS + s2) * tiles + tile) * nct) * 2048 + w * 16; }
+            stg[q] = *reinterpret_cast<const uint4*>(src);
+        }
+    };
+    auto commit = [&](char* buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int n2 = 0; n2 < NT_N; ++n2) acc[m][n2] = (f32x16)0.f;
-    float vecA[4] = {0.f, 0.f, 0.f, 0.f};          // sum_pt X[pt][row] * g[pt] for this lane's rows (4 M tiles)
-    float vecB[NT_N];
-#pragma unroll
-    for (int n2 = 0; n2 < NT_N; ++n2) vecB[n2] = 0.f;
-    float gsum = 0.f;                               // sum of g over this range (threads 0..63)
-
-    const int64_t tiles32 = a.n_pad / 32;
-    for (int64_t ch = c0; ch < c1; ++ch) {          // 64-point chunks
-        const int64_t p0 = ch * 64;
-        __syncthreads();
-        // ---- stage the chunk
-        if (!x_is_mask) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const uint4* src = reinterpret_cast<const uint4*>(Xg + (((int64_t)net * NS + s) * a.n_pad + p0) * 512);
-                uint4* dst = reinterpret_cast<uint4*>(ldsX + s * 64 * 512);
-                for (int u = threadIdx.x; u < 64 * 32; u += 256) dst[u] = src[u];
-            }
-        } else {
-            for (int u = threadIdx.x; u < 512; u += 256) {
-                const int t = u >> 8, so = u & 255;
-                ldsM[u] = sv.m2k[((int64_t)net * tiles32 + (p0 / 32 + t)) * 256 + so];
+        for (int q = 0; q < NS * 4; ++q) {
+            const int u = threadIdx.x + 512 * q;
+            if (u < total_units) {
+                int s2, w, nc;
+                char* base;
+                if (u < xunits) { s2 = u >> 10; w = u & 1023; nc = 8; base = buf + s2 * 16384; }
+                else { const int v = u - xunits; s2 = v / yunits_s; w = v - s2 * yunits_s; nc = nct; base = buf + NS * 16384 + s2 * 16384; }
+                // source unit w = (ct, lane, kk)  ->  LDS [kk][ct][lane] so that a wave's fragment read is 1 KB contiguous
+                const int ct = w >> 7, ln = (w & 127) >> 1, kk = w & 1;
+                *reinterpret_cast<uint4*>(base + ((kk * nc + ct) * 64 + ln) * 16) = stg[q];
             }
         }
+    };
+
+    f32x16 acc[4][2];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const uint4* src = reinterpret_cast<const uint4*>(Yg + (((int64_t)net * NS + s) * a.n_pad + p0) * YROW);
-            uint4* dst = reinterpret_cast<uint4*>(ldsY + s * 64 * YROW);
-            for (int u = threadIdx.x; u < 64 * YROW / 16; u += 256) dst[u] = src[u];
-        }
-        if (threadIdx.x < 64) {
-            const int64_t p = p0 + threadIdx.x;
-            ldsG[threadIdx.x] = (p < a.n) ? a.g_out[p * 6 + net] : 0.f;
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) gsum += ldsG[threadIdx.x];
-        // ---- 4 k-steps of 16 points
+    for (int m = 0; m < 4; ++m) { acc[m][0] = (f32x16)0.f; acc[m][1] = (f32x16)0.f; }
+    float vecA[4] = {0.f, 0.f, 0.f, 0.f}, vecB[2] = {0.f, 0.f}, gsum = 0.f;
+
+    auto compute = [&](const char* buf, int64_t tile) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int prow = 16 * ks + 8 * h;       // this lane's 8 consecutive points
-            float gp[8];
+        for (int kk = 0; kk < 2; ++kk) {
+            const float* gp_ = gnet + tile * 32 + 16 * kk + 4 * h;       // points of registers 8kk..8kk+7
+            const float4 g0 = *reinterpret_cast<const float4*>(gp_), g1 = *reinterpret_cast<const float4*>(gp_ + 8);
+            const float gp[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            if (prod == 1 && wave == 0 && i == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gp[e] = ldsG[prow + e];
-            Frag<NS> bf[NT_N];
+                for (int e = 0; e < 8; ++e) gsum += gp[e];
+            }
+            u32x4 fa[NS][4], fb[NS][2];
 #pragma unroll
-            for (int n2 = 0; n2 < NT_N; ++n2) {
-                const int col = wn * (NCOL / 2) + 32 * n2 + i;
-                float colsum = 0.f;
+            for (int s2 = 0; s2 < NS; ++s2) {
+                if (s2 < nsx) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    u16 w[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) w[e] = *reinterpret_cast<const u16*>(ldsY + s * 64 * YROW + (prow + e) * YROW + col * 2);
-                    uint4 pk;
-                    pk.x = w[0] | (w[1] << 16); pk.y = w[2] | (w[3] << 16); pk.z = w[4] | (w[5] << 16); pk.w = w[6] | (w[7] << 16);
-                    bf[n2].v[s] = __builtin_bit_cast(bf16x8, pk);
-                    if (prod == 0 && wm == 0) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) colsum += bf2f(w[e]);
-                    }
+                    for (int m = 0; m < 4; ++m)
+                        fa[s2][m] = *reinterpret_cast<const u32x4*>(buf + s2 * 16384 + ((kk * 8 + wm * 4 + m) * 64 + lane) * 16);
                 }
-                vecB[n2] += colsum;
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2)
+                    fb[s2][n2] = *reinterpret_cast<const u32x4*>(buf + NS * 16384 + s2 * 16384 + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int rowc = wm * 128 + 32 * m + i;
-                Frag<NS> af;
-                float dotg = 0.f;
-                if (x_is_mask) {
-                    const unsigned word = ldsM[(ks >> 1) * 256 + rowc];
-                    const unsigned bits = (word >> (16 * (ks & 1) + 8 * h)) & 0xFFu;
-                    uint4 pk;
-                    pk.x = ((bits & 1u) ? 0x3F80u : 0u) | ((bits & 2u) ? 0x3F800000u : 0u);
-                    pk.y = ((bits & 4u) ? 0x3F80u : 0u) | ((bits & 8u) ? 0x3F800000u : 0u);
-                    pk.z = ((bits & 16u) ? 0x3F80u : 0u) | ((bits & 32u) ? 0x3F800000u : 0u);
-                    pk.w = ((bits & 64u) ? 0x3F80u : 0u) | ((bits & 128u) ? 0x3F800000u : 0u);
-                    af.v[0] = __builtin_bit_cast(bf16x8, pk);
-                    if constexpr (NS == 2) af.v[1] = (bf16x8)(__bf16)0.f;
+                if (wn == 0 && prod != 2) {                              // row-side vector: sum_pt X[pt][row] * g[pt]
+                    float d = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) dotg += ((bits >> e) & 1u) ? gp[e] : 0.f;
-                } else {
+                    for (int s2 = 0; s2 < NS; ++s2) {
+                        if (s2 < nsx) {
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        u16 w[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) w[e] = *reinterpret_cast<const u16*>(ldsX + s * 64 * 512 + (prow + e) * 512 + rowc * 2);
-                        uint4 pk;
-                        pk.x = w[0] | (w[1] << 16); pk.y = w[2] | (w[3] << 16); pk.z = w[4] | (w[5] << 16); pk.w = w[6] | (w[7] << 16);
-                        af.v[s] = __builtin_bit_cast(bf16x8, pk);
-                        if (wn == 0) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) dotg = fmaf(bf2f(w[e]), gp[e], dotg);
+                            for (int p = 0; p < 4; ++p) { d = fmaf(bf_lo(fa[s2][m][p]), gp[2 * p], d); d = fmaf(bf_hi(fa[s2][m][p]), gp[2 * p + 1], d); }
                         }
                     }
+                    vecA[m] += d;
                 }
-                vecA[m] += dotg;
 #pragma unroll
-                for (int n2 = 0; n2 < NT_N; ++n2) {
+                for (int n2 = 0; n2 < 2; ++n2) {
                     if constexpr (NS == 2) {
-                        acc[m][n2] = mfma(af.v[0], bf[n2].v[1], acc[m][n2]);
-                        if (!x_is_mask) acc[m][n2] = mfma(af.v[1], bf[n2].v[0], acc[m][n2]);
+                        acc[m][n2] = mfma(as_bf(fa[0][m]), as_bf(fb[1][n2]), acc[m][n2]);
+                        if (nsx == 2) acc[m][n2] = mfma(as_bf(fa[1][m]), as_bf(fb[0][n2]), acc[m][n2]);
                     }
-                    acc[m][n2] = mfma(af.v[0], bf[n2].v[0], acc[m][n2]);
+                    acc[m][n2] = mfma(as_bf(fa[0][m]), as_bf(fb[0][n2]), acc[m][n2]);
+                }
+            }
+            if (prod == 0 && wm == 0) {                                  // column-side vector: q = sum_pt Z[pt][col]
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) d += bf_lo(fb[s2][n2][p]) + bf_hi(fb[s2][n2][p]);
+                    vecB[n2] += d;
                 }
             }
         }
+    };
+
+    int cur = 0;
+    if (t1 > t0) { fetch(t0); commit(lds); }
+    __syncthreads();
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) fetch(tile + 1);
+        if (active) compute(lds + cur * kBuf, tile);
+        if (tile + 1 < t1) commit(lds + (cur ^ 1) * kBuf);
+        __syncthreads();
+        cur ^= 1;
     }
-    // ---- write this split's partial sums: natural [row slot][col slot] order
+    // ---- write this split's partial sums: natural [row slot][col] order
     float* part = a.partials + ((int64_t)blockIdx.x * kNets + net) * kPartFloats;
     float* out = part + part_off(prod);
+    if (active) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n2 = 0; n2 < NT_N; ++n2)
+            for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = wm * 128 + 32 * m + drow32(r, h);
-                const int cc = wn * (NCOL / 2) + 32 * n2 + i;
-                out[rr * NCOL + cc] = acc[m][n2][r];
-            }
-    // vectors: A side (rows), lanes of both halves hold partial sums over their 8-point groups
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = wm * 128 + 32 * m + drow32(r, h);
+                    const int cc = wn * 64 + 32 * n2 + i;
+                    out[rr * ncol + cc] = acc[m][n2][r];
+                }
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        float v = vecA[m] + __shfl_xor(vecA[m], 32);
+        const float v = vecA[m] + __shfl_xor(vecA[m], 32);
         if (wn == 0 && h == 0) {
             const int rr = wm * 128 + 32 * m + i;
             if (prod == 0) part[kPartVec + 0 * 256 + rr] = v;          // mvec
@@ -939,29 +1013,17 @@ DEV void wgrad_body(const WgradArgs& a, int net, int prod, int64_t c0, int64_t c
             if (prod == 3) part[kPartVec + 3 * 256 + rr] = v;          // db1
         }
     }
-    if (wave == 0) {
-        const float gs = wave_sum(gsum);
-        if (prod == 1 && lane == 0) part[kPartVec + 4 * 256] = gs;
+    if (prod == 1 && wave == 0) {
+        const float gs = gsum + __shfl_xor(gsum, 32);                  // lanes 0 and 32 hold the two halves
+        if (lane == 0) part[kPartVec + 4 * 256] = gs;
     }
     if (prod == 0 && wm == 0) {
 #pragma unroll
-        for (int n2 = 0; n2 < NT_N; ++n2) {
-            float v = vecB[n2] + __shfl_xor(vecB[n2], 32);
-            if (h == 0) part[kPartVec + 1 * 256 + wn * (NCOL / 2) + 32 * n2 + i] = v;   // q = colsum(Z)
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const float v = vecB[n2] + __shfl_xor(vecB[n2], 32);
+            if (h == 0) part[kPartVec + 1 * 256 + wn * 64 + 32 * n2 + i] = v;   // q = colsum(Z)
         }
     }
-}
-
-template <int NS>
-__global__ __launch_bounds__(256, 1) void dpn_wgrad_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[NS * 64 * 512 * 2 + 64 * 4 + 512 * 4];
-    const int prod = blockIdx.y, net = blockIdx.z;
-    const int64_t chunks = a.n_pad / 64;
-    const int64_t per = (chunks + a.k_splits - 1) / a.k_splits;
-    const int64_t c0 = (int64_t)blockIdx.x * per;
-    const int64_t c1 = (c0 + per < chunks) ? c0 + per : chunks;
-    if (prod < 2) wgrad_body<NS, 256>(a, net, prod, c0, c1 > c0 ? c1 : c0, lds);
-    else wgrad_body<NS, 192>(a, net, prod, c0, c1 > c0 ? c1 : c0, lds);
 }
 
 // ------------------------------------------------------------------------------------------------ backward, stage 3
@@ -1007,13 +1069,13 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
     const float* vec = reinterpret_cast<const float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
     const int T = o >> 5, w = o & 31, hh = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);
     const float uo = vec[kVecU * 256 + hh * 128 + T * 16 + r];
-    const float Goi = part_sum(a.partials, a.k_splits, net, part_off(0) + so * 256 + si);
+    const float Goi = part_sum(a.partials, a.k_splits, net, part_off(0) + so * 256 + i);   // Z's columns are in natural order (SWAP output)
     Gd.W1[o * 256 + i] = uo * Goi;
     red[i] = P.W1[o * 256 + i] * Goi;
-    Gd.w2b2[o * kW2Stride + i] = part_sum(a.partials, a.k_splits, net, part_off(1) + so * 256 + si);
+    Gd.w2b2[o * Gd.ld_w2b2 + i] = part_sum(a.partials, a.k_splits, net, part_off(1) + so * 256 + si);
     if (i < kPe) {
         Gd.Wd[o * kPe + i] = part_sum(a.partials, a.k_splits, net, part_off(2) + so * 192 + slot_of_pe6(i));
-        Gd.w1b1[o * kW1Stride + i] = part_sum(a.partials, a.k_splits, net, part_off(3) + so * 192 + slot_of_pe3(i));
+        Gd.w1b1[o * Gd.ld_w1b1 + i] = part_sum(a.partials, a.k_splits, net, part_off(3) + so * 192 + slot_of_pe3(i));
     }
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -1026,8 +1088,8 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
         const float db1 = part_sum(a.partials, a.k_splits, net, kPartVec + 3 * 256 + so);
         a.scratch_r[net * 256 + o] = red[0] + P.bf1[o] * mvec;
         Gd.bf1[o] = uo * mvec;
-        Gd.w2b2[o * kW2Stride + 256] = gcv;
-        Gd.w1b1[o * kW1Stride + 192] = db1;
+        Gd.w2b2[o * Gd.ld_w2b2 + 256] = gcv;
+        Gd.w1b1[o * Gd.ld_w1b1 + 192] = db1;
         Gd.bd[o] = gcv;
         Gd.evec[o] = gcv;
     }
@@ -1050,10 +1112,91 @@ __global__ __launch_bounds__(256) void dpn_finish_fc2_kernel(FinishArgs a) {
     }
     if (o == 0) {
         const float s = part_sum(a.partials, a.k_splits, net, kPartVec + 4 * 256);
-        const float q = part_sum(a.partials, a.k_splits, net, kPartVec + 1 * 256 + slot_of_ch(op));
+        const float q = part_sum(a.partials, a.k_splits, net, kPartVec + 1 * 256 + op);
         Gd.bf2[op] = wop * s;
         Gd.wo[op] = red[0] + P.bf2[op] * s + 2.f * q;
         if (op == 0) Gd.bo[0] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small fp32 GEMM
+// The encoder (L = 287 tokens, d = 256) and the hyper-network heads are a few dozen tiny fp32 GEMMs per step; library
+// GEMMs cost 19-75 us each at these shapes (latency-bound).  One LDS-tiled fp32 kernel serves all of them:
+//   C[M][N] = op(A)[M][K] * op(B)[K][N] (+ bias[N]) (+ C)      op = identity or transpose, row-major with leading dims
+//   optionally colsum[N] = sum_m op(A)^T ... is NOT needed; instead rowsum of op(A)^T is offered through `asum`:
+//   asum[M] = sum_k op(A)[m][k]  (used as the bias gradient when op(A) = grad_out^T).
+struct SgemmArgs {
+    const float *A, *B, *bias;
+    float *C, *asum;
+    int M, N, K, lda, ldb, ldc, ta, tb, accumulate, k_per_split;
+};
+
+__global__ __launch_bounds__(256) void dpn_sgemm_kernel(SgemmArgs a) {
+    constexpr int BM = 32, BN = 32, BK = 32;
+    __shared__ float As[BK][BM + 1];
+    __shared__ float Bs[BK][BN + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, 2 x 2 outputs each
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * a.k_per_split;
+    const int kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
+    const bool split = gridDim.z > 1;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float rs = 0.f;
+    const bool do_asum = a.asum != nullptr && blockIdx.x == 0;
+    float ra[4], rb[4];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = threadIdx.x + 256 * i;                  // 1024 elements per tile
+            {
+                const int kk = a.ta ? (e >> 5) : (e & 31), mm = a.ta ? (e & 31) : (e >> 5);
+                const int gm = m0 + mm, gk = k0 + kk;
+                ra[i] = (gm < a.M && gk < kend) ? (a.ta ? a.A[(int64_t)gk * a.lda + gm] : a.A[(int64_t)gm * a.lda + gk]) : 0.f;
+            }
+            {
+                const int kk = a.tb ? (e & 31) : (e >> 5), nn = a.tb ? (e >> 5) : (e & 31);
+                const int gk = k0 + kk, gn = n0 + nn;
+                rb[i] = (gk < kend && gn < a.N) ? (a.tb ? a.B[(int64_t)gn * a.ldb + gk] : a.B[(int64_t)gk * a.ldb + gn]) : 0.f;
+            }
+        }
+    };
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            As[a.ta ? (e >> 5) : (e & 31)][a.ta ? (e & 31) : (e >> 5)] = ra[i];
+            Bs[a.tb ? (e & 31) : (e >> 5)][a.tb ? (e >> 5) : (e & 31)] = rb[i];
+        }
+        __syncthreads();
+        if (k0 + BK < kend) gload(k0 + BK);                       // next tile in flight under the FMAs
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            const float a0 = As[kk][ty], a1 = As[kk][ty + 16], b0 = Bs[kk][tx], b1 = Bs[kk][tx + 16];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        if (do_asum && threadIdx.x < BM) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rs += As[kk][threadIdx.x];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gm = m0 + ty + 16 * i, gn = n0 + tx + 16 * j;
+            if (gm < a.M && gn < a.N) {
+                float v = acc[i][j] + ((a.bias && blockIdx.z == 0) ? a.bias[gn] : 0.f);
+                float* c = a.C + (int64_t)gm * a.ldc + gn;
+                if (split) atomicAdd(c, v);                       // C was zeroed by the launcher (or holds the value to accumulate onto)
+                else *c = a.accumulate ? (*c + v) : v;
+            }
+        }
+    if (do_asum && threadIdx.x < BM && m0 + threadIdx.x < a.M) {
+        if (split) atomicAdd(&a.asum[m0 + threadIdx.x], rs);
+        else a.asum[m0 + threadIdx.x] = rs;
     }
 }
 
@@ -1165,12 +1308,13 @@ int dpn_bwd_points(const float* x, const float* y, const float* t, const float* 
 
 int dpn_wgrad(int64_t n, int prec, const float* g_out, const void* saved, const void* operands, void* partials, void* stream) {
     if (!g_out || !saved || !operands || !partials || n <= 0 || (prec != 1 && prec != 2)) return -1;
-    WgradArgs a{n, pad_points(n), choose_splits(pad_points(n)), g_out, const_cast<void*>(saved), const_cast<void*>(operands),
+    WgradArgs a{n, pad_points(n), choose_splits(pad_points(n)), const_cast<void*>(saved), const_cast<void*>(operands),
                 reinterpret_cast<float*>(partials)};
+    (void)g_out;   // the per-net cotangents were staged into `operands` by dpn_bwd_points
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(a.k_splits, 4, kNets);
-    if (prec == 1) hipLaunchKernelGGL(dpn_wgrad_kernel<1>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(dpn_wgrad_kernel<2>, grid, dim3(256), 0, s, a);
+    if (prec == 1) hipLaunchKernelGGL(dpn_wgrad_kernel<1>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(dpn_wgrad_kernel<2>, grid, dim3(512), 0, s, a);
     return ck(hipGetLastError());
 }
 
@@ -1188,6 +1332,31 @@ int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
     hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
+    return ck(hipGetLastError());
+}
+
+int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+              const float* bias, float* asum, int accumulate, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return -1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
+    int splits = 1;
+    if (tiles < 256 && K >= 1024 && ldc == N) {                  // long reductions with few output tiles: split K over the grid
+        splits = (512 + tiles - 1) / tiles;
+        const int maxs = K / 256;
+        if (splits > maxs) splits = maxs;
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    int kps = (K + splits - 1) / splits;
+    kps = ((kps + 31) / 32) * 32;
+    splits = (K + kps - 1) / kps;
+    if (splits > 1) {
+        if (!accumulate && hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s) != hipSuccess) return -2;
+        if (asum && hipMemsetAsync(asum, 0, (size_t)M * sizeof(float), s) != hipSuccess) return -2;
+    }
+    SgemmArgs a{A, B, bias, C, asum, M, N, K, lda, ldb, ldc, ta, tb, accumulate, kps};
+    hipLaunchKernelGGL(dpn_sgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, splits), dim3(256), 0, s, a);
     return ck(hipGetLastError());
 }
 

@@ -48,7 +48,7 @@ DPN_HD int gpe_row_to_pe3_ch(int rho) {
 // ------------------------------------------------------------------ packed per-net weight block
 // Stream order (KB = 1024 B units for NS = 1; multiply by NS for the hi/lo split):
 //   S0  w1          8 tiles x 12 k-steps   (A rows o,   K = PE3 slots)
-//   S1  w2 | Wd     8 tiles x (16 + 12)    (A rows o,   K = chain(h1) then PE6 slots), interleaved per tile
+//   S1  w2 , Wd     8 x 16 then 8 x 12     (A rows o,   K = chain(h1) / PE6 slots): all w2 tiles, then all Wd tiles
 //   S2  W1          8 x 16                 (A rows o,   K = chain(c))
 //   S3  W1^T        8 x 16                 (A rows i,   K = chain(t2))
 //   S4  w2^T        8 x 16                 (A rows i,   K = chain(v))

@@ -164,8 +164,8 @@ class InterfacePhysics(nn.Module):
     def pde_loss_terms(self, x, y, t, f, field_data, input_data, forecast_h, loss_factor=None, use_cache=False):
         """The six scaled residual losses as a [6] tensor (motion_u, motion_v, continuous, energy, vapor, gas)."""
         cfg = self.point_config(loss_factor)
-        w1b1, w2b2, evec, statics = self.physics_net.field_weights(field_data, forecast_h, use_cache=use_cache)
-        return pde_losses(cfg, x, y, t, f, input_data, w1b1, w2b2, evec, statics)
+        heads, evec, statics = self.physics_net.field_weights(field_data, forecast_h, use_cache=use_cache)
+        return pde_losses(cfg, x, y, t, f, input_data, heads, evec, statics)
 
     def place_one_batch(self, x, y, t, f, field_data, input_data, forecast_h, criterion, loss_factor, global_step, local_rank, device,
                         summary=None, prefix='inter', log_step=100, use_cache=False):

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..linear import linear
 from ..utils.position_encoding import SineCosPE
 
 
@@ -40,6 +41,12 @@ class TokenEmbedding(nn.Module):
         nn.init.kaiming_normal_(self.tokenConv.weight, mode='fan_in', nonlinearity='leaky_relu')
 
     def forward(self, x):
+        if x.is_cuda and x.shape[0] == 1:
+            # circular k=3 convolution over the token axis == one GEMM on [x[t-1] | x[t] | x[t+1]]
+            x0 = x[0]
+            xu = torch.cat([torch.roll(x0, 1, 0), x0, torch.roll(x0, -1, 0)], dim=1)           # [159, 3*c_in], tap-major
+            w = self.tokenConv.weight.permute(0, 2, 1).reshape(self.tokenConv.weight.shape[0], -1)   # [d_model, 3*c_in]
+            return linear(xu, w, self.tokenConv.bias).unsqueeze(0)
         return self.tokenConv(x.permute(0, 2, 1)).transpose(1, 2)
 
 
@@ -88,13 +95,13 @@ class AttentionLayer(nn.Module):
     def forward(self, queries, keys, values, attn_mask=None):
         B, L, _ = queries.shape
         S, H = keys.shape[1], self.n_heads
-        q = self.query_projection(queries).view(B, L, H, -1)
-        k = self.key_projection(keys).view(B, S, H, -1)
-        v = self.value_projection(values).view(B, S, H, -1)
+        q = linear(queries, self.query_projection.weight, self.query_projection.bias).view(B, L, H, -1)
+        k = linear(keys, self.key_projection.weight, self.key_projection.bias).view(B, S, H, -1)
+        v = linear(values, self.value_projection.weight, self.value_projection.bias).view(B, S, H, -1)
         out, attn = self.inner_attention(q, k, v, attn_mask)
         if self.mix:
             out = out.transpose(2, 1).contiguous()
-        return self.out_projection(out.reshape(B, L, -1)), attn
+        return linear(out.reshape(B, L, -1), self.out_projection.weight, self.out_projection.bias), attn
 
 
 class EncoderLayer(nn.Module):
@@ -114,8 +121,8 @@ class EncoderLayer(nn.Module):
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask)
         x = self.norm1(x + new_x)
         # kernel-size-1 convolutions over the token axis are per-token linear maps: run them as GEMMs
-        y = self.activation(F.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias))
-        y = F.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias)
+        y = self.activation(linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias))
+        y = linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias)
         return self.norm2(x + y), attn
 
 
@@ -154,7 +161,7 @@ class TransformerNet(nn.Module):
     def forward(self, x_enc, forecast_h, enc_self_mask=None):
         enc_out = self.enc_embedding(x_enc, forecast_h, self.learnable_token)
         enc_out, _ = self.encoder(enc_out, attn_mask=enc_self_mask)
-        return self.projection(enc_out)
+        return linear(enc_out, self.projection.weight, self.projection.bias)
 
 
 class MetaNet(nn.Module):

@@ -3,6 +3,7 @@
 import torch
 import torch.nn as nn
 
+from ..linear import linear
 from .meta_net import MetaNet
 from .variable_net import VariableNet
 
@@ -50,15 +51,23 @@ class PhysicsNet(nn.Module):
         self._meta_cache = None
 
     def field_weights(self, field_x, forecast_h, use_cache=False):
-        """Everything the point kernels need for one field sample: (w1b1 [6,256,193], w2b2 [6,256,257], evec [6,256], statics[48])."""
+        """Everything the point kernels need for one field sample: (heads [256, 2700], evec [6,256], statics[48]).
+
+        The twelve hyper-network heads (coord_input_fc / coord_hidden_fc of the six nets, variable_net.py:59-65) share their
+        input, so they run as ONE GEMM whose output rows are [w1b1_0..5 | w2b2_0..5]; the six lead-time embeddings
+        (variable_net.py:75-78) are one GEMV batch."""
         meta_out = self.encode_field(field_x, forecast_h, use_cache=use_cache)
         nets = self.nets_in_output_order()
-        hw = [n.hyper_weights(meta_out, forecast_h) for n in nets]
-        w1b1 = torch.stack([h[0] for h in hw])
-        w2b2 = torch.stack([h[1] for h in hw])
-        evec = torch.stack([h[2] for h in hw])
+        m_t = torch.squeeze(meta_out, dim=0)[0:nets[0].token_num].T                    # [256 channels, 256 tokens]
+        w_cat = torch.cat([n.coord_input_fc.weight for n in nets] + [n.coord_hidden_fc.weight for n in nets], dim=0)
+        b_cat = torch.cat([n.coord_input_fc.bias for n in nets] + [n.coord_hidden_fc.bias for n in nets], dim=0)
+        heads = linear(m_t, w_cat, b_cat)                                              # [256, 2700]
+        pe_h = nets[0].pe_fore_h(forecast_h.squeeze(dim=-1))                           # [1, 192] (same encoder in every net)
+        wf = torch.cat([n.fore_h_fc.weight for n in nets], dim=0)                      # [6*256, 192]
+        bf = torch.cat([n.fore_h_fc.bias for n in nets], dim=0)
+        evec = linear(pe_h, wf, bf).view(6, 256)
         statics = [p for n in nets for p in n.static_params()]
-        return w1b1, w2b2, evec, statics
+        return heads, evec, statics
 
     def _cfg(self):
         from ..point_path import PointConfig
@@ -68,15 +77,15 @@ class PhysicsNet(nn.Module):
     def forward(self, field_x, coord_x, coord_data, forecast_h):
         """coord_x: [N,192] coordinates already encoded by SineCosPE(3) (interface_physics.py:322-332)."""
         from ..point_path import point_fields
-        w1b1, w2b2, evec, statics = self.field_weights(field_x, forecast_h)
-        out = point_fields(self._cfg(), coord_data, w1b1, w2b2, evec, statics, pe_in=coord_x)
+        heads, evec, statics = self.field_weights(field_x, forecast_h)
+        out = point_fields(self._cfg(), coord_data, heads, evec, statics, pe_in=coord_x)
         return tuple(out[:, k:k + 1] for k in range(6))
 
     def forward_xyt(self, field_x, x, y, t, coord_data, forecast_h, use_cache=False):
         """Same fields from raw coordinates; the encoding happens inside the kernel (fast path)."""
         from ..point_path import point_fields
-        w1b1, w2b2, evec, statics = self.field_weights(field_x, forecast_h, use_cache=use_cache)
-        out = point_fields(self._cfg(), coord_data, w1b1, w2b2, evec, statics, x=x, y=y, t=t)
+        heads, evec, statics = self.field_weights(field_x, forecast_h, use_cache=use_cache)
+        out = point_fields(self._cfg(), coord_data, heads, evec, statics, x=x, y=y, t=t)
         return tuple(out[:, k:k + 1] for k in range(6))
 
     def forward_single(self, variable_name, field_x, coord_x):

@@ -59,8 +59,7 @@ class VariableNet(nn.Module):
         from ..point_path import PointConfig, point_fields
         w1b1, w2b2, evec = self.hyper_weights(meta_out, fore_h)
         cfg = getattr(self, '_point_cfg', None) or PointConfig()
-        out = point_fields(cfg, coord_data, w1b1.unsqueeze(0).expand(6, -1, -1).contiguous(),
-                           w2b2.unsqueeze(0).expand(6, -1, -1).contiguous(), evec.unsqueeze(0).expand(6, -1).contiguous(),
-                           self.static_params() * 6, pe_in=coord)
+        heads = torch.cat([w1b1] * 6 + [w2b2] * 6, dim=1)
+        out = point_fields(cfg, coord_data, heads, evec.unsqueeze(0).expand(6, -1).contiguous(), self.static_params() * 6, pe_in=coord)
         # the kernel adds coord_data[:, k] as ref_data of slot k; replace slot 0's by the caller's ref_data
         return out[:, 0:1] - coord_data[:, 0:1] + ref_data

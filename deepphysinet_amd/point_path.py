@@ -87,11 +87,18 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _net_ptrs(w1b1, w2b2, evec, statics):
-    arr = (L.DpnNetPtrs * L.NETS)()
+HEADS_COLS = 6 * 193 + 6 * 257          # one GEMM output row: [w1b1 of net 0..5 | w2b2 of net 0..5]
+HEADS_W2_OFF = 6 * 193
+
+
+def _net_ptrs(heads, evec, statics, cls=None):
+    """Pointer table over the hyper-network output `heads` [256, 2700] (row stride 2700), evec [6,256] and the 48 static tensors."""
+    arr = ((cls or L.DpnNetPtrs) * L.NETS)()
     for k in range(L.NETS):
-        arr[k].w1b1 = w1b1.data_ptr() + k * 256 * 193 * 4
-        arr[k].w2b2 = w2b2.data_ptr() + k * 256 * 257 * 4
+        arr[k].w1b1 = heads.data_ptr() + k * 193 * 4
+        arr[k].w2b2 = heads.data_ptr() + (HEADS_W2_OFF + k * 257) * 4
+        arr[k].ld_w1b1 = HEADS_COLS
+        arr[k].ld_w2b2 = HEADS_COLS
         arr[k].evec = evec.data_ptr() + k * 256 * 4
         for j, nm in enumerate(STATIC_NAMES):
             setattr(arr[k], nm, statics[k * 8 + j].data_ptr())
@@ -129,7 +136,7 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
 
 
 def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics):
-    """Weight gradients from per-point cotangents.  Returns (g_w1b1, g_w2b2, g_evec, [48 static grads])."""
+    """Weight gradients from per-point cotangents.  Returns (g_heads [256,2700], g_evec [6,256], [48 static grads])."""
     lib = L.load()
     n = coord_data.shape[0]
     dev = coord_data.device
@@ -140,64 +147,57 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
                                _ptr(ws.packed), cfg.prec, _ptr(g_out), _ptr(g_jxi), _ptr(ws.saved), _ptr(operands), _stream()),
             'dpn_bwd_points')
     L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
-    g_w1b1 = torch.empty((6, 256, 193), dtype=torch.float32, device=dev)
-    g_w2b2 = torch.empty((6, 256, 257), dtype=torch.float32, device=dev)
+    g_heads = torch.empty((256, HEADS_COLS), dtype=torch.float32, device=dev)
     g_evec = torch.empty((6, 256), dtype=torch.float32, device=dev)
     g_stat = [torch.empty(STATIC_SHAPES[j], dtype=torch.float32, device=dev) for _ in range(6) for j in range(8)]
-    garr = (L.DpnNetGradPtrs * L.NETS)()
-    for k in range(L.NETS):
-        garr[k].w1b1 = g_w1b1.data_ptr() + k * 256 * 193 * 4
-        garr[k].w2b2 = g_w2b2.data_ptr() + k * 256 * 257 * 4
-        garr[k].evec = g_evec.data_ptr() + k * 256 * 4
-        for j, nm in enumerate(STATIC_NAMES):
-            setattr(garr[k], nm, g_stat[k * 8 + j].data_ptr())
+    garr = _net_ptrs(g_heads, g_evec, g_stat, cls=L.DpnNetGradPtrs)
     L.check(lib.dpn_wgrad_finish(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, _stream()), 'dpn_wgrad_finish')
-    return g_w1b1, g_w2b2, g_evec, g_stat
+    return g_heads, g_evec, g_stat
 
 
 class _PointFieldsFn(torch.autograd.Function):
     """out_n [N,6] = six VariableNets at N points.  First-order differentiable w.r.t. the weights."""
 
     @staticmethod
-    def forward(ctx, cfg, x, y, t, pe_in, coord_data, w1b1, w2b2, evec, *statics):
-        for nm, v in (('coord_data', coord_data), ('w1b1', w1b1)):
+    def forward(ctx, cfg, x, y, t, pe_in, coord_data, heads, evec, *statics):
+        for nm, v in (('coord_data', coord_data), ('heads', heads)):
             _require_gpu(v, nm)
-        tens = [None if v is None else _f32c(v) for v in (x, y, t, pe_in, coord_data, w1b1, w2b2, evec)]
-        x_, y_, t_, pe_, cd_, w1_, w2_, ev_ = tens
+        tens = [None if v is None else _f32c(v) for v in (x, y, t, pe_in, coord_data, heads, evec)]
+        x_, y_, t_, pe_, cd_, hd_, ev_ = tens
         st = [_f32c(s) for s in statics]
-        need_grad = any(v.requires_grad for v in (w1b1, w2b2, evec) + tuple(statics))
+        need_grad = any(v.requires_grad for v in (heads, evec) + tuple(statics))
         ws = _Workspace(cd_.shape[0], cfg.prec, cd_.device)
-        nets = _net_ptrs(w1_, w2_, ev_, st)
+        nets = _net_ptrs(hd_, ev_, st)
         out_n, _ = _forward_points(cfg, ws, nets, x_, y_, t_, pe_, cd_, want_jac=False, want_saved=need_grad)
         ctx.cfg, ctx.ws = cfg, ws
-        ctx.keep = (x_, y_, t_, pe_, cd_, w1_, w2_, ev_, st)
+        ctx.keep = (x_, y_, t_, pe_, cd_, hd_, ev_, st)
         return out_n
 
     @staticmethod
     def backward(ctx, g_out):
-        x_, y_, t_, pe_, cd_, w1_, w2_, ev_, st = ctx.keep
-        nets = _net_ptrs(w1_, w2_, ev_, st)
+        x_, y_, t_, pe_, cd_, hd_, ev_, st = ctx.keep
+        nets = _net_ptrs(hd_, ev_, st)
         g = _f32c(g_out)
-        gw1, gw2, gev, gst = _backward_points(ctx.cfg, ctx.ws, nets, x_, y_, t_, pe_, cd_, g, None, st)
-        return (None, None, None, None, None, None, gw1, gw2, gev, *gst)
+        ghd, gev, gst = _backward_points(ctx.cfg, ctx.ws, nets, x_, y_, t_, pe_, cd_, g, None, st)
+        return (None, None, None, None, None, None, ghd, gev, *gst)
 
 
 class _PdeLossFn(torch.autograd.Function):
     """losses [6] = (motion_u, motion_v, continuous, energy, vapor, gas), each already scaled by its factor."""
 
     @staticmethod
-    def forward(ctx, cfg, x, y, t, f, coord_data, w1b1, w2b2, evec, *statics):
-        for nm, v in (('x', x), ('coord_data', coord_data), ('w1b1', w1b1)):
+    def forward(ctx, cfg, x, y, t, f, coord_data, heads, evec, *statics):
+        for nm, v in (('x', x), ('coord_data', coord_data), ('heads', heads)):
             _require_gpu(v, nm)
         lib = L.load()
-        x_, y_, t_, f_, cd_, w1_, w2_, ev_ = [_f32c(v).reshape(-1) if i < 4 else _f32c(v) for i, v in
-                                              enumerate((x, y, t, f, coord_data, w1b1, w2b2, evec))]
+        x_, y_, t_, f_, cd_, hd_, ev_ = [_f32c(v).reshape(-1) if i < 4 else _f32c(v) for i, v in
+                                         enumerate((x, y, t, f, coord_data, heads, evec))]
         st = [_f32c(s) for s in statics]
         n = cd_.shape[0]
         dev = cd_.device
-        need_grad = any(v.requires_grad for v in (w1b1, w2b2, evec) + tuple(statics))
+        need_grad = any(v.requires_grad for v in (heads, evec) + tuple(statics))
         ws = _Workspace(n, cfg.prec, dev)
-        nets = _net_ptrs(w1_, w2_, ev_, st)
+        nets = _net_ptrs(hd_, ev_, st)
         out_n, jac_n = _forward_points(cfg, ws, nets, x_, y_, t_, None, cd_, want_jac=True, want_saved=need_grad)
         sums = torch.zeros(6, dtype=torch.float64, device=dev)
         losses = torch.empty(6, dtype=torch.float32, device=dev)
@@ -206,15 +206,14 @@ class _PdeLossFn(torch.autograd.Function):
                                  None, None, _stream()), 'dpn_residual')
         L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses), _stream()), 'dpn_residual_finish')
         ctx.cfg, ctx.ws = cfg, ws
-        ctx.keep = (x_, y_, t_, f_, cd_, w1_, w2_, ev_, st, out_n, jac_n)
-        ctx.fields = (out_n, jac_n)
+        ctx.keep = (x_, y_, t_, f_, cd_, hd_, ev_, st, out_n, jac_n)
         return losses
 
     @staticmethod
     def backward(ctx, g_losses):
         lib = L.load()
         cfg = ctx.cfg
-        x_, y_, t_, f_, cd_, w1_, w2_, ev_, st, out_n, jac_n = ctx.keep
+        x_, y_, t_, f_, cd_, hd_, ev_, st, out_n, jac_n = ctx.keep
         n = cd_.shape[0]
         dev = cd_.device
         gl = _f32c(g_losses)
@@ -223,33 +222,34 @@ class _PdeLossFn(torch.autograd.Function):
         geo, ph = cfg.geometry(), cfg.physics()
         L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), _ptr(gl), None,
                                  _ptr(g_out), _ptr(g_jxi), _stream()), 'dpn_residual(grad)')
-        nets = _net_ptrs(w1_, w2_, ev_, st)
-        gw1, gw2, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st)
-        return (None, None, None, None, None, None, gw1, gw2, gev, *gst)
+        nets = _net_ptrs(hd_, ev_, st)
+        ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st)
+        return (None, None, None, None, None, None, ghd, gev, *gst)
 
 
-def point_fields(cfg: PointConfig, coord_data, w1b1, w2b2, evec, statics, x=None, y=None, t=None, pe_in=None):
-    """Normalised fields [N,6].  Give either raw (x,y,t) [N] or caller-encoded coordinates pe_in [N,192]."""
+def point_fields(cfg: PointConfig, coord_data, heads, evec, statics, x=None, y=None, t=None, pe_in=None):
+    """Normalised fields [N,6].  Give either raw (x,y,t) [N] or caller-encoded coordinates pe_in [N,192].
+    heads [256, 2700]: one row per hidden channel, columns [w1b1 of nets 0..5 (193 each) | w2b2 of nets 0..5 (257 each)]."""
     if (pe_in is None) == (x is None):
         raise ValueError('give exactly one of (x,y,t) or pe_in')
     if x is not None:
         x, y, t = (v.reshape(-1) for v in (x, y, t))
-    return _PointFieldsFn.apply(cfg, x, y, t, pe_in, coord_data, w1b1, w2b2, evec, *statics)
+    return _PointFieldsFn.apply(cfg, x, y, t, pe_in, coord_data, heads, evec, *statics)
 
 
-def pde_losses(cfg: PointConfig, x, y, t, f, coord_data, w1b1, w2b2, evec, statics):
+def pde_losses(cfg: PointConfig, x, y, t, f, coord_data, heads, evec, statics):
     """The six scaled residual losses [6] of place_one_batch."""
-    return _PdeLossFn.apply(cfg, x, y, t, f, coord_data, w1b1, w2b2, evec, *statics)
+    return _PdeLossFn.apply(cfg, x, y, t, f, coord_data, heads, evec, *statics)
 
 
-def pde_fields_and_jacobian(cfg: PointConfig, x, y, t, coord_data, w1b1, w2b2, evec, statics):
+def pde_fields_and_jacobian(cfg: PointConfig, x, y, t, coord_data, heads, evec, statics):
     """No-grad helper: normalised fields [N,6] and d(fields_n)/d(x,y,t) [N,6,3] straight from the forward kernel."""
     with torch.no_grad():
         x_, y_, t_ = (_f32c(v).reshape(-1) for v in (x, y, t))
-        cd_, w1_, w2_, ev_ = (_f32c(v) for v in (coord_data, w1b1, w2b2, evec))
+        cd_, hd_, ev_ = (_f32c(v) for v in (coord_data, heads, evec))
         st = [_f32c(s) for s in statics]
         ws = _Workspace(cd_.shape[0], cfg.prec, cd_.device)
-        return _forward_points(cfg, ws, _net_ptrs(w1_, w2_, ev_, st), x_, y_, t_, None, cd_, want_jac=True, want_saved=False)
+        return _forward_points(cfg, ws, _net_ptrs(hd_, ev_, st), x_, y_, t_, None, cd_, want_jac=True, want_saved=False)
 
 
 def smooth_l1_data_loss(out_n, labels, beta=0.1, factor=1.0):

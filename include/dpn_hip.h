@@ -40,11 +40,14 @@ typedef struct DpnNetPtrs {
     const float* bf2;    /* [256]       cat_fc1.fc.2.bias                */
     const float* wo;     /* [256]       out_fc.weight                    */
     const float* bo;     /* [1]         out_fc.bias                      */
+    int64_t ld_w1b1;     /* row stride of w1b1 in floats (>= 193): lets the six heads live in one GEMM output */
+    int64_t ld_w2b2;     /* row stride of w2b2 in floats (>= 257)                                             */
 } DpnNetPtrs;
 
 /* Gradient destinations, same shapes as DpnNetPtrs (written, not accumulated). */
 typedef struct DpnNetGradPtrs {
     float* w1b1; float* w2b2; float* evec; float* Wd; float* bd; float* W1; float* bf1; float* W2; float* bf2; float* wo; float* bo;
+    int64_t ld_w1b1, ld_w2b2;   /* row strides (floats) of the w1b1 / w2b2 gradient destinations */
 } DpnNetGradPtrs;
 
 /* Grid constants of encoding_coord (interface_physics.py:322-332). */
@@ -120,6 +123,13 @@ int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_
  * g_out = gl * factor/(6N) * dSmoothL1 (may be NULL). */
 int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, float beta, float scale,
                   double* loss_sum, float* g_out, void* stream);
+
+/* Small fp32 GEMM for the per-field tensors (encoder linears of model/attn.py:177-196 and transformer_net.py:28-44, the
+ * hyper-network heads of variable_net.py:59-65):  C[M][N] = op(A)[M][K] op(B)[K][N] (+ bias[N]) (+ C if accumulate);
+ * ta/tb = 1 reads A as [K][M] / B as [N][K] (row-major, leading dimensions lda/ldb/ldc);
+ * asum (may be NULL) receives sum_k op(A)[m][k] -- the bias gradient when op(A) = grad_out^T. */
+int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+              const float* bias, float* asum, int accumulate, void* stream);
 
 /* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
 int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);

@@ -36,8 +36,8 @@ for prec in ('bf16x2', 'bf16'):
     g = {k: v.to(dev) for k, v in inp.items()}
     cfg = m.point_config()
     with torch.no_grad():
-        w1b1, w2b2, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
-        out_n, jac_n = dpn.pde_fields_and_jacobian(cfg, g['x'], g['y'], g['t'], g['coord_data'], w1b1, w2b2, evec, statics)
+        heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
+        out_n, jac_n = dpn.pde_fields_and_jacobian(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
     torch.cuda.synchronize()
     e_f = (out_n.cpu() - fn).abs().max() / fn.abs().max()
     print('[%s] fields rel err %.3e' % (prec, e_f))
