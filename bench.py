@@ -77,7 +77,7 @@ def main():
     ap.add_argument('--prec', default=os.environ.get('DPN_PREC', 'bf16'), choices=['bf16', 'bf16x2'])
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=2048)
+    ap.add_argument('--cpu-sample', type=int, default=16384)
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
     args = ap.parse_args()

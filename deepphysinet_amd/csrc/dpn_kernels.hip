@@ -643,7 +643,8 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
     const float B = J[4][2] + u * J[4][0] + v * J[4][1];
     const float tc = T - 273.15f;
     const float e_s = 6.112f * expf(17.67f * tc / (tc + 243.5f)) * 100.f;                 // get_qs :181-185
-    const float q_s = fmaxf(0.622f * e_s / (p - 0.378f * e_s), 1e-6f);
+    const float qs_raw = 0.622f * e_s / (p - 0.378f * e_s);
+    const float q_s = (qs_raw != qs_raw) ? qs_raw : fmaxf(qs_raw, 1e-6f);          // torch.maximum propagates NaN (:166)
     const float delta = (omega < 0.f && q >= q_s) ? 1.f : 0.f;
     const float R = (1.f + 0.608f * q) * R_D;
     const float Fv = (L_V * R - C_P * R_V * T) / (C_P * R_V + T * T + L_V * L_V * q_s) * q_s * T;   // precedence as written :161-163
@@ -888,7 +889,14 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     const int xunits = nsx * 1024, yunits_s = nct * 128, total_units = xunits + NS * yunits_s;
 
     uint4 stg[NS * 4];
+    float4 gnext[4], gcur[4];                                           // cotangents of this lane's points: [kk][first/second quad]
     auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const float* gp_ = gnet + tile * 32 + 16 * kk + 4 * h;       // points of registers 8kk..8kk+7
+            gnext[2 * kk] = *reinterpret_cast<const float4*>(gp_);
+            gnext[2 * kk + 1] = *reinterpret_cast<const float4*>(gp_ + 8);
+        }
 #pragma unroll
         for (int q = 0; q < NS * 4; ++q) {
             int u = threadIdx.x + 512 * q;
@@ -923,8 +931,7 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     auto compute = [&](const char* buf, int64_t tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const float* gp_ = gnet + tile * 32 + 16 * kk + 4 * h;       // points of registers 8kk..8kk+7
-            const float4 g0 = *reinterpret_cast<const float4*>(gp_), g1 = *reinterpret_cast<const float4*>(gp_ + 8);
+            const float4 g0 = gcur[2 * kk], g1 = gcur[2 * kk + 1];
             const float gp[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             if (prod == 1 && wave == 0 && i == 0) {
 #pragma unroll
@@ -982,6 +989,8 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     if (t1 > t0) { fetch(t0); commit(lds); }
     __syncthreads();
     for (int64_t tile = t0; tile < t1; ++tile) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gcur[q] = gnext[q];
         if (tile + 1 < t1) fetch(tile + 1);
         if (active) compute(lds + cur * kBuf, tile);
         if (tile + 1 < t1) commit(lds + (cur ^ 1) * kBuf);
@@ -1127,7 +1136,7 @@ __global__ __launch_bounds__(256) void dpn_finish_fc2_kernel(FinishArgs a) {
 //   asum[M] = sum_k op(A)[m][k]  (used as the bias gradient when op(A) = grad_out^T).
 struct SgemmArgs {
     const float *A, *B, *bias;
-    float *C, *asum;
+    float *C, *asum, *ws;
     int M, N, K, lda, ldb, ldc, ta, tb, accumulate, k_per_split;
 };
 
@@ -1188,15 +1197,37 @@ __global__ __launch_bounds__(256) void dpn_sgemm_kernel(SgemmArgs a) {
         for (int j = 0; j < 2; ++j) {
             const int gm = m0 + ty + 16 * i, gn = n0 + tx + 16 * j;
             if (gm < a.M && gn < a.N) {
-                float v = acc[i][j] + ((a.bias && blockIdx.z == 0) ? a.bias[gn] : 0.f);
-                float* c = a.C + (int64_t)gm * a.ldc + gn;
-                if (split) atomicAdd(c, v);                       // C was zeroed by the launcher (or holds the value to accumulate onto)
-                else *c = a.accumulate ? (*c + v) : v;
+                if (split) {                                      // deterministic split-K: partial tile -> workspace[z][M][N]
+                    a.ws[((int64_t)blockIdx.z * a.M + gm) * a.N + gn] = acc[i][j];
+                } else {
+                    const float v = acc[i][j] + (a.bias ? a.bias[gn] : 0.f);
+                    float* c = a.C + (int64_t)gm * a.ldc + gn;
+                    *c = a.accumulate ? (*c + v) : v;
+                }
             }
         }
     if (do_asum && threadIdx.x < BM && m0 + threadIdx.x < a.M) {
-        if (split) atomicAdd(&a.asum[m0 + threadIdx.x], rs);
+        if (split) a.ws[(int64_t)gridDim.z * a.M * a.N + (int64_t)blockIdx.z * a.M + m0 + threadIdx.x] = rs;
         else a.asum[m0 + threadIdx.x] = rs;
+    }
+}
+
+// second pass of the split-K path: fixed-order sum over the splits (+ bias, + C)
+__global__ __launch_bounds__(256) void dpn_sgemm_reduce_kernel(SgemmArgs a, int splits) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t mn = (int64_t)a.M * a.N;
+    if (idx < mn) {
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += a.ws[z * mn + idx];
+        const int gm = (int)(idx / a.N), gn = (int)(idx % a.N);
+        v += a.bias ? a.bias[gn] : 0.f;
+        float* c = a.C + (int64_t)gm * a.ldc + gn;
+        *c = a.accumulate ? (*c + v) : v;
+    }
+    if (a.asum && idx < a.M) {
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += a.ws[splits * mn + (int64_t)z * a.M + idx];
+        a.asum[idx] = v;
     }
 }
 
@@ -1224,9 +1255,10 @@ __global__ void dpn_selftest_kernel(float* out) {
 // ------------------------------------------------------------------------------------------------ C ABI
 static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 static inline int choose_splits(int64_t n_pad) {
-    int64_t c = n_pad / 64 / 8;
+    // 24 workgroups (4 products x 6 nets) per split; two 8-wave workgroups fit on a CU -> ~2 x 256 CUs / 24
+    int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
-    if (c > 10) c = 10;
+    if (c > 21) c = 21;
     return (int)c;
 }
 static inline int ck(hipError_t e) { return (int)e; }
@@ -1336,27 +1368,28 @@ int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_
 }
 
 int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-              const float* bias, float* asum, int accumulate, void* stream) {
+              const float* bias, float* asum, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return -1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
     int splits = 1;
-    if (tiles < 256 && K >= 1024 && ldc == N) {                  // long reductions with few output tiles: split K over the grid
+    if (workspace && tiles < 256 && K >= 1024) {                 // long reductions with few output tiles: split K over the grid
         splits = (512 + tiles - 1) / tiles;
         const int maxs = K / 256;
         if (splits > maxs) splits = maxs;
         if (splits > 32) splits = 32;
+        while (splits > 1 && (int64_t)splits * ((int64_t)M * N + M) * 4 > workspace_bytes) --splits;
         if (splits < 1) splits = 1;
     }
     int kps = (K + splits - 1) / splits;
     kps = ((kps + 31) / 32) * 32;
     splits = (K + kps - 1) / kps;
-    if (splits > 1) {
-        if (!accumulate && hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s) != hipSuccess) return -2;
-        if (asum && hipMemsetAsync(asum, 0, (size_t)M * sizeof(float), s) != hipSuccess) return -2;
-    }
-    SgemmArgs a{A, B, bias, C, asum, M, N, K, lda, ldb, ldc, ta, tb, accumulate, kps};
+    SgemmArgs a{A, B, bias, C, asum, reinterpret_cast<float*>(workspace), M, N, K, lda, ldb, ldc, ta, tb, accumulate, kps};
     hipLaunchKernelGGL(dpn_sgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, splits), dim3(256), 0, s, a);
+    if (splits > 1) {
+        const int64_t work = (int64_t)M * N > M ? (int64_t)M * N : M;
+        hipLaunchKernelGGL(dpn_sgemm_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a, splits);
+    }
     return ck(hipGetLastError());
 }
 

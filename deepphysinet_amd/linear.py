@@ -17,7 +17,11 @@ def _p(t):
 
 def _sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, asum=None, accumulate=0):
     lib = L.load()
-    L.check(lib.dpn_sgemm(ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias), _p(asum), accumulate,
+    ws, ws_bytes = None, 0
+    if K >= 1024 and ((M + 31) // 32) * ((N + 31) // 32) < 256:        # long reduction, small output: deterministic split-K scratch
+        ws_bytes = 32 * (M * N + M) * 4
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=C.device)
+    L.check(lib.dpn_sgemm(ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias), _p(asum), accumulate, _p(ws), ws_bytes,
                           torch.cuda.current_stream().cuda_stream), 'dpn_sgemm')
 
 

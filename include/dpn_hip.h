@@ -127,9 +127,10 @@ int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, flo
 /* Small fp32 GEMM for the per-field tensors (encoder linears of model/attn.py:177-196 and transformer_net.py:28-44, the
  * hyper-network heads of variable_net.py:59-65):  C[M][N] = op(A)[M][K] op(B)[K][N] (+ bias[N]) (+ C if accumulate);
  * ta/tb = 1 reads A as [K][M] / B as [N][K] (row-major, leading dimensions lda/ldb/ldc);
- * asum (may be NULL) receives sum_k op(A)[m][k] -- the bias gradient when op(A) = grad_out^T. */
+ * asum (may be NULL) receives sum_k op(A)[m][k] -- the bias gradient when op(A) = grad_out^T.
+ * workspace (may be NULL): scratch for the deterministic two-pass split-K used when K is long and the output small. */
 int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-              const float* bias, float* asum, int accumulate, void* stream);
+              const float* bias, float* asum, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
 int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);

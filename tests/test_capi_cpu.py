@@ -1,0 +1,116 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/dpn_hip.h declares; the layout
+algebra the kernels rely on (dpn_layout.h) is bijective.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_build_and_load():
+    import __graft_entry__ as g
+    g.build()
+    from deepphysinet_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    assert _lib.load().dpn_version() >= 1
+
+
+def test_every_declared_symbol_is_exported():
+    from deepphysinet_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'dpn_hip.h')).read()
+    declared = set(re.findall(r'^\s*int\s+(dpn_\w+)\s*\(', header, flags=re.M))
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+
+
+def test_sizes_host_function():
+    from deepphysinet_amd import _lib
+    lib = _lib.load()
+    sz = _lib.DpnSizes()
+    assert lib.dpn_sizes(37265, 1, ctypes.byref(sz)) == 0
+    assert sz.n_pad == 37376 and sz.n_pad % 128 == 0
+    assert sz.packed == 6 * (800 * 1024 + 6 * 1024 + 16)
+    sz2 = _lib.DpnSizes()
+    assert lib.dpn_sizes(37265, 2, ctypes.byref(sz2)) == 0
+    assert sz2.saved > sz.saved and sz2.operands > sz.operands
+    assert lib.dpn_sizes(0, 1, ctypes.byref(sz)) != 0          # bad arguments are rejected, not ignored
+    assert lib.dpn_sizes(16, 3, ctypes.byref(sz)) != 0
+
+
+def test_struct_layouts_match_header():
+    from deepphysinet_amd import _lib
+    assert ctypes.sizeof(_lib.DpnNetPtrs) == 13 * 8
+    assert ctypes.sizeof(_lib.DpnNetGradPtrs) == 13 * 8
+    assert ctypes.sizeof(_lib.DpnGeometry) == 5 * 4
+    assert ctypes.sizeof(_lib.DpnPhysics) == 6 * 4 * 6
+
+
+LAYOUT_TEST = r'''
+#include <cstdio>
+#include <set>
+#include "dpn_layout.h"
+using namespace dpn;
+int slot_of_ch(int ch) { return (ch & ~15) + 8 * ((ch >> 2) & 1) + 4 * ((ch >> 3) & 1) + (ch & 3); }
+int main() {
+    // chained k-slots cover every channel once, and agree with the accumulator rows they are built from
+    std::set<int> seen;
+    for (int ks = 0; ks < 16; ++ks) for (int h = 0; h < 2; ++h) for (int e = 0; e < 8; ++e) {
+        const int ch = chain_ch(ks, h, e);
+        if (!seen.insert(ch).second) return 1;
+        const int T = ks / 2, r = 8 * (ks & 1) + e;
+        if (ch != 32 * T + drow32(r, h)) return 2;
+        if (slot_of_ch(ch) != 16 * ks + 8 * h + e) return 3;
+    }
+    if (seen.size() != 256) return 4;
+    // coordinate / data PE slots are permutations of the reference's 192 channels
+    std::set<int> p3, p6, g;
+    for (int ks = 0; ks < 12; ++ks) for (int h = 0; h < 2; ++h) for (int e = 0; e < 8; ++e) {
+        p3.insert(pe3_ch(ks, h, e)); p6.insert(pe6_ch(ks, h, e));
+        // sin/cos of one angle sit in adjacent slots; the coordinate index is constant over a k-step quad
+        if ((e & 1) == 0 && pe3_ch(ks, h, e + 1) != pe3_ch(ks, h, e) + 3) return 5;
+        if (pe3_ch(ks, h, e) % 3 != ks / 4) return 6;
+        if (pe6_ch(ks, h, e) % 6 != ks / 2) return 7;
+    }
+    if (p3.size() != 192 || p6.size() != 192 || *p3.rbegin() != 191 || *p6.rbegin() != 191) return 8;
+    // the Jacobian GEMM's row order hands every lane the cotangent of its own q-th feature
+    for (int rho = 0; rho < 192; ++rho) g.insert(gpe_row_to_pe3_ch(rho));
+    if (g.size() != 192) return 9;
+    for (int T = 0; T < 6; ++T) for (int h = 0; h < 2; ++h) for (int r = 0; r < 16; ++r) {
+        const int rho = 32 * T + drow32(r, h);
+        const int q = 16 * T + r;
+        if (gpe_row_to_pe3_ch(rho) != pe3_ch(q / 8, h, q % 8)) return 10;
+    }
+    if (kPackKB != 800) return 11;
+    std::puts("layout ok");
+    return 0;
+}
+'''
+
+
+def test_layout_algebra(tmp_path):
+    src = tmp_path / 'layout_test.cpp'
+    src.write_text(LAYOUT_TEST)
+    exe = tmp_path / 'layout_test'
+    subprocess.run(['g++', '-std=c++17', '-O1', '-I', os.path.join(ROOT, 'deepphysinet_amd', 'csrc'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, 'layout check %d failed' % out.returncode
+    assert 'layout ok' in out.stdout
+
+
+def test_point_path_refuses_cpu_tensors():
+    import torch
+    from deepphysinet_amd.configs import ncep_config
+    from deepphysinet_amd.interface import builder_models
+    m = builder_models(**ncep_config())
+    n = 8
+    z = torch.zeros(n, 1)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.place_one_batch(z, z, z, z, torch.zeros(1, 159, 2405), torch.zeros(n, 6), torch.zeros(1, 1, 1), torch.nn.MSELoss(),
+                          m.train_cfg['losses']['loss_factor'], 0, 0, 'cpu')

@@ -1,0 +1,135 @@
+"""CPU: host-side mirror of the reference interface (module tree, state_dict contract, encoder math, factories, generic
+residual expressions, checkpoints).  The per-point HIP path is not exercised here (it has no CPU form)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from deepphysinet_amd.configs import ncep_config
+from deepphysinet_amd.interface import builder_models
+from deepphysinet_amd.losses import builder_loss
+from deepphysinet_amd.model import PhysicsNet
+from deepphysinet_amd.utils.position_encoding import SineCosPE
+from oracle import dpn_oracle as O
+from oracle.fill import fill_state_dict_, synthetic_inputs
+
+
+@pytest.fixture(scope='module')
+def model():
+    m = builder_models(**ncep_config())
+    sd = m.physics_net.state_dict()
+    fill_state_dict_(sd)
+    m.physics_net.load_state_dict(sd)
+    return m
+
+
+def test_state_dict_names_shapes_and_order(golden_dir, model):
+    d = np.load(os.path.join(golden_dir, 'f0_state_names.npz'))
+    ref = [(str(k), str(s)) for k, s in zip(d['names'], d['shapes'])]
+    mine = [(k, str(tuple(v.shape))) for k, v in model.physics_net.state_dict().items()]
+    assert mine == ref                      # a reference checkpoint loads with strict=True
+
+
+def test_sine_cos_pe_matches_reference_vectors(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'f1_pe.npz'))
+    t = torch.from_numpy
+    assert np.array_equal(SineCosPE(3, N_freqs=32, include_input=False)(t(d['in3'])).numpy(), d['pe3'])
+    assert np.array_equal(SineCosPE(6, N_freqs=16, include_input=False)(t(d['in6'])).numpy(), d['pe6'])
+    assert np.array_equal(SineCosPE(1, N_freqs=96, include_input=False)(t(d['in1'])).numpy(), d['pe1_96'])
+    pe = SineCosPE(3, N_freqs=4)
+    assert pe.out_dim == 27 and pe(torch.zeros(5, 3)).shape == (5, 27)
+    assert 'freq_bands' not in pe.state_dict()          # non-persistent buffer, like the reference
+
+
+def test_encoding_coord(golden_dir, model):
+    d = np.load(os.path.join(golden_dir, 'f1_pe.npz'))
+    t = torch.from_numpy
+    enc = model.encoding_coord(t(d['x']), t(d['y']), t(d['t']), model.pred_t_span).numpy()
+    assert np.array_equal(enc, d['enc'])
+    assert model.pred_t_span == 86400.0 and model.dx == 27000.0 and (model.lat_size, model.lon_size) == (145, 257)
+
+
+def test_encoder_matches_reference_vectors(golden_dir, model):
+    d = np.load(os.path.join(golden_dir, 'f2_encoder.npz'))
+    inp = synthetic_inputs(4)
+    with torch.no_grad():
+        for h in (0, 24, 336):
+            mo = model.physics_net.meta_net(inp['field_data'], torch.full((1, 1, 1), h / 360.0)).numpy()
+            ref = d['meta_out_h%d' % h]
+            assert np.abs(mo - ref).max() <= 3e-6 * np.abs(ref).max()
+
+
+def test_hyper_heads_batched_gemm_equals_per_net_linears(model):
+    """PhysicsNet.field_weights packs the 12 head GEMMs into one; compare with the reference formulation net by net."""
+    inp = synthetic_inputs(4)
+    net = model.physics_net
+    with torch.no_grad():
+        heads, evec, statics = net.field_weights(inp['field_data'], inp['forecast_h'])
+        meta_out = net.meta_net(inp['field_data'], inp['forecast_h'])
+        for k, vn in enumerate(net.nets_in_output_order()):
+            w1b1, w2b2, e = vn.hyper_weights(meta_out, inp['forecast_h'])
+            assert torch.allclose(heads[:, k * 193:(k + 1) * 193], w1b1, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(heads[:, 1158 + k * 257:1158 + (k + 1) * 257], w2b2, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(evec[k], e, rtol=1e-5, atol=1e-6)
+    assert len(statics) == 48 and statics[6].shape == (1, 256)
+
+
+def test_loss_factory_surface():
+    assert isinstance(builder_loss('MSELoss'), torch.nn.MSELoss)
+    crit = builder_loss(name='WeightSmoothL1Loss', beta=0.1)
+    a, b = torch.randn(32, 6), torch.randn(32, 6)
+    assert torch.allclose(crit(a, b), torch.nn.functional.smooth_l1_loss(a, b, beta=0.1))
+    with pytest.raises(NotImplementedError):
+        builder_loss('nope')
+    with pytest.raises(NotImplementedError):
+        builder_models(name='nope')
+
+
+def test_generic_equation_methods_equal_reference_terms(golden_dir, model):
+    """The six *_equation methods + inverse_norm, fed with autograd-connected oracle fields, reproduce the golden scalars."""
+    d = np.load(os.path.join(golden_dir, 'f345_pde_clip1_fp32.npz'))
+    inp = synthetic_inputs(256, tag='inter')
+    st = O.make_state()
+    x, y, t = (inp[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
+    pe = model.encoding_coord(x, y, t, model.pred_t_span)
+    fn = O.physics_net_forward(st, inp['field_data'], pe, inp['coord_data'], inp['forecast_h'])
+    model.with_clip = True
+    u, v, P, T, q, rio = model.inverse_norm(*fn, obs_norm_cfg=model.obs_norm_cfg)
+    crit = builder_loss('MSELoss')
+    lf = model.train_cfg['losses']['loss_factor']
+    f = inp['f']
+    mine = [model.montion_equation_u(x, y, t, u, v, P, rio, f, crit, factor=lf['motion_u_factor']),
+            model.montion_equation_v(x, y, t, u, v, P, rio, f, crit, factor=lf['motion_v_factor']),
+            model.continuous_equation(x, y, t, u, v, rio, crit, factor=lf['continuous_factor']),
+            model.energy_equation(x, y, t, u, v, P, T, rio, q, crit, factor=lf['energy_factor']),
+            model.vapor_equation(x, y, t, u, v, P, T, q, crit, factor=lf['vapor_factor']),
+            model.gas_equation(P, T, rio, q, crit, factor=lf['gas_factor'])]
+    mine = np.array([float(m_.detach()) for m_ in mine])
+    assert np.all(np.abs(mine - d['parts']) <= 2e-5 * np.abs(d['parts']))
+
+
+def test_checkpoint_roundtrip_and_ddp_prefix(tmp_path, model):
+    model.save_model(str(tmp_path), epoch=3, global_step=77, dx=27000.0)
+    assert os.path.exists(tmp_path / 'physics_3.pth') and os.path.exists(tmp_path / 'physics_latest.pth')
+    sd, epoch, step = model.load_model(str(tmp_path), prefix='physics')
+    assert epoch == 4 and step == 77 and sd['dx'] == 27000.0
+    model.physics_net.load_state_dict(sd['model'], strict=True)
+    # a checkpoint written under DistributedDataParallel carries 'module.' prefixes
+    torch.save({'model': {'module.' + k: v for k, v in model.physics_net.state_dict().items()}, 'epoch': 0, 'gobal_step': 1},
+               tmp_path / 'ddp.pth')
+    sd2, _, _ = model.load_model(str(tmp_path / 'ddp.pth'))
+    model.physics_net.load_state_dict(sd2['model'], strict=True)
+
+
+def test_point_config_follows_the_config_file(model):
+    cfg = model.point_config()
+    assert cfg.factors == (1e3, 1e3, 1e10, 1e1, 1e14, 1e-7)
+    ph = cfg.physics()
+    assert list(ph.clip_on) == [0, 0, 1, 1, 1, 1]               # u, v never clipped
+    assert abs(ph.std[2] - 13296.749084125422) < 1e-2 and ph.clip_hi[2] == 500000.0
+    model.with_clip = False
+    assert list(model.point_config().physics().clip_on) == [0] * 6
+    model.with_clip = True
+    with pytest.raises(NotImplementedError):
+        model._check_pde_criterion(torch.nn.L1Loss())
