@@ -95,7 +95,8 @@ def main():
     def build(prec):
         torch.manual_seed(1)                      # identical random-init weights on every rank
         m = builder_models(**ncep_config(), precision=prec).to(dev)
-        opt = torch.optim.Adam(m.physics_net.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True, fused=True)
+        from deepphysinet_amd.optim import FusedClipAdam
+        opt = FusedClipAdam(m.physics_net.parameters(), lr=1e-4, weight_decay=1e-4, max_norm=2.5e7)   # clip_grad_norm_ + Adam, cfg:151-155
         return m, opt
 
     batch = synth_batch(args.points, dev, seed=1 + rank)
@@ -113,8 +114,7 @@ def main():
             loss.backward()
             if sync is not None:
                 sync(params)
-            torch.nn.utils.clip_grad_norm_(params, max_norm=2.5e7, foreach=True)
-            opt.step()
+            opt.step()                                 # global-norm clip (2.5e7) + Adam in the HIP library
             return loss
         return step
 

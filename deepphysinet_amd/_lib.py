@@ -32,6 +32,12 @@ class DpnPhysics(Structure):
                 ('clip_on', c_int * NETS), ('factor', c_float * NETS)]
 
 
+class DpnGemmProblem(Structure):
+    _fields_ = [('A', c_void_p * 3), ('B', c_void_p * 3), ('lda', c_int32 * 3), ('ldb', c_int32 * 3), ('bias', c_void_p), ('C', c_void_p),
+                ('asum', c_void_p), ('M', c_int32), ('N', c_int32), ('K', c_int32), ('ldc', c_int32), ('ta', c_int32), ('tb', c_int32),
+                ('nterms', c_int32)]
+
+
 class DpnSizes(Structure):
     _fields_ = [('n_pad', c_int64), ('packed', c_int64), ('saved', c_int64), ('operands', c_int64), ('partials', c_int64),
                 ('k_splits', c_int32)]
@@ -53,6 +59,9 @@ EXPORTS = {
     'dpn_smooth_l1': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'dpn_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                           c_void_p, c_int64, c_void_p]),
+    'dpn_sgemm_batch': (c_int, [c_int, POINTER(DpnGemmProblem), c_void_p]),
+    'dpn_clip_adam': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                              c_float, c_float, c_void_p, c_void_p]),
     'dpn_selftest': (c_int, [c_void_p, c_void_p]),
 }
 

@@ -185,23 +185,28 @@ __global__ __launch_bounds__(256) void dpn_pack_vectors_kernel(PackArgs a) {
 template <int NS>
 struct Pipe {
     static constexpr int kBufBytes = 16 * 1024 * NS;
+    static constexpr int kDepth = (NS == 1) ? 2 : 1;   // chunks in flight in registers (bf16x2 has no registers to spare)
     const uint4* g;
     char* lds;
     int cur;
-    uint4 stg[4 * NS];
+    uint4 stg[kDepth][4 * NS];
 
     DEV void init(const void* gsrc, char* lds_base) { g = reinterpret_cast<const uint4*>(gsrc); lds = lds_base; cur = 0; }
-    template <int NK> DEV void fetch() {
+    template <int NK> DEV void fetch(const int set) {
 #pragma unroll
-        for (int i = 0; i < NK * NS / 4; ++i) stg[i] = g[i * 256 + threadIdx.x];
+        for (int i = 0; i < NK * NS / 4; ++i) stg[set][i] = g[i * 256 + threadIdx.x];
         g += NK * NS * 64;
     }
-    template <int NK> DEV void commit() {
+    template <int NK> DEV void commit(const int set) {
         uint4* d = reinterpret_cast<uint4*>(lds + (cur ^ 1) * kBufBytes);
 #pragma unroll
-        for (int i = 0; i < NK * NS / 4; ++i) d[i * 256 + threadIdx.x] = stg[i];
+        for (int i = 0; i < NK * NS / 4; ++i) d[i * 256 + threadIdx.x] = stg[set][i];
     }
-    template <int NK> DEV void prime() { cur = 1; fetch<NK>(); commit<NK>(); __syncthreads(); cur = 0; }
+    // chunk 0 -> LDS buffer 0; with depth 2 chunk 1 is already in flight when the first MFMA issues
+    template <int NK0, int NK1> DEV void prime() {
+        cur = 1; fetch<NK0>(0); commit<NK0>(0); __syncthreads(); cur = 0;
+        if constexpr (kDepth == 2) fetch<NK1>(1);
+    }
     DEV void flip() { __syncthreads(); cur ^= 1; }
     DEV const char* cur_buf() const { return lds + cur * kBufBytes; }
 };
@@ -211,12 +216,26 @@ struct Pipe {
 //               channel-per-lane / points-in-registers, which is the K-operand layout of the weight-gradient GEMMs)
 template <int NS, int NK, bool SWAP>
 DEV void mma_chunk(const char* buf, const Frag<NS>* act, f32x16& acc) {
+    // The A fragments of a chunk are read LOOKAHEAD k-steps ahead of the MFMA that consumes them, so that the LDS latency
+    // (~64-128 cycles) hides under the 32-cycle MFMAs instead of being paid once per MFMA.
+    constexpr int LOOKAHEAD = (NS == 1) ? 4 : 2;
     const int lane = threadIdx.x & 63;
+    const char* base = buf + lane * 16;
+    bf16x8 w[LOOKAHEAD][NS];
+#pragma unroll
+    for (int i = 0; i < LOOKAHEAD; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) w[i][s2] = *reinterpret_cast<const bf16x8*>(base + ((i * NS + s2) * 64) * 16);
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-        const bf16x8 whi = *reinterpret_cast<const bf16x8*>(buf + ((ks * NS) * 64 + lane) * 16);
+        bf16x8 whi = w[ks % LOOKAHEAD][0], wlo;
+        if constexpr (NS == 2) wlo = w[ks % LOOKAHEAD][1];
+        if (ks + LOOKAHEAD < NK) {
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+                w[ks % LOOKAHEAD][s2] = *reinterpret_cast<const bf16x8*>(base + (((ks + LOOKAHEAD) * NS + s2) * 64) * 16);
+        }
         if constexpr (NS == 2) {
-            const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(buf + ((ks * NS + 1) * 64 + lane) * 16);
             if constexpr (SWAP) { acc = mfma(as_bf(act[ks].w[1]), whi, acc); acc = mfma(as_bf(act[ks].w[0]), wlo, acc); }
             else { acc = mfma(whi, as_bf(act[ks].w[1]), acc); acc = mfma(wlo, as_bf(act[ks].w[0]), acc); }
         }
@@ -405,15 +424,18 @@ struct FwdArgs {
     void* saved;
 };
 
-// One pipeline step on output tile T: prefetch the next chunk (NKN k-steps, 0 = none), multiply the current one, run the
-// epilogue of the PREVIOUS tile in the shadow of these MFMAs (it only touches that tile's accumulator), publish the prefetch.
-#define DPN_STEP(NK, NKN, SWAP, ACT, ACC, EPI_PREV)                                  \
-    do {                                                                             \
-        if constexpr ((NKN) > 0) pipe.template fetch<(NKN)>();                       \
-        mma_chunk<NS, (NK), (SWAP)>(pipe.cur_buf(), (ACT), (ACC));                   \
-        EPI_PREV;                                                                    \
-        if constexpr ((NKN) > 0) pipe.template commit<(NKN)>();                      \
-        pipe.flip();                                                                 \
+// One pipeline step on the chunk of output tile T (T's parity = the chunk's parity: every layer has an even chunk count).
+// NK = k-steps of this chunk, NKN / NKNN = of the next / the one after (0 = none).  Depth 2: fetch chunk c+2 into register
+// set T&1, multiply chunk c, run the epilogue of the PREVIOUS tile in the shadow of these MFMAs (it only touches that tile's
+// accumulator), publish chunk c+1 (fetched one step ago) to the other LDS buffer.  Depth 1: fetch c+1 / publish c+1.
+#define DPN_STEP(T, NK, NKN, NKNN, SWAP, ACT, ACC, EPI_PREV)                                              \
+    do {                                                                                                  \
+        if constexpr (Pipe<NS>::kDepth == 2) { if constexpr ((NKNN) > 0) pipe.template fetch<(NKNN)>((T) & 1); } \
+        else { if constexpr ((NKN) > 0) pipe.template fetch<(NKN)>(0); }                                   \
+        mma_chunk<NS, (NK), (SWAP)>(pipe.cur_buf(), (ACT), (ACC));                                        \
+        EPI_PREV;                                                                                         \
+        if constexpr ((NKN) > 0) pipe.template commit<(NKN)>(Pipe<NS>::kDepth == 2 ? (((T) + 1) & 1) : 0); \
+        pipe.flip();                                                                                      \
     } while (0)
 
 template <int NS>
@@ -443,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 
     Pipe<NS> pipe;
     pipe.init(pk, lds_w);
-    pipe.template prime<12>();          // first chunk: w1 tile 0 (the barrier inside also publishes lds_vec)
+    pipe.template prime<12, 12>();      // first chunk: w1 tile 0 (the barrier inside also publishes lds_vec)
 
     f32x16 acc[8];
     u32 m1w[4] = {0u, 0u, 0u, 0u};
@@ -465,9 +487,10 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             acc_init_vec(acc[T], lds_vec, kVecB1, h, T, 1.0f);
-            if (T == 0) DPN_STEP(12, 12, false, pe, acc[T], (void)0);
-            else if (T < 7) DPN_STEP(12, 12, false, pe, acc[T], epi1(T - 1));
-            else DPN_STEP(12, 16, false, pe, acc[T], epi1(T - 1));          // next: w2 tile 0
+            if (T == 0) DPN_STEP(T, 12, 12, 12, false, pe, acc[T], (void)0);
+            else if (T < 6) DPN_STEP(T, 12, 12, 12, false, pe, acc[T], epi1(T - 1));
+            else if (T == 6) DPN_STEP(T, 12, 12, 16, false, pe, acc[T], epi1(T - 1));
+            else DPN_STEP(T, 12, 16, 16, false, pe, acc[T], epi1(T - 1));   // next: w2 tile 0
         }
         epi1(7);
     }
@@ -488,16 +511,18 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             acc_init_vec(acc[T], lds_vec, kVecCvec, h, T, 1.0f);
-            if (T < 7) DPN_STEP(16, 16, false, actA, acc[T], (void)0);
-            else DPN_STEP(16, 12, false, actA, acc[T], (void)0);               // next: Wd tile 0
+            if (T < 6) DPN_STEP(T, 16, 16, 16, false, actA, acc[T], (void)0);
+            else if (T == 6) DPN_STEP(T, 16, 16, 12, false, actA, acc[T], (void)0);
+            else DPN_STEP(T, 16, 12, 12, false, actA, acc[T], (void)0);        // next: Wd tile 0
         }
         Frag<NS> pe6[12];
         build_pe6<NS>(L, cd6, pe6, 1.0f);
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
-            if (T == 0) DPN_STEP(12, 12, false, pe6, acc[T], (void)0);
-            else if (T < 7) DPN_STEP(12, 12, false, pe6, acc[T], epi2(T - 1));
-            else DPN_STEP(12, 16, false, pe6, acc[T], epi2(T - 1));            // next: W1 tile 0
+            if (T == 0) DPN_STEP(T, 12, 12, 12, false, pe6, acc[T], (void)0);
+            else if (T < 6) DPN_STEP(T, 12, 12, 12, false, pe6, acc[T], epi2(T - 1));
+            else if (T == 6) DPN_STEP(T, 12, 12, 16, false, pe6, acc[T], epi2(T - 1));
+            else DPN_STEP(T, 12, 16, 16, false, pe6, acc[T], epi2(T - 1));     // next: W1 tile 0
         }
         epi2(7);
     }
@@ -526,8 +551,8 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         acc_init_vec(acc[T], lds_vec, kVecBf1, h, T, 1.0f);
-        if (T == 0) DPN_STEP(16, 16, false, actB, acc[T], (void)0);            // next: W1 tile T+1, or W1^T tile 0
-        else DPN_STEP(16, 16, false, actB, acc[T], epi3(T - 1));
+        if (T == 0) DPN_STEP(T, 16, 16, 16, false, actB, acc[T], (void)0);     // next: W1 tile T+1, or W1^T tile 0
+        else DPN_STEP(T, 16, 16, 16, false, actB, acc[T], epi3(T - 1));
     }
     epi3(7);
     {
@@ -546,8 +571,8 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         acc_init_vec(acc[T], lds_vec, kVecWo, h, T, 2.0f);
-        if (T == 0) DPN_STEP(16, 16, false, actA, acc[T], (void)0);            // next: W1^T tile T+1, or w2^T tile 0
-        else DPN_STEP(16, 16, false, actA, acc[T], epiv(T - 1));
+        if (T == 0) DPN_STEP(T, 16, 16, 16, false, actA, acc[T], (void)0);     // next: W1^T tile T+1, or w2^T tile 0
+        else DPN_STEP(T, 16, 16, 16, false, actA, acc[T], epiv(T - 1));
     }
     epiv(7);
     // ---------------- y = w2^T v ; t1 = m1 (.) y -> actA (+ saved T1)
@@ -562,10 +587,8 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         acc[T] = (f32x16)0.f;
-        if (T == 0) DPN_STEP(16, 16, false, actB, acc[T], (void)0);
-        else if (T < 7) DPN_STEP(16, 16, false, actB, acc[T], epiy(T - 1));
-        else if (a.jac_n) DPN_STEP(16, 16, false, actB, acc[T], epiy(T - 1));  // next: w1^T tile 0
-        else DPN_STEP(16, 0, false, actB, acc[T], epiy(T - 1));
+        if (T == 0) DPN_STEP(T, 16, 16, 16, false, actB, acc[T], (void)0);
+        else DPN_STEP(T, 16, 16, 16, false, actB, acc[T], epiy(T - 1));        // the w1^T chunks always exist: prefetching them is harmless
     }
     epiy(7);
     if (!a.jac_n) return;
@@ -586,9 +609,10 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 6; ++T) {
         acc[T] = (f32x16)0.f;
-        if (T == 0) DPN_STEP(16, 16, false, actA, acc[T], (void)0);
-        else if (T < 5) DPN_STEP(16, 16, false, actA, acc[T], epij(T - 1));
-        else DPN_STEP(16, 0, false, actA, acc[T], epij(T - 1));
+        if (T == 0) DPN_STEP(T, 16, 16, 16, false, actA, acc[T], (void)0);
+        else if (T < 4) DPN_STEP(T, 16, 16, 16, false, actA, acc[T], epij(T - 1));
+        else if (T == 4) DPN_STEP(T, 16, 16, 0, false, actA, acc[T], epij(T - 1));
+        else DPN_STEP(T, 16, 0, 0, false, actA, acc[T], epij(T - 1));
     }
     epij(5);
 #pragma unroll
@@ -771,7 +795,7 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 
     Pipe<NS> pipe;
     pipe.init(pk, lds_w);
-    pipe.template prime<12>();
+    pipe.template prime<12, 12>();
 
     f32x16 acc[8];
     Frag<NS> actA[16];
@@ -793,9 +817,10 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             acc_init_vec(acc[T], lds_vec, kVecB1, h, T, g);
-            if (T == 0) DPN_STEP(12, 12, false, z0, acc[T], (void)0);
-            else if (T < 7) DPN_STEP(12, 12, false, z0, acc[T], epi1(T - 1));
-            else DPN_STEP(12, 16, false, z0, acc[T], epi1(T - 1));
+            if (T == 0) DPN_STEP(T, 12, 12, 12, false, z0, acc[T], (void)0);
+            else if (T < 6) DPN_STEP(T, 12, 12, 12, false, z0, acc[T], epi1(T - 1));
+            else if (T == 6) DPN_STEP(T, 12, 12, 16, false, z0, acc[T], epi1(T - 1));
+            else DPN_STEP(T, 12, 16, 16, false, z0, acc[T], epi1(T - 1));
         }
         epi1(7);
     }
@@ -826,14 +851,16 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
             const float cv = lds_vec[kVecCvec * 256 + hh * 128 + T * 16 + rr];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[T][r] = g16[r] * cv;
-            if (T < 7) DPN_STEP(16, 16, true, actA, acc[T], (void)0);
-            else DPN_STEP(16, 12, true, actA, acc[T], (void)0);
+            if (T < 6) DPN_STEP(T, 16, 16, 16, true, actA, acc[T], (void)0);
+            else if (T == 6) DPN_STEP(T, 16, 16, 12, true, actA, acc[T], (void)0);
+            else DPN_STEP(T, 16, 12, 12, true, actA, acc[T], (void)0);
         }
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
-            if (T == 0) DPN_STEP(12, 12, true, g6, acc[T], (void)0);
-            else if (T < 7) DPN_STEP(12, 12, true, g6, acc[T], epiz(T - 1));
-            else DPN_STEP(12, 0, true, g6, acc[T], epiz(T - 1));
+            if (T == 0) DPN_STEP(T, 12, 12, 12, true, g6, acc[T], (void)0);
+            else if (T < 6) DPN_STEP(T, 12, 12, 12, true, g6, acc[T], epiz(T - 1));
+            else if (T == 6) DPN_STEP(T, 12, 12, 0, true, g6, acc[T], epiz(T - 1));
+            else DPN_STEP(T, 12, 0, 0, true, g6, acc[T], epiz(T - 1));
         }
         epiz(7);
     }
@@ -1231,6 +1258,149 @@ __global__ __launch_bounds__(256) void dpn_sgemm_reduce_kernel(SgemmArgs a, int 
     }
 }
 
+// Several independent small GEMMs in ONE launch (blockIdx.z = problem), each optionally a sum of up to 3 products
+// (C = sum_t op(A_t) op(B_t)): the three q/k/v projections of an attention layer, or the input- and weight-gradient
+// GEMMs of a linear layer, cost one launch instead of 2-6.  Two k-tiles are kept in flight in registers.
+constexpr int kBatchMaxProblems = 4, kBatchMaxTerms = 3;
+struct SgemmProblem {
+    const float* A[kBatchMaxTerms];
+    const float* B[kBatchMaxTerms];
+    int lda[kBatchMaxTerms], ldb[kBatchMaxTerms];
+    const float* bias;
+    float *C, *asum;
+    int M, N, K, ldc, ta, tb, nterms;
+};
+struct SgemmBatch {
+    SgemmProblem p[kBatchMaxProblems];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
+    constexpr int BM = 32, BN = 32, BK = 32;
+    const SgemmProblem& a = batch.p[blockIdx.z];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= a.M || n0 >= a.N) return;
+    __shared__ float As[2][BK][BM + 1];
+    __shared__ float Bs[2][BK][BN + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float rs = 0.f;
+    const bool do_asum = a.asum != nullptr && blockIdx.x == 0;
+    const int ktiles = (a.K + BK - 1) / BK, total = ktiles * a.nterms;
+    float ra[4], rb[4];
+    auto gload = [&](int it) __attribute__((always_inline)) {
+        const int t = it / ktiles, k0 = (it - t * ktiles) * BK;
+        const float* A = a.A[t];
+        const float* B = a.B[t];
+        const int lda = a.lda[t], ldb = a.ldb[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            {
+                const int kk = a.ta ? (e >> 5) : (e & 31), mm = a.ta ? (e & 31) : (e >> 5);
+                const int gm = m0 + mm, gk = k0 + kk;
+                ra[i] = (gm < a.M && gk < a.K) ? (a.ta ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
+            }
+            {
+                const int kk = a.tb ? (e & 31) : (e >> 5), nn = a.tb ? (e >> 5) : (e & 31);
+                const int gk = k0 + kk, gn = n0 + nn;
+                rb[i] = (gk < a.K && gn < a.N) ? (a.tb ? B[(int64_t)gn * ldb + gk] : B[(int64_t)gk * ldb + gn]) : 0.f;
+            }
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            As[buf][a.ta ? (e >> 5) : (e & 31)][a.ta ? (e & 31) : (e >> 5)] = ra[i];
+            Bs[buf][a.tb ? (e & 31) : (e >> 5)][a.tb ? (e >> 5) : (e & 31)] = rb[i];
+        }
+    };
+    gload(0);
+    lstore(0);
+    if (total > 1) gload(1);
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < total) lstore(buf ^ 1);                      // tile it+1 (loaded during the previous iteration) -> other LDS buffer
+        if (it + 2 < total) gload(it + 2);                        // tile it+2 in flight under the FMAs
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            const float a0 = As[buf][kk][ty], a1 = As[buf][kk][ty + 16], b0 = Bs[buf][kk][tx], b1 = Bs[buf][kk][tx + 16];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        if (do_asum && it < ktiles && threadIdx.x < BM) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rs += As[buf][kk][threadIdx.x];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gm = m0 + ty + 16 * i, gn = n0 + tx + 16 * j;
+            if (gm < a.M && gn < a.N) a.C[(int64_t)gm * a.ldc + gn] = acc[i][j] + (a.bias ? a.bias[gn] : 0.f);
+        }
+    if (do_asum && threadIdx.x < BM && m0 + threadIdx.x < a.M) a.asum[m0 + threadIdx.x] = rs;
+}
+
+// ------------------------------------------------------------------------------------------------ fused clip + Adam
+// clip_grad_norm_(max_norm) followed by torch.optim.Adam(lr, betas, eps, weight_decay) (L2-in-gradient, not AdamW), as in
+// interface_physics.py:514-515 / cfg:151-155, for a LIST of tensors per launch (pointer table in the kernel arguments).
+constexpr int kAdamMaxTensors = 72;
+constexpr int kAdamChunk = 2048;                 // elements per block
+struct AdamTable {
+    float* p[kAdamMaxTensors];
+    const float* g[kAdamMaxTensors];
+    float* m[kAdamMaxTensors];
+    float* v[kAdamMaxTensors];
+    int chunk_start[kAdamMaxTensors + 1];        // prefix sum of ceil(numel / kAdamChunk)
+    int numel[kAdamMaxTensors];
+    int n;
+};
+DEV int adam_find(const AdamTable& t, int blk) {
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.chunk_start[mid] <= blk) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void dpn_gradnorm_kernel(AdamTable t, double* sumsq, int* step, int bump_step) {
+    if (bump_step && blockIdx.x == 0 && threadIdx.x == 0) *step += 1;       // device-side step counter: graph replays advance it
+    const int ti = adam_find(t, blockIdx.x);
+    const int base = (blockIdx.x - t.chunk_start[ti]) * kAdamChunk;
+    const float* g = t.g[ti];
+    float s = 0.f;
+    for (int i = base + threadIdx.x; i < base + kAdamChunk && i < t.numel[ti]; i += 256) s = fmaf(g[i], g[i], s);
+    double d = (double)s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void dpn_adam_kernel(AdamTable t, const double* sumsq, const int* step, float lr, float b1, float b2, float eps,
+                                                       float wd, float max_norm, float* out_norm) {
+    const float total = (float)sqrt(*sumsq);
+    if (out_norm && blockIdx.x == 0 && threadIdx.x == 0) *out_norm = total;
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.0f);             // clip_grad_norm_'s clamp(max_norm / (norm + 1e-6), max=1)
+    const float st = (float)(*step);
+    const float bc1 = 1.f - powf(b1, st), bc2s = sqrtf(1.f - powf(b2, st));
+    const float step_size = lr / bc1;
+    const int ti = adam_find(t, blockIdx.x);
+    const int base = (blockIdx.x - t.chunk_start[ti]) * kAdamChunk;
+    float* p = t.p[ti]; const float* g = t.g[ti]; float* m = t.m[ti]; float* v = t.v[ti];
+    for (int i = base + threadIdx.x; i < base + kAdamChunk && i < t.numel[ti]; i += 256) {
+        const float pi = p[i];
+        const float gi = fmaf(wd, pi, g[i] * coef);
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);                   // lerp(m, g, 1-b1)
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step_size * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ MFMA layout self-test
 __global__ void dpn_selftest_kernel(float* out) {
     // A = I (32x32 over two k-steps of 16) against B1[k][j] = k and B2[k][j] = j: D1[i][j] = i, D2[i][j] = j.
@@ -1389,6 +1559,51 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
     if (splits > 1) {
         const int64_t work = (int64_t)M * N > M ? (int64_t)M * N : M;
         hipLaunchKernelGGL(dpn_sgemm_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a, splits);
+    }
+    return ck(hipGetLastError());
+}
+
+int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream) {
+    if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems) return -1;
+    SgemmBatch b;
+    b.n = n_problems;
+    int gx = 0, gy = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const DpnGemmProblem& q = problems[i];
+        if (q.nterms < 1 || q.nterms > kBatchMaxTerms || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0) return -1;
+        SgemmProblem& p = b.p[i];
+        for (int t = 0; t < kBatchMaxTerms; ++t) { p.A[t] = q.A[t]; p.B[t] = q.B[t]; p.lda[t] = q.lda[t]; p.ldb[t] = q.ldb[t]; }
+        p.bias = q.bias; p.C = q.C; p.asum = q.asum; p.M = q.M; p.N = q.N; p.K = q.K; p.ldc = q.ldc; p.ta = q.ta; p.tb = q.tb; p.nterms = q.nterms;
+        gx = gx > (q.N + 31) / 32 ? gx : (q.N + 31) / 32;
+        gy = gy > (q.M + 31) / 32 ? gy : (q.M + 31) / 32;
+    }
+    hipLaunchKernelGGL(dpn_sgemm_batch_kernel, dim3(gx, gy, n_problems), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    return ck(hipGetLastError());
+}
+
+int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const int64_t* numel, double* sumsq_dev, int* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float max_norm, float* out_norm_dev, void* stream) {
+    if (n_tensors <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !sumsq_dev || !step_dev) return -1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(sumsq_dev, 0, sizeof(double), s) != hipSuccess) return -2;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int t0 = 0; t0 < n_tensors; t0 += kAdamMaxTensors) {
+            AdamTable t;
+            t.n = (n_tensors - t0 < kAdamMaxTensors) ? n_tensors - t0 : kAdamMaxTensors;
+            int chunks = 0;
+            for (int i = 0; i < t.n; ++i) {
+                if (numel[t0 + i] <= 0 || numel[t0 + i] > 0x7fffffff) return -1;
+                t.p[i] = params[t0 + i]; t.g[i] = grads[t0 + i]; t.m[i] = exp_avg[t0 + i]; t.v[i] = exp_avg_sq[t0 + i];
+                t.numel[i] = (int)numel[t0 + i];
+                t.chunk_start[i] = chunks;
+                chunks += (t.numel[i] + kAdamChunk - 1) / kAdamChunk;
+            }
+            t.chunk_start[t.n] = chunks;
+            if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel, dim3(chunks), dim3(256), 0, s, t, sumsq_dev, step_dev, t0 == 0 ? 1 : 0);
+            else hipLaunchKernelGGL(dpn_adam_kernel, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq_dev, (const int*)step_dev, lr, beta1,
+                                    beta2, eps, weight_decay, max_norm, out_norm_dev);
+        }
     }
     return ck(hipGetLastError());
 }

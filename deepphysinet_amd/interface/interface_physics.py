@@ -219,6 +219,11 @@ class InterfacePhysics(nn.Module):
         self.physics_net.clear_field_cache()
         if grad_sync is not None:
             grad_sync(self.physics_net.parameters())
-        gnorm = torch.nn.utils.clip_grad_norm_(self.physics_net.parameters(), max_norm=max_norm)
-        optimizer.step()
+        from ..optim import FusedClipAdam
+        if isinstance(optimizer, FusedClipAdam):                  # clip + Adam in one HIP pass
+            optimizer.max_norm = float(max_norm)
+            gnorm = optimizer.step()
+        else:
+            gnorm = torch.nn.utils.clip_grad_norm_(self.physics_net.parameters(), max_norm=max_norm)
+            optimizer.step()
         return train_loss.detach(), {k: v.detach() for k, v in parts.items()}, gnorm

@@ -1,7 +1,8 @@
-"""y = x W^T + b for the per-field tensors (encoder, hyper-network heads) on the library's own small fp32 GEMM.
+"""y = x W^T + b for the per-field tensors (encoder, hyper-network heads) on the library's own small fp32 GEMMs.
 
-At these shapes (M <= 288 tokens, K = N = 256) library GEMMs are latency-bound (19-75 us each on MI355X, rocprofv3
-profiles/round1); dpn_sgemm is a few microseconds.  CPU tensors take torch's F.linear (tests of the encoder math only).
+At these shapes (M <= 288 tokens, K = N = 256) library GEMMs are latency-bound (19-75 us each on MI355X, see
+profiles/); dpn_sgemm_batch runs the independent GEMMs of one layer step in a single launch (the three q/k/v projections;
+the input- and weight-gradient GEMMs of a linear).  CPU tensors take torch's F.linear (tests of the encoder math only).
 """
 import ctypes
 
@@ -12,57 +13,99 @@ from . import _lib as L
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
-def _sgemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, asum=None, accumulate=0):
+def _problem(M, N, K, terms, C, ldc, ta, tb, bias=None, asum=None):
+    q = L.DpnGemmProblem()
+    for i, (A, lda, B, ldb) in enumerate(terms):
+        q.A[i], q.lda[i], q.B[i], q.ldb[i] = A.data_ptr(), lda, B.data_ptr(), ldb
+    q.bias, q.C, q.asum = _p(bias), C.data_ptr(), _p(asum)
+    q.M, q.N, q.K, q.ldc, q.ta, q.tb, q.nterms = M, N, K, ldc, ta, tb, len(terms)
+    return q
+
+
+def _launch(problems):
     lib = L.load()
-    ws, ws_bytes = None, 0
-    if K >= 1024 and ((M + 31) // 32) * ((N + 31) // 32) < 256:        # long reduction, small output: deterministic split-K scratch
-        ws_bytes = 32 * (M * N + M) * 4
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=C.device)
-    L.check(lib.dpn_sgemm(ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias), _p(asum), accumulate, _p(ws), ws_bytes,
-                          torch.cuda.current_stream().cuda_stream), 'dpn_sgemm')
+    arr = (L.DpnGemmProblem * len(problems))(*problems)
+    L.check(lib.dpn_sgemm_batch(len(problems), arr, torch.cuda.current_stream().cuda_stream), 'dpn_sgemm_batch')
 
 
-class _LinearFn(torch.autograd.Function):
+def _sgemm_splitk(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, asum=None):
+    """Single GEMM with the deterministic two-pass split-K (long reductions, small outputs: token embedding, head input-gradient)."""
+    lib = L.load()
+    ws_bytes = 32 * (M * N + M) * 4
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=C.device)
+    L.check(lib.dpn_sgemm(ta, tb, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, _p(bias), _p(asum), 0, ws.data_ptr(),
+                          ws_bytes, torch.cuda.current_stream().cuda_stream), 'dpn_sgemm')
+
+
+def _long_k(M, N, K):
+    return K >= 1024 and ((M + 31) // 32) * ((N + 31) // 32) < 256
+
+
+class _MultiLinearFn(torch.autograd.Function):
+    """(y_1..y_n) = (x W_1^T + b_1, ..., x W_n^T + b_n), n <= 3, one launch forward, one launch backward."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, *wb):
+        n = len(wb) // 2
+        ws = [w if w.is_contiguous() else w.contiguous() for w in wb[:n]]
+        bs = list(wb[n:])
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        w = weight if weight.is_contiguous() else weight.contiguous()
         M, K = x2.shape
-        N = w.shape[0]
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        _sgemm(0, 1, M, N, K, x2, K, w, K, y, N, bias=bias)
-        ctx.save_for_backward(x2, w)
-        ctx.has_bias = bias is not None
-        ctx.x_shape = x.shape
-        return y.reshape(x.shape[:-1] + (N,))
+        ys = [torch.empty((M, w.shape[0]), dtype=torch.float32, device=x.device) for w in ws]
+        if n == 1 and _long_k(M, ws[0].shape[0], K):
+            _sgemm_splitk(0, 1, M, ws[0].shape[0], K, x2, K, ws[0], K, ys[0], ws[0].shape[0], bias=bs[0])
+        else:
+            _launch([_problem(M, w.shape[0], K, [(x2, K, w, K)], y, w.shape[0], 0, 1, bias=b) for w, b, y in zip(ws, bs, ys)])
+        ctx.save_for_backward(x2, *ws)
+        ctx.n, ctx.has_bias, ctx.x_shape = n, [b is not None for b in bs], x.shape
+        return tuple(y.reshape(x.shape[:-1] + (y.shape[1],)) for y in ys)
 
     @staticmethod
-    def backward(ctx, gy):
-        x2, w = ctx.saved_tensors
+    def backward(ctx, *gys):
+        x2, *ws = ctx.saved_tensors
+        n = ctx.n
         M, K = x2.shape
-        N = w.shape[0]
-        g = gy.reshape(M, N)
-        g = g if g.is_contiguous() else g.contiguous()
-        gx = gw = gb = None
+        gs = []
+        for gy, w in zip(gys, ws):
+            g = gy.reshape(M, w.shape[0])
+            gs.append(g if g.is_contiguous() else g.contiguous())
+        dev = x2.device
+        problems = []
+        gx = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty((M, K), dtype=torch.float32, device=g.device)
-            _sgemm(0, 0, M, K, N, g, N, w, K, gx, K)                   # gx = g W
-            gx = gx.reshape(ctx.x_shape)
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty((N, K), dtype=torch.float32, device=g.device)
-            gb = torch.empty((N,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
-            _sgemm(1, 0, N, K, M, g, N, x2, K, gw, K, asum=gb)          # gw = g^T x ; gb = sum_m g
-        elif ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0)
-        return gx, gw, gb
+            gx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            if n == 1 and _long_k(M, K, ws[0].shape[0]):
+                _sgemm_splitk(0, 0, M, K, ws[0].shape[0], gs[0], ws[0].shape[0], ws[0], K, gx, K)
+            else:
+                N0 = ws[0].shape[0]
+                assert all(w.shape[0] == N0 for w in ws)
+                problems.append(_problem(M, K, N0, [(g, N0, w, K) for g, w in zip(gs, ws)], gx, K, 0, 0))      # gx = sum_i g_i W_i
+        gws, gbs = [], []
+        for i, (g, w) in enumerate(zip(gs, ws)):
+            N = w.shape[0]
+            gw = torch.empty((N, K), dtype=torch.float32, device=dev)
+            gb = torch.empty((N,), dtype=torch.float32, device=dev) if ctx.has_bias[i] else None
+            problems.append(_problem(N, K, M, [(g, N, x2, K)], gw, K, 1, 0, asum=gb))                        # gw = g^T x ; gb = sum_m g
+            gws.append(gw)
+            gbs.append(gb)
+        for i in range(0, len(problems), 4):
+            _launch(problems[i:i + 4])
+        return (gx.reshape(ctx.x_shape) if gx is not None else None, *gws, *gbs)
 
 
 def linear(x, weight, bias=None):
     """Drop-in for F.linear on fp32 HIP tensors; falls back to torch only for CPU tensors."""
     if x.is_cuda and x.dtype == torch.float32:
-        return _LinearFn.apply(x, weight, bias)
+        return _MultiLinearFn.apply(x, weight, bias)[0]
     return F.linear(x, weight, bias)
+
+
+def linear_multi(x, weights, biases):
+    """[F.linear(x, w, b) for w, b in ...] as one launch (same output width for all; at most three)."""
+    if x.is_cuda and x.dtype == torch.float32 and len(weights) <= 3:
+        return _MultiLinearFn.apply(x, *weights, *biases)
+    return tuple(F.linear(x, w, b) for w, b in zip(weights, biases))

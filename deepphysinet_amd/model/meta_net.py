@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..linear import linear
+from ..linear import linear, linear_multi
 from ..utils.position_encoding import SineCosPE
 
 
@@ -95,9 +95,14 @@ class AttentionLayer(nn.Module):
     def forward(self, queries, keys, values, attn_mask=None):
         B, L, _ = queries.shape
         S, H = keys.shape[1], self.n_heads
-        q = linear(queries, self.query_projection.weight, self.query_projection.bias).view(B, L, H, -1)
-        k = linear(keys, self.key_projection.weight, self.key_projection.bias).view(B, S, H, -1)
-        v = linear(values, self.value_projection.weight, self.value_projection.bias).view(B, S, H, -1)
+        if queries is keys and keys is values:          # self-attention (the only use in the model): one launch for q, k, v
+            q, k, v = linear_multi(queries, [self.query_projection.weight, self.key_projection.weight, self.value_projection.weight],
+                                   [self.query_projection.bias, self.key_projection.bias, self.value_projection.bias])
+        else:
+            q = linear(queries, self.query_projection.weight, self.query_projection.bias)
+            k = linear(keys, self.key_projection.weight, self.key_projection.bias)
+            v = linear(values, self.value_projection.weight, self.value_projection.bias)
+        q, k, v = q.view(B, L, H, -1), k.view(B, S, H, -1), v.view(B, S, H, -1)
         out, attn = self.inner_attention(q, k, v, attn_mask)
         if self.mix:
             out = out.transpose(2, 1).contiguous()

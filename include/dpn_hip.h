@@ -132,6 +132,24 @@ int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, flo
 int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
               const float* bias, float* asum, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Up to 4 independent small fp32 GEMMs in one launch; each C[M][N] = sum_{t<nterms} op(A_t)[M][K] op(B_t)[K][N] (+ bias[N]),
+ * asum as in dpn_sgemm.  Used for the q/k/v projections (attn.py:183-185) and for the paired input-/weight-gradient GEMMs
+ * of every encoder linear. */
+typedef struct DpnGemmProblem {
+    const float* A[3]; const float* B[3]; int32_t lda[3], ldb[3];
+    const float* bias; float* C; float* asum;
+    int32_t M, N, K, ldc, ta, tb, nterms;
+} DpnGemmProblem;
+int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems /* host array */, void* stream);
+
+/* clip_grad_norm_(max_norm) + torch.optim.Adam step (interface_physics.py:514-515; cfg:151-155: L2-in-gradient weight decay)
+ * over a list of fp32 tensors.  The pointer arrays and `numel` are HOST arrays of length n_tensors (device pointers inside);
+ * sumsq_dev (double), step_dev (int, the Adam step counter, incremented on the device) and out_norm_dev (float, may be NULL)
+ * are device scalars.  Four launches for the 155 tensors of a PhysicsNet. */
+int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const int64_t* numel, double* sumsq_dev, int* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float max_norm, float* out_norm_dev, void* stream);
+
 /* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
 int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);
 

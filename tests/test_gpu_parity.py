@@ -223,3 +223,27 @@ def test_full_grid_properties(prec):
     _, parts, _, _ = O.place_one_batch(st, x, y, t, cpu['f'], cpu['field_data'], cpu['coord_data'], cpu['forecast_h'], GEO, return_parts=True)
     ref = np.array([float(p.detach()) for p in parts])
     assert np.all(np.abs(terms(slice(0, k)) - ref) <= TOL[prec]['loss'] * np.abs(ref)), (terms(slice(0, k)), ref)
+
+
+def test_fused_clip_adam_equals_torch():
+    """dpn_clip_adam vs clip_grad_norm_ + torch.optim.Adam(weight_decay) over three steps, with the clip active and inactive."""
+    from deepphysinet_amd.optim import FusedClipAdam
+    dev = _dev()
+    for max_norm in (1e9, 0.5):
+        torch.manual_seed(0)
+        shapes = [(256, 193), (7,), (1, 128, 256), (300, 17), (1,)] * 20            # 100 tensors: exercises the two-table path
+        a = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+        b = [t.detach().clone().requires_grad_(True) for t in a]
+        ref = torch.optim.Adam(a, lr=1e-3, weight_decay=1e-2)
+        mine = FusedClipAdam(b, lr=1e-3, weight_decay=1e-2, max_norm=max_norm)
+        for it in range(3):
+            gs = [torch.randn_like(t) * (1 + it) for t in a]
+            for t, u, g in zip(a, b, gs):
+                t.grad = g.clone(); u.grad = g.clone()
+            n_ref = torch.nn.utils.clip_grad_norm_(a, max_norm=max_norm)
+            ref.step()
+            n_mine = mine.step()
+            assert abs(float(n_mine) - float(n_ref)) <= 1e-5 * float(n_ref)
+            for t, u in zip(a, b):
+                assert torch.allclose(t, u, rtol=2e-5, atol=2e-7)
+        assert int(mine.step_count) == 3
