@@ -5,7 +5,7 @@ import os
 from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdpn_hip.so')
+LIB_PATH = os.environ.get('DPN_LIB', os.path.join(_HERE, 'libdpn_hip.so'))    # DPN_LIB: experiment builds only
 
 NETS = 6
 PREC_BF16 = 1       # bf16 MFMA operands, fp32 accumulate

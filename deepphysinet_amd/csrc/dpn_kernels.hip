@@ -185,27 +185,26 @@ __global__ __launch_bounds__(256) void dpn_pack_vectors_kernel(PackArgs a) {
 template <int NS>
 struct Pipe {
     static constexpr int kBufBytes = 16 * 1024 * NS;
-    static constexpr int kDepth = (NS == 1) ? 2 : 1;   // chunks in flight in registers (bf16x2 has no registers to spare)
     const uint4* g;
     char* lds;
     int cur;
-    uint4 stg[kDepth][4 * NS];
+    uint4 stg[4 * NS];
 
     DEV void init(const void* gsrc, char* lds_base) { g = reinterpret_cast<const uint4*>(gsrc); lds = lds_base; cur = 0; }
-    template <int NK> DEV void fetch(const int set) {
+    template <int NK> DEV void fetch() {
 #pragma unroll
-        for (int i = 0; i < NK * NS / 4; ++i) stg[set][i] = g[i * 256 + threadIdx.x];
+        for (int i = 0; i < NK * NS / 4; ++i) stg[i] = g[i * 256 + threadIdx.x];
         g += NK * NS * 64;
     }
-    template <int NK> DEV void commit(const int set) {
+    template <int NK> DEV void commit() {
         uint4* d = reinterpret_cast<uint4*>(lds + (cur ^ 1) * kBufBytes);
 #pragma unroll
-        for (int i = 0; i < NK * NS / 4; ++i) d[i * 256 + threadIdx.x] = stg[set][i];
+        for (int i = 0; i < NK * NS / 4; ++i) d[i * 256 + threadIdx.x] = stg[i];
     }
-    // chunk 0 -> LDS buffer 0; with depth 2 chunk 1 is already in flight when the first MFMA issues
+    // chunk 0 -> LDS buffer 0; chunk 1 is in flight (in registers) when the first MFMA issues
     template <int NK0, int NK1> DEV void prime() {
-        cur = 1; fetch<NK0>(0); commit<NK0>(0); __syncthreads(); cur = 0;
-        if constexpr (kDepth == 2) fetch<NK1>(1);
+        cur = 1; fetch<NK0>(); commit<NK0>(); __syncthreads(); cur = 0;
+        fetch<NK1>();
     }
     DEV void flip() { __syncthreads(); cur ^= 1; }
     DEV const char* cur_buf() const { return lds + cur * kBufBytes; }
@@ -342,7 +341,7 @@ DEV float4 ld_vec4(const float* vec_lds, int which, int h, int T, int q4) {
 // ------------------------------------------------------------------------------------------------ K-layout operand matrices
 // Every matrix the points-reduction GEMMs consume is stored "channel-per-lane": for each 32-point tile and each 32-column
 // tile, lane (col = lane&31, h = lane>>5) owns 16 bf16 = the values of its column at points drow32(r,h), r = 0..15, i.e.
-// exactly the A/B fragments of v_mfma_f32_32x32x16_bf16 with K = points (k-step a = registers 8a..8a+7).  Columns are in
+// exactly the A/B fragments of v_mfma_f32_32x32x16_bf16 with K = points (k-step kk = registers 8kk..8kk+7).  Columns are in
 // SLOT order (column 32*ct + jj <-> k-step 2ct + (jj>>4), slot (h=(jj>>3)&1, e=jj&7)).
 // A matrix held point-per-lane (as chained fragments) is brought into this layout by multiplying with an identity B
 // operand: one extra MFMA per 16 channels instead of an LDS round trip.
@@ -351,15 +350,17 @@ struct KMat {
     int64_t tiles32;
     int ct_per_tile;      // column tiles: 8 (256 columns) or 6 (192)
 };
-DEV char* kmat_ptr(const KMat& m, int net, int ns, int s, int64_t tile32, int ct, int lane) {
-    return m.base + (((((int64_t)net * ns + s) * m.tiles32 + tile32) * m.ct_per_tile + ct) * 64 + lane) * 32;
+// one 32-point tile of a matrix = [2 k-steps][ct_per_tile column tiles][64 lanes][16 B]: a linear image of what the
+// weight-gradient kernel wants in LDS (its global -> LDS transfer is a plain 1-KB-per-wave-instruction DMA)
+DEV char* kmat_ptr(const KMat& m, int net, int ns, int s, int64_t tile32, int ct, int lane, int kk) {
+    return m.base + (((int64_t)net * ns + s) * m.tiles32 + tile32) * (m.ct_per_tile * 2048) + ((kk * m.ct_per_tile + ct) * 64 + lane) * 16;
 }
-DEV void store_d_as_k(char* dst, const f32x16& d) {
+DEV void store_d_as_k(const KMat& m, int net, int ns, int s, int64_t tile32, int ct, int lane, const f32x16& d) {
     uint4 a, b;
     a.x = pack2(d[0], d[1]); a.y = pack2(d[2], d[3]); a.z = pack2(d[4], d[5]); a.w = pack2(d[6], d[7]);
     b.x = pack2(d[8], d[9]); b.y = pack2(d[10], d[11]); b.z = pack2(d[12], d[13]); b.w = pack2(d[14], d[15]);
-    reinterpret_cast<uint4*>(dst)[0] = a;
-    reinterpret_cast<uint4*>(dst)[1] = b;
+    *reinterpret_cast<uint4*>(kmat_ptr(m, net, ns, s, tile32, ct, lane, 0)) = a;
+    *reinterpret_cast<uint4*>(kmat_ptr(m, net, ns, s, tile32, ct, lane, 1)) = b;
 }
 // transpose-store the two fragments (k-steps 2ct, 2ct+1) that make up column tile ct; zero rows of invalid points
 template <int NS, int NSTORE>
@@ -371,7 +372,7 @@ DEV void store_tile_k(const KMat& m, int net, int64_t tile32, int ct, const Lane
         f32x16 d = (f32x16)0.f;
         d = mfma(as_bf(a0), as_bf(L.idA), d);
         d = mfma(as_bf(a1), as_bf(L.idB), d);
-        store_d_as_k(kmat_ptr(m, net, NSTORE, s, tile32, ct, L.lane), d);
+        store_d_as_k(m, net, NSTORE, s, tile32, ct, L.lane, d);
     }
 }
 
@@ -411,7 +412,7 @@ DEV OperandView operand_view(void* base, int64_t n_pad, int ns) {
     o.gnet = reinterpret_cast<float*>(b + 2 * m256 + 2 * m192);
     return o;
 }
-static int64_t operand_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + 2 * (int64_t)kNets * ns * n_pad * 384 + (int64_t)kNets * n_pad * 4; }
+static int64_t operand_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + 2 * (int64_t)kNets * ns * n_pad * 384 + (int64_t)kNets * n_pad * 4 + 1024; }
 
 // ------------------------------------------------------------------------------------------------ forward + Jacobian
 struct FwdArgs {
@@ -424,17 +425,17 @@ struct FwdArgs {
     void* saved;
 };
 
-// One pipeline step on the chunk of output tile T (T's parity = the chunk's parity: every layer has an even chunk count).
-// NK = k-steps of this chunk, NKN / NKNN = of the next / the one after (0 = none).  Depth 2: fetch chunk c+2 into register
-// set T&1, multiply chunk c, run the epilogue of the PREVIOUS tile in the shadow of these MFMAs (it only touches that tile's
-// accumulator), publish chunk c+1 (fetched one step ago) to the other LDS buffer.  Depth 1: fetch c+1 / publish c+1.
+// One pipeline step on chunk c (output tile T).  NK = k-steps of this chunk, NKN / NKNN = of chunk c+1 / c+2 (0 = none).
+//   1. publish chunk c+1 (its loads were issued one full step ago) to the other LDS buffer,
+//   2. issue the loads of chunk c+2 into the same registers (nothing newer is outstanding when step 1 waits),
+//   3. multiply chunk c, with the epilogue of the PREVIOUS tile in the shadow of these MFMAs,
+//   4. barrier.
 #define DPN_STEP(T, NK, NKN, NKNN, SWAP, ACT, ACC, EPI_PREV)                                              \
     do {                                                                                                  \
-        if constexpr (Pipe<NS>::kDepth == 2) { if constexpr ((NKNN) > 0) pipe.template fetch<(NKNN)>((T) & 1); } \
-        else { if constexpr ((NKN) > 0) pipe.template fetch<(NKN)>(0); }                                   \
+        if constexpr ((NKN) > 0) pipe.template commit<(NKN)>();                                           \
+        if constexpr ((NKNN) > 0) pipe.template fetch<(NKNN)>();                                          \
         mma_chunk<NS, (NK), (SWAP)>(pipe.cur_buf(), (ACT), (ACC));                                        \
         EPI_PREV;                                                                                         \
-        if constexpr ((NKN) > 0) pipe.template commit<(NKN)>(Pipe<NS>::kDepth == 2 ? (((T) + 1) & 1) : 0); \
         pipe.flip();                                                                                      \
     } while (0)
 
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
                         d[r] = acc[T][r] - bf_lo(hi); d[r + 1] = acc[T][r + 1] - bf_hi(hi);
                     }
                 }
-                store_d_as_k(kmat_ptr(ov.Z, net, NS, s, tile32, T, L.lane), d);
+                store_d_as_k(ov.Z, net, NS, s, tile32, T, L.lane, d);
             }
         };
 #pragma unroll
@@ -888,13 +889,27 @@ struct WgradArgs {
 };
 
 
-// one workgroup = 8 waves (2 x 4): wave (wm, wn) owns rows 128wm.. and columns 64wn.. of the product.  Per 32-point tile the
-// workgroup stages the X and Y fragments once in LDS (double-buffered, register-staged prefetch) and every wave reads its
-// 4 + 2 fragments per k-step from there: each operand byte is fetched from HBM/L2 exactly once per product.
+// one workgroup = 8 waves (2 x 4): wave (wm, wn) owns rows 128wm.. and columns 64wn.. of the product.  The X and Y fragments
+// of each 32-point tile are moved global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, no staging
+// registers) into a ring of RING slots, RING-1 tiles ahead; every operand byte is fetched from HBM exactly once per product.
+// Synchronisation per tile: counted s_waitcnt vmcnt (this wave's pieces of the tile have landed) + one raw s_barrier (all
+// pieces have landed AND everybody is done with the slot that is refilled next).
+DEV void dma16(const char* gsrc_lane, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
+}
+DEV void dma4(const char* gsrc_lane, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 4, 0, 0);
+}
+template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int NS>
 __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
-    constexpr int kBuf = NS * 32768;                                   // X: NS x 16 KB, Y: NS x 16 KB
-    __shared__ __attribute__((aligned(16))) char lds[2 * kBuf];
+    constexpr int kSlot = NS * 32768 + 8 * 256;                        // X: NS x 16 KB | Y: NS x 16 KB | 8 per-wave copies of g[64]
+    constexpr int RING = (NS == 1) ? 4 : 2;
+    constexpr int PER_TILE = NS * 4 + 1;                               // DMA instructions per wave per tile
+    __shared__ __attribute__((aligned(16))) char lds[RING * kSlot];
     const int prod = blockIdx.y, net = blockIdx.z;
     const int ncol = prod < 2 ? 256 : 192, nct = ncol / 32;
     const int64_t tiles = a.n_pad / 32;
@@ -903,7 +918,7 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     int64_t t1 = t0 + per < tiles ? t0 + per : tiles;
     if (t1 < t0) t1 = t0;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int i = lane & 31, h = lane >> 5;
     const bool active = wn * 2 < nct;                                   // 192-column products leave the wn = 3 waves idle
@@ -913,41 +928,30 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     const char* yb = (prod == 0) ? ov.Z.base : (prod == 1) ? ov.Z1.base : (prod == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
     const int nsx = (prod == 0) ? 1 : NS;                               // the 0/1 mask has no lo part
     const float* gnet = ov.gnet + (int64_t)net * a.n_pad;
-    const int xunits = nsx * 1024, yunits_s = nct * 128, total_units = xunits + NS * yunits_s;
+    const int xbytes = 16384, ybytes = nct * 2048;
 
-    uint4 stg[NS * 4];
-    float4 gnext[4], gcur[4];                                           // cotangents of this lane's points: [kk][first/second quad]
-    auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
+    // every wave issues PER_TILE DMA instructions per tile: piece q = wave + 8*j of the (X s=0.., Y s=0..) image, + its own g copy.
+    // Pieces beyond the image (192-column Y, mask without lo part) re-read a valid piece into a dummy LDS area (uniform count).
+    auto issue = [&](int64_t tile, int slot) __attribute__((always_inline)) {
+        char* sl = lds + slot * kSlot;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const float* gp_ = gnet + tile * 32 + 16 * kk + 4 * h;       // points of registers 8kk..8kk+7
-            gnext[2 * kk] = *reinterpret_cast<const float4*>(gp_);
-            gnext[2 * kk + 1] = *reinterpret_cast<const float4*>(gp_ + 8);
-        }
-#pragma unroll
-        for (int q = 0; q < NS * 4; ++q) {
-            int u = threadIdx.x + 512 * q;
-            u = u < total_units ? u : total_units - 1;                  // clamp: the surplus loads are simply not committed
+        for (int j = 0; j < NS * 4; ++j) {
+            const int q = wave + 8 * j;                                 // 1-KB piece index in [0, NS*32)
+            const int s2 = q / 32, r = q % 32;                          // split s2; r < 16: X piece r ; r >= 16: Y piece r-16
             const char* src;
-            if (u < xunits) src = xb + ((((int64_t)net * nsx + (u >> 10)) * tiles + tile) * 8) * 2048 + (u & 1023) * 16;
-            else { const int v = u - xunits, s2 = v / yunits_s, w = v - s2 * yunits_s; src = yb + ((((int64_t)net * NS + s2) * tiles + tile) * nct) * 2048 + w * 16; }
-            stg[q] = *reinterpret_cast<const uint4*>(src);
-        }
-    };
-    auto commit = [&](char* buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < NS * 4; ++q) {
-            const int u = threadIdx.x + 512 * q;
-            if (u < total_units) {
-                int s2, w, nc;
-                char* base;
-                if (u < xunits) { s2 = u >> 10; w = u & 1023; nc = 8; base = buf + s2 * 16384; }
-                else { const int v = u - xunits; s2 = v / yunits_s; w = v - s2 * yunits_s; nc = nct; base = buf + NS * 16384 + s2 * 16384; }
-                // source unit w = (ct, lane, kk)  ->  LDS [kk][ct][lane] so that a wave's fragment read is 1 KB contiguous
-                const int ct = w >> 7, ln = (w & 127) >> 1, kk = w & 1;
-                *reinterpret_cast<uint4*>(base + ((kk * nc + ct) * 64 + ln) * 16) = stg[q];
+            char* dst;
+            if (r < 16) {
+                const int sx = s2 < nsx ? s2 : 0;
+                src = xb + (((int64_t)net * nsx + sx) * tiles + tile) * xbytes + r * 1024;
+                dst = sl + s2 * 16384 + r * 1024;
+            } else {
+                const int ry = (r - 16) * 1024 < ybytes ? (r - 16) : 0;
+                src = yb + (((int64_t)net * NS + s2) * tiles + tile) * ybytes + ry * 1024;
+                dst = sl + NS * 16384 + s2 * 16384 + (r - 16) * 1024;
             }
+            dma16(src + lane * 16, dst);
         }
+        dma4(reinterpret_cast<const char*>(gnet + tile * 32) + lane * 4, sl + NS * 32768 + wave * 256);
     };
 
     f32x16 acc[4][2];
@@ -955,10 +959,11 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     for (int m = 0; m < 4; ++m) { acc[m][0] = (f32x16)0.f; acc[m][1] = (f32x16)0.f; }
     float vecA[4] = {0.f, 0.f, 0.f, 0.f}, vecB[2] = {0.f, 0.f}, gsum = 0.f;
 
-    auto compute = [&](const char* buf, int64_t tile) __attribute__((always_inline)) {
+    auto compute = [&](const char* buf) __attribute__((always_inline)) {
+        const float* gl = reinterpret_cast<const float*>(buf + NS * 32768 + wave * 256);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const float4 g0 = gcur[2 * kk], g1 = gcur[2 * kk + 1];
+            const float4 g0 = *reinterpret_cast<const float4*>(gl + 16 * kk + 4 * h), g1 = *reinterpret_cast<const float4*>(gl + 16 * kk + 4 * h + 8);
             const float gp[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             if (prod == 1 && wave == 0 && i == 0) {
 #pragma unroll
@@ -1012,18 +1017,23 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
         }
     };
 
-    int cur = 0;
-    if (t1 > t0) { fetch(t0); commit(lds); }
-    __syncthreads();
-    for (int64_t tile = t0; tile < t1; ++tile) {
+    // prologue: RING-1 tiles in flight (out-of-range tiles re-read the last valid one; their data is never used)
+    const int64_t tl = t1 > t0 ? t1 - 1 : t0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gcur[q] = gnext[q];
-        if (tile + 1 < t1) fetch(tile + 1);
-        if (active) compute(lds + cur * kBuf, tile);
-        if (tile + 1 < t1) commit(lds + (cur ^ 1) * kBuf);
-        __syncthreads();
-        cur ^= 1;
+    for (int r = 0; r < RING - 1; ++r) issue(t0 + r < t1 ? t0 + r : tl, r);
+    int slot = 0;
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        wait_vmcnt<(RING - 2) * PER_TILE>();                             // this wave's pieces of `tile` have landed
+        __builtin_amdgcn_s_barrier();                                    // ... and everybody else's; and compute(tile-1) is finished everywhere
+        {
+            const int64_t nt = tile + RING - 1;
+            issue(nt < t1 ? nt : tl, (slot + RING - 1) % RING);          // refill the slot that compute(tile-1) just released
+        }
+        if (active) compute(lds + slot * kSlot);
+        slot = (slot + 1) % RING;
     }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
     // ---- write this split's partial sums: natural [row slot][col] order
     float* part = a.partials + ((int64_t)blockIdx.x * kNets + net) * kPartFloats;
     float* out = part + part_off(prod);
@@ -1425,6 +1435,9 @@ __global__ void dpn_selftest_kernel(float* out) {
 // ------------------------------------------------------------------------------------------------ C ABI
 static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 static inline int choose_splits(int64_t n_pad) {
+#ifdef DPN_EXP_SPLITS
+    return DPN_EXP_SPLITS;
+#endif
     // 24 workgroups (4 products x 6 nets) per split; two 8-wave workgroups fit on a CU -> ~2 x 256 CUs / 24
     int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
