@@ -37,6 +37,7 @@ typedef unsigned int u32;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) u32 u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 DEV u16 f2bf(float x) {                       // round-to-nearest-even, finite inputs (pack kernel)
     unsigned u = __float_as_uint(x);
@@ -179,67 +180,145 @@ __global__ __launch_bounds__(256) void dpn_pack_vectors_kernel(PackArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight stream
-// All four waves of a workgroup walk the same packed weight block chunk by chunk (one chunk = the A fragments
-// of one 32-row output tile for up to 16 k-steps).  Chunks are double-buffered in LDS: the next chunk is fetched
-// into registers before the MFMAs of the current one issue and written to the other buffer after them.
+// All four waves of a workgroup walk the same packed weight block chunk by chunk (one chunk = the A fragments of one 32-row
+// output tile for 12 or 16 k-steps).  Chunks travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per
+// wave-instruction, no staging registers, no ds_write pass) into a ring of 4 slots, three chunks ahead of the MFMAs.
+// Per chunk: counted s_waitcnt vmcnt (my pieces of chunk c have landed; the DMAs of c+1, c+2 stay in flight), one raw
+// s_barrier (everybody's pieces have landed, everybody is done with the slot refilled next), issue chunk c+3, multiply chunk c.
+// vmcnt retires in order on gfx9-class hardware (the compiler's own counted waits rely on it); other VMEM traffic of the wave
+// (saved-state stores) only makes the counted wait stricter, never weaker.
+DEV void dma16(const char* gsrc_lane, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
+}
+DEV void dma4(const char* gsrc_lane, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 4, 0, 0);
+}
+template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+DEV void wait_vmcnt_n(const int n) {        // n is a compile-time constant after unrolling: the switch folds to one s_waitcnt
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;   case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;
+        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
+        case 12: wait_vmcnt<12>(); break; case 14: wait_vmcnt<14>(); break; case 16: wait_vmcnt<16>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+// k-steps of chunk c in stream order (dpn_layout.h): w1 8x12 | w2 8x16 | Wd 8x12 | W1 8x16 | W1^T 8x16 | w2^T 8x16 | w1^T 6x16
+DPN_HD int stream_nk(int c, int end) { return (c < 0 || c >= end) ? 0 : (c < 8 ? 12 : c < 16 ? 16 : c < 24 ? 12 : 16); }
+
 template <int NS>
 struct Pipe {
-    static constexpr int kBufBytes = 16 * 1024 * NS;
-    const uint4* g;
+    static constexpr int kRing = 4;
+    static constexpr int kSlotBytes = 16 * 1024 * NS;
+    const char* g;       // global address of the next chunk to issue (wave-uniform)
     char* lds;
-    int cur;
-    uint4 stg[4 * NS];
+    int end;             // number of chunks this kernel may touch (54 forward, 24 backward)
+    int wave, lane;
 
-    DEV void init(const void* gsrc, char* lds_base) { g = reinterpret_cast<const uint4*>(gsrc); lds = lds_base; cur = 0; }
-    template <int NK> DEV void fetch() {
+    DEV void init(const void* gsrc, char* lds_base, int end_chunks) {
+        g = reinterpret_cast<const char*>(gsrc); lds = lds_base; end = end_chunks;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); lane = threadIdx.x & 63;
+    }
+    DEV static int dmas(int nk) { return nk * NS / 4; }                 // DMA instructions per wave for a chunk of nk k-steps
+    DEV void issue(const int c) {                                       // chunk c -> slot c % 4
+        const int n = dmas(stream_nk(c, end));
+        char* slot = lds + (c & (kRing - 1)) * kSlotBytes;
 #pragma unroll
-        for (int i = 0; i < NK * NS / 4; ++i) stg[i] = g[i * 256 + threadIdx.x];
-        g += NK * NS * 64;
+        for (int i = 0; i < 4 * NS; ++i)
+            if (i < n) dma16(g + (i * 4 + wave) * 1024 + lane * 16, slot + (i * 4 + wave) * 1024);
+        g += n * 4096;
     }
-    template <int NK> DEV void commit() {
-        uint4* d = reinterpret_cast<uint4*>(lds + (cur ^ 1) * kBufBytes);
-#pragma unroll
-        for (int i = 0; i < NK * NS / 4; ++i) d[i * 256 + threadIdx.x] = stg[i];
+    DEV void prime() { issue(0); issue(1); issue(2); }
+    DEV void acquire(const int c) {                                     // after this, every wave may read chunk c from LDS
+        __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from stretching live ranges across pipeline steps
+        wait_vmcnt_n(dmas(stream_nk(c + 1, end)) + dmas(stream_nk(c + 2, end)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // compiler-level ordering only: no s_waitcnt is emitted
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        issue(c + 3);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // chunk 0 -> LDS buffer 0; chunk 1 is in flight (in registers) when the first MFMA issues
-    template <int NK0, int NK1> DEV void prime() {
-        cur = 1; fetch<NK0>(); commit<NK0>(); __syncthreads(); cur = 0;
-        fetch<NK1>();
+    DEV unsigned buf(const int c) const {                               // LDS byte address of slot c % 4
+        return (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds + (c & (kRing - 1)) * kSlotBytes;
     }
-    DEV void flip() { __syncthreads(); cur ^= 1; }
-    DEV const char* cur_buf() const { return lds + cur * kBufBytes; }
+    DEV void drain() { wait_vmcnt<0>(); }                               // no DMA may outlive the workgroup's LDS allocation
 };
 
 // SWAP = false: Out[channel][point] (+)= W[channel][k] * Act[k][point]   (weights as A, chained layout)
 // SWAP = true : Out[point][channel] (+)= Act[point][k] * W[channel][k]   (same packed weights as B: the result lands
 //               channel-per-lane / points-in-registers, which is the K-operand layout of the weight-gradient GEMMs)
-template <int NS, int NK, bool SWAP>
-DEV void mma_chunk(const char* buf, const Frag<NS>* act, f32x16& acc) {
-    // The A fragments of a chunk are read LOOKAHEAD k-steps ahead of the MFMA that consumes them, so that the LDS latency
-    // (~64-128 cycles) hides under the 32-cycle MFMAs instead of being paid once per MFMA.
-    constexpr int LOOKAHEAD = (NS == 1) ? 4 : 2;
-    const int lane = threadIdx.x & 63;
-    const char* base = buf + lane * 16;
-    bf16x8 w[LOOKAHEAD][NS];
+// The A fragments are read with inline-asm ds_read_b128: hipcc orders every LDS read it can see behind ALL outstanding
+// LDS-DMA (s_waitcnt vmcnt(0)), which would drain the three chunks in flight at every step.  The reads of a chunk are
+// issued in blocks of four k-steps, one block ahead of the MFMAs that consume them, with counted lgkmcnt waits
+// (LDS operations retire in order; anything else on the counter only makes the wait stricter).
+template <int NS>
+struct WBlock { u32x4 w[4][NS]; };
+
+template <int NS, int KS0>
+DEV void lds_load_block(WBlock<NS>& b, unsigned addr) {
+    if constexpr (NS == 1) {
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                     : "=&v"(b.w[0][0]), "=&v"(b.w[1][0]), "=&v"(b.w[2][0]), "=&v"(b.w[3][0])
+                     : "v"(addr), "n"((KS0 + 0) * 1024), "n"((KS0 + 1) * 1024), "n"((KS0 + 2) * 1024), "n"((KS0 + 3) * 1024)
+                     : "memory");
+    } else {
+        asm volatile("ds_read_b128 %0, %8 offset:%9\n\tds_read_b128 %1, %8 offset:%10\n\tds_read_b128 %2, %8 offset:%11\n\tds_read_b128 %3, %8 offset:%12\n\t"
+                     "ds_read_b128 %4, %8 offset:%13\n\tds_read_b128 %5, %8 offset:%14\n\tds_read_b128 %6, %8 offset:%15\n\tds_read_b128 %7, %8 offset:%16"
+                     : "=&v"(b.w[0][0]), "=&v"(b.w[0][1]), "=&v"(b.w[1][0]), "=&v"(b.w[1][1]), "=&v"(b.w[2][0]), "=&v"(b.w[2][1]), "=&v"(b.w[3][0]), "=&v"(b.w[3][1])
+                     : "v"(addr), "n"((KS0 * 2 + 0) * 1024), "n"((KS0 * 2 + 1) * 1024), "n"((KS0 * 2 + 2) * 1024), "n"((KS0 * 2 + 3) * 1024),
+                       "n"((KS0 * 2 + 4) * 1024), "n"((KS0 * 2 + 5) * 1024), "n"((KS0 * 2 + 6) * 1024), "n"((KS0 * 2 + 7) * 1024)
+                     : "memory");
+    }
+}
+// wait until at most N LDS operations issued after this block are outstanding; the "+v" ties keep every consumer below the wait
+template <int NS, int N>
+DEV void lds_wait_block(WBlock<NS>& b) {
+    if constexpr (NS == 1)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b.w[0][0]), "+v"(b.w[1][0]), "+v"(b.w[2][0]), "+v"(b.w[3][0]) : "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(b.w[0][0]), "+v"(b.w[0][1]), "+v"(b.w[1][0]), "+v"(b.w[1][1]), "+v"(b.w[2][0]), "+v"(b.w[2][1]),
+                     "+v"(b.w[3][0]), "+v"(b.w[3][1]) : "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);          // hipcc would otherwise hoist register-only MFMAs above the asm wait
+}
+
+template <int NS, bool SWAP, int KS0>
+DEV void mma_block(const WBlock<NS>& b, const Frag<NS>* act, f32x16& acc) {
 #pragma unroll
-    for (int i = 0; i < LOOKAHEAD; ++i)
-#pragma unroll
-        for (int s2 = 0; s2 < NS; ++s2) w[i][s2] = *reinterpret_cast<const bf16x8*>(base + ((i * NS + s2) * 64) * 16);
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-        bf16x8 whi = w[ks % LOOKAHEAD][0], wlo;
-        if constexpr (NS == 2) wlo = w[ks % LOOKAHEAD][1];
-        if (ks + LOOKAHEAD < NK) {
-#pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2)
-                w[ks % LOOKAHEAD][s2] = *reinterpret_cast<const bf16x8*>(base + (((ks + LOOKAHEAD) * NS + s2) * 64) * 16);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const bf16x8 whi = as_bf(b.w[k][0]);
         if constexpr (NS == 2) {
-            if constexpr (SWAP) { acc = mfma(as_bf(act[ks].w[1]), whi, acc); acc = mfma(as_bf(act[ks].w[0]), wlo, acc); }
-            else { acc = mfma(whi, as_bf(act[ks].w[1]), acc); acc = mfma(wlo, as_bf(act[ks].w[0]), acc); }
+            const bf16x8 wlo = as_bf(b.w[k][1]);
+            if constexpr (SWAP) { acc = mfma(as_bf(act[KS0 + k].w[1]), whi, acc); acc = mfma(as_bf(act[KS0 + k].w[0]), wlo, acc); }
+            else { acc = mfma(whi, as_bf(act[KS0 + k].w[1]), acc); acc = mfma(wlo, as_bf(act[KS0 + k].w[0]), acc); }
         }
-        if constexpr (SWAP) acc = mfma(as_bf(act[ks].w[0]), whi, acc);
-        else acc = mfma(whi, as_bf(act[ks].w[0]), acc);
+        if constexpr (SWAP) acc = mfma(as_bf(act[KS0 + k].w[0]), whi, acc);
+        else acc = mfma(whi, as_bf(act[KS0 + k].w[0]), acc);
+    }
+}
+
+template <int NS, int NK, bool SWAP>
+DEV void mma_chunk(unsigned slot_addr, const Frag<NS>* act, f32x16& acc) {
+    static_assert(NK == 12 || NK == 16, "chunks are 12 or 16 k-steps");
+    const unsigned addr = slot_addr + (threadIdx.x & 63) * 16;
+    WBlock<NS> b0, b1;
+    lds_load_block<NS, 0>(b0, addr);
+    lds_load_block<NS, 4>(b1, addr);
+    lds_wait_block<NS, 4 * NS>(b0);
+    mma_block<NS, SWAP, 0>(b0, act, acc);
+    lds_load_block<NS, 8>(b0, addr);
+    lds_wait_block<NS, 4 * NS>(b1);
+    mma_block<NS, SWAP, 4>(b1, act, acc);
+    if constexpr (NK == 16) {
+        lds_load_block<NS, 12>(b1, addr);
+        lds_wait_block<NS, 4 * NS>(b0);
+        mma_block<NS, SWAP, 8>(b0, act, acc);
+        lds_wait_block<NS, 0>(b1);
+        mma_block<NS, SWAP, 12>(b1, act, acc);
+    } else {
+        lds_wait_block<NS, 0>(b0);
+        mma_block<NS, SWAP, 8>(b0, act, acc);
     }
 }
 
@@ -327,15 +406,28 @@ DEV void build_pe6(const Lane& L, const float* cd6, Frag<NS>* act, float g) {
     }
 }
 
-DEV void acc_init_vec(f32x16& acc, const float* vec_lds, int which, int h, int T, float scale) {
+// The permuted bias vectors live in LDS (filled once, before any DMA is in flight) and are read with inline-asm ds_read_b128
+// for the same reason as the weight fragments: a read hipcc can see is ordered behind every outstanding LDS-DMA, and a
+// global load it can see is waited for with vmcnt(0), which drains the DMA ring as well.
+struct Vec16 { f32x4 q[4]; };
+DEV void lds_read_vec16(Vec16& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v.q[0]), "=&v"(v.q[1]), "=&v"(v.q[2]), "=&v"(v.q[3]) : "v"(addr) : "memory");
+}
+DEV unsigned vec_addr(unsigned vec_base, int which, int h, int T) { return vec_base + (which * 256 + h * 128 + T * 16) * 4; }
+DEV void acc_init_vec(f32x16& acc, unsigned vec_base, int which, int h, int T, float scale) {
+    Vec16 v;
+    lds_read_vec16(v, vec_addr(vec_base, which, h, T));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 b = *reinterpret_cast<const float4*>(vec_lds + which * 256 + h * 128 + T * 16 + 4 * q);
-        acc[4 * q] = scale * b.x; acc[4 * q + 1] = scale * b.y; acc[4 * q + 2] = scale * b.z; acc[4 * q + 3] = scale * b.w;
+        acc[4 * q] = scale * v.q[q][0]; acc[4 * q + 1] = scale * v.q[q][1]; acc[4 * q + 2] = scale * v.q[q][2]; acc[4 * q + 3] = scale * v.q[q][3];
     }
 }
-DEV float4 ld_vec4(const float* vec_lds, int which, int h, int T, int q4) {
-    return *reinterpret_cast<const float4*>(vec_lds + which * 256 + h * 128 + T * 16 + 4 * q4);
+DEV float lds_read_f32(unsigned addr) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------ K-layout operand matrices
@@ -425,33 +517,29 @@ struct FwdArgs {
     void* saved;
 };
 
-// One pipeline step on chunk c (output tile T).  NK = k-steps of this chunk, NKN / NKNN = of chunk c+1 / c+2 (0 = none).
-//   1. publish chunk c+1 (its loads were issued one full step ago) to the other LDS buffer,
-//   2. issue the loads of chunk c+2 into the same registers (nothing newer is outstanding when step 1 waits),
-//   3. multiply chunk c, with the epilogue of the PREVIOUS tile in the shadow of these MFMAs,
-//   4. barrier.
-#define DPN_STEP(T, NK, NKN, NKNN, SWAP, ACT, ACC, EPI_PREV)                                              \
-    do {                                                                                                  \
-        if constexpr ((NKN) > 0) pipe.template commit<(NKN)>();                                           \
-        if constexpr ((NKNN) > 0) pipe.template fetch<(NKNN)>();                                          \
-        mma_chunk<NS, (NK), (SWAP)>(pipe.cur_buf(), (ACT), (ACC));                                        \
-        EPI_PREV;                                                                                         \
-        pipe.flip();                                                                                      \
+// One pipeline step on chunk C: make it readable (and put chunk C+3 in flight), multiply it, and run the epilogue of the
+// PREVIOUS tile in the shadow of these MFMAs (it only touches that tile's accumulator).
+#define DPN_STEP(C, NK, SWAP, ACT, ACC, EPI_PREV)                                    \
+    do {                                                                             \
+        pipe.acquire(C);                                                             \
+        mma_chunk<NS, (NK), (SWAP)>(pipe.buf(C), (ACT), (ACC));                      \
+        EPI_PREV;                                                                    \
     } while (0)
 
 template <int NS>
 __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds_w[2 * Pipe<NS>::kBufBytes];
-    __shared__ __attribute__((aligned(16))) float lds_vec[kNumVecs * 256 + 4];
+    __shared__ __attribute__((aligned(16))) char lds_w[Pipe<NS>::kRing * Pipe<NS>::kSlotBytes];
 
     const int net = blockIdx.y;
     const int wave = threadIdx.x >> 6;
     const int64_t tile32 = (int64_t)blockIdx.x * 4 + wave;
     const char* pk = a.packed + (long)net * pack_bytes_per_net(NS);
-    {   // permuted fp32 vectors of this net -> LDS
+    __shared__ __attribute__((aligned(16))) float lds_vec_store[kNumVecs * 256 + 4];
+    {   // permuted fp32 vectors of this net -> LDS (published by the barrier below, before the first DMA is issued)
         const float* gv = reinterpret_cast<const float*>(pk + (long)kPackKB * 1024 * NS);
-        for (int i = threadIdx.x; i < kNumVecs * 256 + 4; i += 256) lds_vec[i] = gv[i];
+        for (int i = threadIdx.x; i < kNumVecs * 256 + 4; i += 256) lds_vec_store[i] = gv[i];
     }
+    const unsigned lds_vec = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds_vec_store;
     Lane L;
     lane_init(L, a.x, a.y, a.t, a.n, a.freqs, a.geo, tile32);
     const int h = L.h;
@@ -465,8 +553,9 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     const bool save = a.saved != nullptr;
 
     Pipe<NS> pipe;
-    pipe.init(pk, lds_w);
-    pipe.template prime<12, 12>();      // first chunk: w1 tile 0 (the barrier inside also publishes lds_vec)
+    __syncthreads();
+    pipe.init(pk, lds_w, 54);
+    pipe.prime();
 
     f32x16 acc[8];
     u32 m1w[4] = {0u, 0u, 0u, 0u};
@@ -488,21 +577,20 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             acc_init_vec(acc[T], lds_vec, kVecB1, h, T, 1.0f);
-            if (T == 0) DPN_STEP(T, 12, 12, 12, false, pe, acc[T], (void)0);
-            else if (T < 6) DPN_STEP(T, 12, 12, 12, false, pe, acc[T], epi1(T - 1));
-            else if (T == 6) DPN_STEP(T, 12, 12, 16, false, pe, acc[T], epi1(T - 1));
-            else DPN_STEP(T, 12, 16, 16, false, pe, acc[T], epi1(T - 1));   // next: w2 tile 0
+            if (T == 0) DPN_STEP(T, 12, false, pe, acc[T], (void)0);
+            else DPN_STEP(T, 12, false, pe, acc[T], epi1(T - 1));
         }
         epi1(7);
     }
     // ---------------- L2 + data: c = w2 . h1 + Wd . pe6 + (b2 + bd + e) -> actB ; cdot = wo . c
     float cdot = 0.f;
     auto epi2 = [&](const int T) __attribute__((always_inline)) {
+        Vec16 wv;
+        lds_read_vec16(wv, vec_addr(lds_vec, kVecWo, h, T));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 w = ld_vec4(lds_vec, kVecWo, h, T, q);
-            cdot = fmaf(w.x, acc[T][4 * q], cdot); cdot = fmaf(w.y, acc[T][4 * q + 1], cdot);
-            cdot = fmaf(w.z, acc[T][4 * q + 2], cdot); cdot = fmaf(w.w, acc[T][4 * q + 3], cdot);
+            cdot = fmaf(wv.q[q][0], acc[T][4 * q], cdot); cdot = fmaf(wv.q[q][1], acc[T][4 * q + 1], cdot);
+            cdot = fmaf(wv.q[q][2], acc[T][4 * q + 2], cdot); cdot = fmaf(wv.q[q][3], acc[T][4 * q + 3], cdot);
         }
 #pragma unroll
         for (int r = 0; r < 16; r += 2) frag_set2<NS>(actB[2 * T + (r >> 3)], (r & 7) >> 1, acc[T][r], acc[T][r + 1]);
@@ -512,29 +600,27 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             acc_init_vec(acc[T], lds_vec, kVecCvec, h, T, 1.0f);
-            if (T < 6) DPN_STEP(T, 16, 16, 16, false, actA, acc[T], (void)0);
-            else if (T == 6) DPN_STEP(T, 16, 16, 12, false, actA, acc[T], (void)0);
-            else DPN_STEP(T, 16, 12, 12, false, actA, acc[T], (void)0);        // next: Wd tile 0
+            DPN_STEP(8 + T, 16, false, actA, acc[T], (void)0);
         }
         Frag<NS> pe6[12];
         build_pe6<NS>(L, cd6, pe6, 1.0f);
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
-            if (T == 0) DPN_STEP(T, 12, 12, 12, false, pe6, acc[T], (void)0);
-            else if (T < 6) DPN_STEP(T, 12, 12, 12, false, pe6, acc[T], epi2(T - 1));
-            else if (T == 6) DPN_STEP(T, 12, 12, 16, false, pe6, acc[T], epi2(T - 1));
-            else DPN_STEP(T, 12, 16, 16, false, pe6, acc[T], epi2(T - 1));     // next: W1 tile 0
+            if (T == 0) DPN_STEP(16 + T, 12, false, pe6, acc[T], (void)0);
+            else DPN_STEP(16 + T, 12, false, pe6, acc[T], epi2(T - 1));
         }
         epi2(7);
     }
     // ---------------- fc1: pre2 = W1 . c + bf1 ; a = relu ; out = u.a + 2 wo.c + const ; t2 = m2 (.) u -> actA ; M2 -> saved
+    const float const0 = lds_read_f32(lds_vec + kNumVecs * 256 * 4);
     float adot = 0.f;
     auto epi3 = [&](const int T) __attribute__((always_inline)) {
         Frag<1> mk0, mk1;
+        Vec16 uv;
+        lds_read_vec16(uv, vec_addr(lds_vec, kVecU, h, T));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 u4 = ld_vec4(lds_vec, kVecU, h, T, q);
-            const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
+            const float uu[4] = {uv.q[q][0], uv.q[q][1], uv.q[q][2], uv.q[q][3]};
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
                 const int r = 4 * q + i;
@@ -552,17 +638,17 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         acc_init_vec(acc[T], lds_vec, kVecBf1, h, T, 1.0f);
-        if (T == 0) DPN_STEP(T, 16, 16, 16, false, actB, acc[T], (void)0);     // next: W1 tile T+1, or W1^T tile 0
-        else DPN_STEP(T, 16, 16, 16, false, actB, acc[T], epi3(T - 1));
+        if (T == 0) DPN_STEP(24 + T, 16, false, actB, acc[T], (void)0);
+        else DPN_STEP(24 + T, 16, false, actB, acc[T], epi3(T - 1));
     }
     epi3(7);
     {
         float o = adot + 2.0f * cdot;
         o += __shfl_xor(o, 32);
-        if (L.valid && h == 0) a.out_n[L.pt * 6 + net] = o + lds_vec[kNumVecs * 256] + ref_data;   // + ref_data (variable_net.py:86)
+        if (L.valid && h == 0) a.out_n[L.pt * 6 + net] = o + const0 + ref_data;   // + ref_data (variable_net.py:86)
     }
     if (save) sv.m1[((int64_t)net * (a.n_pad / 32) + tile32) * 64 + L.lane] = make_uint4(m1w[0], m1w[1], m1w[2], m1w[3]);
-    if (!save && !a.jac_n) return;
+    if (!save && !a.jac_n) { pipe.drain(); return; }
     // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> actB (+ saved V)
     auto epiv = [&](const int T) __attribute__((always_inline)) {
 #pragma unroll
@@ -572,8 +658,8 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         acc_init_vec(acc[T], lds_vec, kVecWo, h, T, 2.0f);
-        if (T == 0) DPN_STEP(T, 16, 16, 16, false, actA, acc[T], (void)0);     // next: W1^T tile T+1, or w2^T tile 0
-        else DPN_STEP(T, 16, 16, 16, false, actA, acc[T], epiv(T - 1));
+        if (T == 0) DPN_STEP(32 + T, 16, false, actA, acc[T], (void)0);
+        else DPN_STEP(32 + T, 16, false, actA, acc[T], epiv(T - 1));
     }
     epiv(7);
     // ---------------- y = w2^T v ; t1 = m1 (.) y -> actA (+ saved T1)
@@ -588,11 +674,11 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         acc[T] = (f32x16)0.f;
-        if (T == 0) DPN_STEP(T, 16, 16, 16, false, actB, acc[T], (void)0);
-        else DPN_STEP(T, 16, 16, 16, false, actB, acc[T], epiy(T - 1));        // the w1^T chunks always exist: prefetching them is harmless
+        if (T == 0) DPN_STEP(40 + T, 16, false, actB, acc[T], (void)0);
+        else DPN_STEP(40 + T, 16, false, actB, acc[T], epiy(T - 1));           // the w1^T chunks always exist: prefetching them is harmless
     }
     epiy(7);
-    if (!a.jac_n) return;
+    if (!a.jac_n) { pipe.drain(); return; }
     // ---------------- gpe = w1^T t1 (6 tiles), contracted with d(pe)/d(xi) in registers
     float jc[3] = {0.f, 0.f, 0.f};
     auto epij = [&](const int T) __attribute__((always_inline)) {
@@ -610,12 +696,11 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int T = 0; T < 6; ++T) {
         acc[T] = (f32x16)0.f;
-        if (T == 0) DPN_STEP(T, 16, 16, 16, false, actA, acc[T], (void)0);
-        else if (T < 4) DPN_STEP(T, 16, 16, 16, false, actA, acc[T], epij(T - 1));
-        else if (T == 4) DPN_STEP(T, 16, 16, 0, false, actA, acc[T], epij(T - 1));
-        else DPN_STEP(T, 16, 0, 0, false, actA, acc[T], epij(T - 1));
+        if (T == 0) DPN_STEP(48 + T, 16, false, actA, acc[T], (void)0);
+        else DPN_STEP(48 + T, 16, false, actA, acc[T], epij(T - 1));
     }
     epij(5);
+    pipe.drain();
 #pragma unroll
     for (int c = 0; c < 3; ++c) jc[c] += __shfl_xor(jc[c], 32);
     if (L.valid && h == 0) {
@@ -757,16 +842,17 @@ struct BwdArgs {
 
 template <int NS>
 __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds_w[2 * Pipe<NS>::kBufBytes];
-    __shared__ __attribute__((aligned(16))) float lds_vec[kNumVecs * 256 + 4];
+    __shared__ __attribute__((aligned(16))) char lds_w[Pipe<NS>::kRing * Pipe<NS>::kSlotBytes];
     const int net = blockIdx.y;
     const int wave = threadIdx.x >> 6;
     const int64_t tile32 = (int64_t)blockIdx.x * 4 + wave;
     const char* pk = a.packed + (long)net * pack_bytes_per_net(NS);
+    __shared__ __attribute__((aligned(16))) float lds_vec_store[kNumVecs * 256 + 4];
     {
         const float* gv = reinterpret_cast<const float*>(pk + (long)kPackKB * 1024 * NS);
-        for (int i = threadIdx.x; i < kNumVecs * 256 + 4; i += 256) lds_vec[i] = gv[i];
+        for (int i = threadIdx.x; i < kNumVecs * 256 + 4; i += 256) lds_vec_store[i] = gv[i];
     }
+    const unsigned lds_vec = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds_vec_store;
     Lane L;
     lane_init(L, a.x, a.y, a.t, a.n, a.freqs, a.geo, tile32);
     const int h = L.h;
@@ -795,8 +881,9 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
     }
 
     Pipe<NS> pipe;
-    pipe.init(pk, lds_w);
-    pipe.template prime<12, 12>();
+    __syncthreads();
+    pipe.init(pk, lds_w, 24);
+    pipe.prime();
 
     f32x16 acc[8];
     Frag<NS> actA[16];
@@ -818,10 +905,8 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             acc_init_vec(acc[T], lds_vec, kVecB1, h, T, g);
-            if (T == 0) DPN_STEP(T, 12, 12, 12, false, z0, acc[T], (void)0);
-            else if (T < 6) DPN_STEP(T, 12, 12, 12, false, z0, acc[T], epi1(T - 1));
-            else if (T == 6) DPN_STEP(T, 12, 12, 16, false, z0, acc[T], epi1(T - 1));
-            else DPN_STEP(T, 12, 16, 16, false, z0, acc[T], epi1(T - 1));
+            if (T == 0) DPN_STEP(T, 12, false, z0, acc[T], (void)0);
+            else DPN_STEP(T, 12, false, z0, acc[T], epi1(T - 1));
         }
         epi1(7);
     }
@@ -849,21 +934,18 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
         };
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
-            const float cv = lds_vec[kVecCvec * 256 + hh * 128 + T * 16 + rr];
+            const float cv = lds_read_f32(lds_vec + (kVecCvec * 256 + hh * 128 + T * 16 + rr) * 4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[T][r] = g16[r] * cv;
-            if (T < 6) DPN_STEP(T, 16, 16, 16, true, actA, acc[T], (void)0);
-            else if (T == 6) DPN_STEP(T, 16, 16, 12, true, actA, acc[T], (void)0);
-            else DPN_STEP(T, 16, 12, 12, true, actA, acc[T], (void)0);
+            DPN_STEP(8 + T, 16, true, actA, acc[T], (void)0);
         }
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
-            if (T == 0) DPN_STEP(T, 12, 12, 12, true, g6, acc[T], (void)0);
-            else if (T < 6) DPN_STEP(T, 12, 12, 12, true, g6, acc[T], epiz(T - 1));
-            else if (T == 6) DPN_STEP(T, 12, 12, 0, true, g6, acc[T], epiz(T - 1));
-            else DPN_STEP(T, 12, 0, 0, true, g6, acc[T], epiz(T - 1));
+            if (T == 0) DPN_STEP(16 + T, 12, true, g6, acc[T], (void)0);
+            else DPN_STEP(16 + T, 12, true, g6, acc[T], epiz(T - 1));
         }
         epiz(7);
+        pipe.drain();
     }
 }
 
@@ -894,16 +976,6 @@ struct WgradArgs {
 // registers) into a ring of RING slots, RING-1 tiles ahead; every operand byte is fetched from HBM exactly once per product.
 // Synchronisation per tile: counted s_waitcnt vmcnt (this wave's pieces of the tile have landed) + one raw s_barrier (all
 // pieces have landed AND everybody is done with the slot that is refilled next).
-DEV void dma16(const char* gsrc_lane, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
-                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
-}
-DEV void dma4(const char* gsrc_lane, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
-                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 4, 0, 0);
-}
-template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 template <int NS>
 __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     constexpr int kSlot = NS * 32768 + 8 * 256;                        // X: NS x 16 KB | Y: NS x 16 KB | 8 per-wave copies of g[64]
