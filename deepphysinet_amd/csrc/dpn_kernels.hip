@@ -1357,75 +1357,84 @@ struct SgemmBatch {
     int n;
 };
 
+// exact-fp32 matrix cores: v_mfma_f32_32x32x2_f32 (A: lane l holds A[l&31][l>>5], B: lane l holds B[l>>5][l&31]); bitwise an fmaf chain.
+typedef float f32x1;
+DEV f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
 __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
-    constexpr int BM = 32, BN = 32, BK = 32;
+    // one workgroup = one 32x32 output tile; its four waves split K four ways (interleaved 8-wide slices) and are summed
+    // through LDS in a fixed order, so results are deterministic.
     const SgemmProblem& a = batch.p[blockIdx.z];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     if (m0 >= a.M || n0 >= a.N) return;
-    __shared__ float As[2][BK][BM + 1];
-    __shared__ float Bs[2][BK][BN + 1];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    __shared__ float part[4][32 * 32];
+    __shared__ float rsum[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int gm = m0 + i, gn = n0 + i;
+    const bool mok = gm < a.M, nok = gn < a.N;
+    f32x16 acc = (f32x16)0.f;
     float rs = 0.f;
-    const bool do_asum = a.asum != nullptr && blockIdx.x == 0;
-    const int ktiles = (a.K + BK - 1) / BK, total = ktiles * a.nterms;
-    float ra[4], rb[4];
-    auto gload = [&](int it) __attribute__((always_inline)) {
-        const int t = it / ktiles, k0 = (it - t * ktiles) * BK;
+    for (int t = 0; t < a.nterms; ++t) {
         const float* A = a.A[t];
         const float* B = a.B[t];
-        const int lda = a.lda[t], ldb = a.ldb[t];
+        const int64_t lda = a.lda[t], ldb = a.ldb[t];
+        // element (row gm, k) of op(A): A[gm*lda + k] or A[k*lda + gm]; element (k, col gn) of op(B): B[k*ldb + gn] or B[gn*ldb + k]
+        const int64_t a_row = a.ta ? gm : gm * lda, a_k = a.ta ? lda : 1;
+        const int64_t b_col = a.tb ? gn * ldb : gn, b_k = a.tb ? 1 : ldb;
+        // this wave owns the 8-wide slice [32*s + 8*wave, +8) of every 32-wide K block s.  Global latency (~1 us) dwarfs the
+        // four MFMAs of a slice, so slices are fetched CH at a time, one group ahead of the group being multiplied.
+        constexpr int CH = 8;
+        const int nslices = (a.K + 31) / 32;
+        float av[2][CH][4], bv[2][CH][4];
+        auto fetch = [&](int buf, int s0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = threadIdx.x + 256 * i;
-            {
-                const int kk = a.ta ? (e >> 5) : (e & 31), mm = a.ta ? (e & 31) : (e >> 5);
-                const int gm = m0 + mm, gk = k0 + kk;
-                ra[i] = (gm < a.M && gk < a.K) ? (a.ta ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
+            for (int c = 0; c < CH; ++c) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = (s0 + c) * 32 + wave * 8 + 2 * u + h;
+                    const bool kok = (s0 + c) < nslices && k < a.K;
+                    av[buf][c][u] = (mok && kok) ? A[a_row + k * a_k] : 0.f;
+                    bv[buf][c][u] = (nok && kok) ? B[b_col + k * b_k] : 0.f;
+                }
             }
-            {
-                const int kk = a.tb ? (e & 31) : (e >> 5), nn = a.tb ? (e >> 5) : (e & 31);
-                const int gk = k0 + kk, gn = n0 + nn;
-                rb[i] = (gk < a.K && gn < a.N) ? (a.tb ? B[(int64_t)gn * ldb + gk] : B[(int64_t)gk * ldb + gn]) : 0.f;
+        };
+        auto multiply = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc = mfma_f32(av[buf][c][u], bv[buf][c][u], acc);
+                    rs += av[buf][c][u];
+                }
             }
+        };
+        fetch(0, 0);
+        for (int s0 = 0; s0 < nslices; s0 += 2 * CH) {
+            if (s0 + CH < nslices) fetch(1, s0 + CH);
+            multiply(0);
+            if (s0 + 2 * CH < nslices) fetch(0, s0 + 2 * CH);
+            if (s0 + CH < nslices) multiply(1);
         }
-    };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = threadIdx.x + 256 * i;
-            As[buf][a.ta ? (e >> 5) : (e & 31)][a.ta ? (e & 31) : (e >> 5)] = ra[i];
-            Bs[buf][a.tb ? (e & 31) : (e >> 5)][a.tb ? (e >> 5) : (e & 31)] = rb[i];
-        }
-    };
-    gload(0);
-    lstore(0);
-    if (total > 1) gload(1);
-    __syncthreads();
-    for (int it = 0; it < total; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < total) lstore(buf ^ 1);                      // tile it+1 (loaded during the previous iteration) -> other LDS buffer
-        if (it + 2 < total) gload(it + 2);                        // tile it+2 in flight under the FMAs
-#pragma unroll
-        for (int kk = 0; kk < BK; ++kk) {
-            const float a0 = As[buf][kk][ty], a1 = As[buf][kk][ty + 16], b0 = Bs[buf][kk][tx], b1 = Bs[buf][kk][tx + 16];
-            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
-            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
-        }
-        if (do_asum && it < ktiles && threadIdx.x < BM) {
-#pragma unroll
-            for (int kk = 0; kk < BK; ++kk) rs += As[buf][kk][threadIdx.x];
-        }
-        __syncthreads();
     }
+    // ---- fixed-order reduction over the four waves
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 16; ++r) part[wave][drow32(r, h) * 32 + i] = acc[r];
+    if (a.asum && blockIdx.x == 0) {
+        const float v = rs + __shfl_xor(rs, 32);
+        if (h == 0) rsum[wave][i] = v;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gm = m0 + ty + 16 * i, gn = n0 + tx + 16 * j;
-            if (gm < a.M && gn < a.N) a.C[(int64_t)gm * a.ldc + gn] = acc[i][j] + (a.bias ? a.bias[gn] : 0.f);
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        if (m0 + r < a.M && n0 + c < a.N) {
+            const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            a.C[(int64_t)(m0 + r) * a.ldc + n0 + c] = v + (a.bias ? a.bias[n0 + c] : 0.f);
         }
-    if (do_asum && threadIdx.x < BM && m0 + threadIdx.x < a.M) a.asum[m0 + threadIdx.x] = rs;
+    }
+    if (a.asum && blockIdx.x == 0 && threadIdx.x < 32 && m0 + threadIdx.x < a.M)
+        a.asum[m0 + threadIdx.x] = ((rsum[0][threadIdx.x] + rsum[1][threadIdx.x]) + rsum[2][threadIdx.x]) + rsum[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------ fused clip + Adam
