@@ -1362,79 +1362,83 @@ typedef float f32x1;
 DEV f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
-    // one workgroup = one 32x32 output tile; its four waves split K four ways (interleaved 8-wide slices) and are summed
-    // through LDS in a fixed order, so results are deterministic.
+    // one workgroup = one 32x32 output tile.  K is walked in 32-wide tiles that are loaded COALESCED (the fast index follows each
+    // operand's contiguous dimension) into double-buffered LDS, two tiles ahead in registers; inside a tile the four waves take
+    // BK/4 k-values each (v_mfma_f32_32x32x2_f32, exact fp32) and their partial tiles are summed through LDS in a fixed order.
+    constexpr int BM = 32, BN = 32, BK = 128, NL = BK * 32 / 256;   // NL loads per operand per thread per k-tile
     const SgemmProblem& a = batch.p[blockIdx.z];
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= a.M || n0 >= a.N) return;
-    __shared__ float part[4][32 * 32];
-    __shared__ float rsum[4][32];
+    __shared__ float As[2][BK][BM + 1];
+    __shared__ float Bs[2][BK][BN + 1];
+    __shared__ float part[4][32 * 33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int gm = m0 + i, gn = n0 + i;
-    const bool mok = gm < a.M, nok = gn < a.N;
     f32x16 acc = (f32x16)0.f;
     float rs = 0.f;
-    for (int t = 0; t < a.nterms; ++t) {
+    const bool do_asum = a.asum != nullptr && blockIdx.x == 0;
+    const int ktiles = (a.K + BK - 1) / BK, total = ktiles * a.nterms;
+    float ra[NL], rb[NL];
+    auto gload = [&](int it) __attribute__((always_inline)) {
+        const int t = it / ktiles, k0 = (it - t * ktiles) * BK;
         const float* A = a.A[t];
         const float* B = a.B[t];
-        const int64_t lda = a.lda[t], ldb = a.ldb[t];
-        // element (row gm, k) of op(A): A[gm*lda + k] or A[k*lda + gm]; element (k, col gn) of op(B): B[k*ldb + gn] or B[gn*ldb + k]
-        const int64_t a_row = a.ta ? gm : gm * lda, a_k = a.ta ? lda : 1;
-        const int64_t b_col = a.tb ? gn * ldb : gn, b_k = a.tb ? 1 : ldb;
-        // this wave owns the 8-wide slice [32*s + 8*wave, +8) of every 32-wide K block s.  Global latency (~1 us) dwarfs the
-        // four MFMAs of a slice, so slices are fetched CH at a time, one group ahead of the group being multiplied.
-        constexpr int CH = 8;
-        const int nslices = (a.K + 31) / 32;
-        float av[2][CH][4], bv[2][CH][4];
-        auto fetch = [&](int buf, int s0) __attribute__((always_inline)) {
+        const int lda = a.lda[t], ldb = a.ldb[t];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = (s0 + c) * 32 + wave * 8 + 2 * u + h;
-                    const bool kok = (s0 + c) < nslices && k < a.K;
-                    av[buf][c][u] = (mok && kok) ? A[a_row + k * a_k] : 0.f;
-                    bv[buf][c][u] = (nok && kok) ? B[b_col + k * b_k] : 0.f;
-                }
+        for (int q = 0; q < NL; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            {
+                const int kk = a.ta ? (e >> 5) : (e & (BK - 1)), mm = a.ta ? (e & 31) : (e / BK);
+                const int gm = m0 + mm, gk = k0 + kk;
+                ra[q] = (gm < a.M && gk < a.K) ? (a.ta ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
             }
-        };
-        auto multiply = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc = mfma_f32(av[buf][c][u], bv[buf][c][u], acc);
-                    rs += av[buf][c][u];
-                }
+            {
+                const int kk = a.tb ? (e & (BK - 1)) : (e >> 5), nn = a.tb ? (e / BK) : (e & 31);
+                const int gk = k0 + kk, gn = n0 + nn;
+                rb[q] = (gk < a.K && gn < a.N) ? (a.tb ? B[(int64_t)gn * ldb + gk] : B[(int64_t)gk * ldb + gn]) : 0.f;
             }
-        };
-        fetch(0, 0);
-        for (int s0 = 0; s0 < nslices; s0 += 2 * CH) {
-            if (s0 + CH < nslices) fetch(1, s0 + CH);
-            multiply(0);
-            if (s0 + 2 * CH < nslices) fetch(0, s0 + 2 * CH);
-            if (s0 + CH < nslices) multiply(1);
         }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            As[buf][a.ta ? (e >> 5) : (e & (BK - 1))][a.ta ? (e & 31) : (e / BK)] = ra[q];
+            Bs[buf][a.tb ? (e & (BK - 1)) : (e >> 5)][a.tb ? (e / BK) : (e & 31)] = rb[q];
+        }
+    };
+    gload(0);
+    lstore(0);
+    if (total > 1) gload(1);
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < total) lstore(buf ^ 1);                      // tile it+1 (loaded during the previous iteration) -> other LDS buffer
+        if (it + 2 < total) gload(it + 2);                        // tile it+2 in flight under the MFMAs
+#pragma unroll
+        for (int u = 0; u < BK / 8; ++u) {
+            const int kk = wave * (BK / 4) + 2 * u + h;
+            acc = mfma_f32(As[buf][kk][i], Bs[buf][kk][i], acc);
+        }
+        if (do_asum && it < ktiles && threadIdx.x < BM) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rs += As[buf][kk][threadIdx.x];
+        }
+        __syncthreads();
     }
     // ---- fixed-order reduction over the four waves
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[wave][drow32(r, h) * 32 + i] = acc[r];
-    if (a.asum && blockIdx.x == 0) {
-        const float v = rs + __shfl_xor(rs, 32);
-        if (h == 0) rsum[wave][i] = v;
-    }
+    for (int r = 0; r < 16; ++r) part[wave][drow32(r, h) * 33 + i] = acc[r];
     __syncthreads();
 #pragma unroll
     for (int e = threadIdx.x; e < 1024; e += 256) {
-        const int r = e >> 5, c = e & 31;
+        const int r = e >> 5, c = e & 31, o = r * 33 + c;
         if (m0 + r < a.M && n0 + c < a.N) {
-            const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
             a.C[(int64_t)(m0 + r) * a.ldc + n0 + c] = v + (a.bias ? a.bias[n0 + c] : 0.f);
         }
     }
-    if (a.asum && blockIdx.x == 0 && threadIdx.x < 32 && m0 + threadIdx.x < a.M)
-        a.asum[m0 + threadIdx.x] = ((rsum[0][threadIdx.x] + rsum[1][threadIdx.x]) + rsum[2][threadIdx.x]) + rsum[3][threadIdx.x];
+    if (do_asum && threadIdx.x < BM && m0 + threadIdx.x < a.M) a.asum[m0 + threadIdx.x] = rs;
 }
 
 // ------------------------------------------------------------------------------------------------ fused clip + Adam
