@@ -8,8 +8,8 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, 'csrc', 'dpn_kernels.hip')
-DEPS = [SRC, os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h')]
+SRCS = [os.path.join(HERE, 'csrc', 'dpn_kernels.hip'), os.path.join(HERE, 'csrc', 'dpn_encoder.hip')]
+DEPS = SRCS + [os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h')]
 LIB = os.path.join(HERE, 'libdpn_hip.so')
 
 
@@ -26,7 +26,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: libdpn_hip.so cannot be built (no CPU fallback exists)')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', SRC, '-o', LIB + '.tmp']
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', *SRCS, '-o', LIB + '.tmp']
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,0 +1,344 @@
+// Grid-encoder ("MetaNet") kernels for MI355X: the per-FIELD part of the step that is not a plain GEMM.
+//
+// Reference behaviour (paths relative to /root/reference/DeepPhysiNet):
+//   model/attn.py:50-68     FullAttention: softmax(q k^T / sqrt(E)) v, no mask, no dropout   -> dpn_attn_fwd / dpn_attn_bwd
+//   model/transformer_net.py:28-44  x = LN1(x + attn), out = LN2(x + ffn)                    -> dpn_add_ln_fwd / dpn_add_ln_bwd
+// Sizes of the shipped config (cfg:13-24): L = 287 tokens, d_model = 256, 8 heads x 32.  Everything is exact fp32:
+// the GEMM-shaped parts use v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain), reductions are fixed-order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dpn_hip.h"
+#include "dpn_layout.h"
+
+using namespace dpn;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define DEV __device__ __forceinline__
+
+namespace {
+
+constexpr int kD = 256, kH = 8, kE = 32, kLmax = 288, kLp = 289;      // kLp: padded LDS row (conflict-free column walks)
+
+DEV f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// rows [r0, r0+nr) x 32 head columns of a [L][256] matrix -> LDS [row][33]; rows >= L are zero
+// (all 16-byte loads are issued before the first LDS store: one memory round trip, not one per element)
+template <int NR>
+DEV void load_rows16(float (*dst)[33], const float* src, int64_t row_stride, int64_t col0, int r0, int L) {
+    constexpr int N = (NR * 8 + 255) / 256;
+    float4 v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const int e = threadIdx.x + 256 * q, r = e >> 3, c4 = e & 7;
+        v[q] = (r < NR && r0 + r < L) ? *reinterpret_cast<const float4*>(src + (int64_t)(r0 + r) * row_stride + col0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const int e = threadIdx.x + 256 * q, r = e >> 3, c4 = e & 7;
+        if (r < NR) { dst[r][c4 * 4] = v[q].x; dst[r][c4 * 4 + 1] = v[q].y; dst[r][c4 * 4 + 2] = v[q].z; dst[r][c4 * 4 + 3] = v[q].w; }
+    }
+}
+DEV void load_head_rows(float (*dst)[33], const float* src, int head, int r0, int nr, int L) {
+    if (nr == kLmax) load_rows16<kLmax>(dst, src, kD, head * kE, r0, L);
+    else load_rows16<32>(dst, src, kD, head * kE, r0, L);
+}
+
+// D[32 x 32] += A[32 x K] * B[K x 32] with A(i,k) = fa(i,k), B(k,j) = fb(k,j); this wave takes the k-pairs u = wave, wave+4, ...
+template <class FA, class FB>
+DEV void mma_tile(f32x16& acc, int npairs, FA fa, FB fb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    for (int u = wave; u < npairs; u += 4) acc = mfma_f32(fa(i, 2 * u + h), fb(2 * u + h, i), acc);
+}
+// sum the four waves' partial 32x32 tiles in a fixed order; result(r, c) handed to `sink`
+template <class SINK>
+DEV void reduce_tile(const f32x16& acc, float (*part)[32 * 33], SINK sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][drow32(r, h) * 33 + i] = acc[r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        const int r = e >> 5, c = e & 31, o = r * 33 + c;
+        sink(r, c, ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
+    }
+}
+
+struct AttnArgs {
+    const float *q, *k, *v, *o, *go;
+    float *out, *P, *dS, *Dv, *dq, *dk, *dv;
+    int L;
+    float scale;
+};
+
+// ---------------------------------------------------------------------------------------------------- attention forward
+// grid (query tiles of 32, heads); one workgroup keeps K and V of its head in LDS, computes its 32 score rows, the row
+// softmax, the probabilities (saved for the backward pass) and the 32 x 32 output tile.
+__global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float (*Ks)[33] = reinterpret_cast<float (*)[33]>(smem);                                  // [288][33]
+    float (*Vs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);                 // [288][33]
+    float (*Qs)[33] = reinterpret_cast<float (*)[33]>(smem + 2 * kLmax * 33 * 4);             // [32][33]
+    float (*Ss)[kLp] = reinterpret_cast<float (*)[kLp]>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4);   // [32][289]
+    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4);   // [4][1056]
+    const int head = blockIdx.y, q0 = blockIdx.x * 32, L = a.L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    load_head_rows(Ks, a.k, head, 0, kLmax, L);
+    load_head_rows(Vs, a.v, head, 0, kLmax, L);
+    load_head_rows(Qs, a.q, head, q0, 32, L);
+    __syncthreads();
+    // scores: column tile ct belongs to wave ct % 4 (whole K = 32 per tile, no cross-wave reduction)
+    for (int ct = wave; ct < kLmax / 32; ct += 4) {
+        f32x16 acc = (f32x16)0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = mfma_f32(Qs[i][2 * u + h], Ks[ct * 32 + i][2 * u + h], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = ct * 32 + i;
+            Ss[drow32(r, h)][col] = (col < L) ? acc[r] * a.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    {   // softmax: 8 threads per row
+        const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
+        float m = -INFINITY;
+        for (int c = sub; c < kLmax; c += 8) m = fmaxf(m, Ss[row][c]);
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float s = 0.f;
+        for (int c = sub; c < kLmax; c += 8) { const float e = expf(Ss[row][c] - m); Ss[row][c] = e; s += e; }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float inv = 1.f / s;
+        const bool rok = q0 + row < L;
+        for (int c = sub; c < kLmax; c += 8) {
+            const float p = rok ? Ss[row][c] * inv : 0.f;
+            Ss[row][c] = p;
+            if (rok) a.P[((int64_t)head * kLmax + q0 + row) * kLmax + c] = p;
+        }
+    }
+    __syncthreads();
+    f32x16 acc = (f32x16)0.f;
+    mma_tile(acc, kLmax / 2, [&](int r, int k) { return Ss[r][k]; }, [&](int k, int c) { return Vs[k][c]; });
+    reduce_tile(acc, part, [&](int r, int c, float v) {
+        if (q0 + r < L) a.out[(int64_t)(q0 + r) * kD + head * kE + c] = v;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------- attention backward
+// pass 1, per (query tile, head): D = rowsum(gO * O), dP = gO V^T, dS = P * (dP - D) * scale (saved), dQ = dS K.
+__global__ __launch_bounds__(256) void dpn_attn_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float (*Ks)[33] = reinterpret_cast<float (*)[33]>(smem);
+    float (*Vs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);
+    float (*Gs)[33] = reinterpret_cast<float (*)[33]>(smem + 2 * kLmax * 33 * 4);             // gO tile [32][33]
+    float (*Ss)[kLp] = reinterpret_cast<float (*)[kLp]>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4);
+    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4);
+    __shared__ float Drow[32];
+    const int head = blockIdx.y, q0 = blockIdx.x * 32, L = a.L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    load_head_rows(Ks, a.k, head, 0, kLmax, L);
+    load_head_rows(Vs, a.v, head, 0, kLmax, L);
+    load_head_rows(Gs, a.go, head, q0, 32, L);
+    {   // P rows of this query tile: 32 x 288 floats = 2304 float4, nine per thread, all in flight at once
+        float4 pv[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int e = threadIdx.x + 256 * q, r = e / 72, c4 = e % 72;
+            pv[q] = (q0 + r < L) ? *reinterpret_cast<const float4*>(a.P + ((int64_t)head * kLmax + q0 + r) * kLmax + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int e = threadIdx.x + 256 * q, r = e / 72, c4 = e % 72;
+            Ss[r][c4 * 4] = pv[q].x; Ss[r][c4 * 4 + 1] = pv[q].y; Ss[r][c4 * 4 + 2] = pv[q].z; Ss[r][c4 * 4 + 3] = pv[q].w;
+        }
+    }
+    if (threadIdx.x < 32) {
+        const int r = threadIdx.x;
+        float d = 0.f;
+        if (q0 + r < L)
+            for (int c = 0; c < kE; ++c) d = fmaf(a.go[(int64_t)(q0 + r) * kD + head * kE + c], a.o[(int64_t)(q0 + r) * kD + head * kE + c], d);
+        Drow[r] = d;
+    }
+    __syncthreads();
+    for (int ct = wave; ct < kLmax / 32; ct += 4) {
+        f32x16 acc = (f32x16)0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = mfma_f32(Gs[i][2 * u + h], Vs[ct * 32 + i][2 * u + h], acc);      // dP tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = drow32(r, h), col = ct * 32 + i;
+            const float ds = Ss[row][col] * (acc[r] - Drow[row]) * a.scale;
+            Ss[row][col] = ds;
+            if (q0 + row < L) a.dS[((int64_t)head * kLmax + q0 + row) * kLmax + col] = ds;
+        }
+    }
+    __syncthreads();
+    f32x16 acc = (f32x16)0.f;
+    mma_tile(acc, kLmax / 2, [&](int r, int k) { return Ss[r][k]; }, [&](int k, int c) { return Ks[k][c]; });
+    reduce_tile(acc, part, [&](int r, int c, float v) {
+        if (q0 + r < L) a.dq[(int64_t)(q0 + r) * kD + head * kE + c] = v;
+    });
+}
+
+// pass 2, per (key tile, head): dK = dS^T Q, then dV = P^T gO  (reductions over all queries; the two LDS images are reused)
+__global__ __launch_bounds__(256) void dpn_attn_bwd_dkv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float (*Rs)[33] = reinterpret_cast<float (*)[33]>(smem);                                  // [288][33] all rows of Q, then of gO
+    float (*Cs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);                 // [288][33]: dS[:, key tile], then P[:, key tile]
+    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem + 2 * kLmax * 33 * 4);
+    const int head = blockIdx.y, j0 = blockIdx.x * 32, L = a.L;
+    load_head_rows(Rs, a.q, head, 0, kLmax, L);
+    load_rows16<kLmax>(Cs, a.dS + (int64_t)head * kLmax * kLmax, kLmax, j0, 0, L);
+    __syncthreads();
+    f32x16 acc = (f32x16)0.f;
+    mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dK[j][e] = sum_i dS[i][j] Q[i][e]
+    reduce_tile(acc, part, [&](int r, int c, float v) {
+        if (j0 + r < L) a.dk[(int64_t)(j0 + r) * kD + head * kE + c] = v;
+    });
+    __syncthreads();
+    load_head_rows(Rs, a.go, head, 0, kLmax, L);
+    load_rows16<kLmax>(Cs, a.P + (int64_t)head * kLmax * kLmax, kLmax, j0, 0, L);
+    __syncthreads();
+    acc = (f32x16)0.f;
+    mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dV[j][e] = sum_i P[i][j] gO[i][e]
+    reduce_tile(acc, part, [&](int r, int c, float v) {
+        if (j0 + r < L) a.dv[(int64_t)(j0 + r) * kD + head * kE + c] = v;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------- add + LayerNorm
+// out = LN(x + r) * gamma + beta over 256 columns (eps 1e-5, biased variance: nn.LayerNorm); one wave per row.
+struct LnArgs {
+    const float *x, *r, *gamma, *beta, *g, *xhat, *rstd;
+    float *out, *xhat_out, *rstd_out, *gx, *dgamma, *dbeta;
+    int rows;
+};
+DEV float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(256) void dpn_add_ln_fwd_kernel(LnArgs a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.rows) return;
+    const float4 xv = reinterpret_cast<const float4*>(a.x + (int64_t)row * kD)[lane];
+    float v[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (a.r) {
+        const float4 rv = reinterpret_cast<const float4*>(a.r + (int64_t)row * kD)[lane];
+        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+    }
+    const float mean = wave_sum64((v[0] + v[1]) + (v[2] + v[3])) * (1.f / kD);
+    float d[4], sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { d[c] = v[c] - mean; sq = fmaf(d[c], d[c], sq); }
+    const float rstd = rsqrtf(wave_sum64(sq) * (1.f / kD) + 1e-5f);
+    const float4 gm = reinterpret_cast<const float4*>(a.gamma)[lane], bt = reinterpret_cast<const float4*>(a.beta)[lane];
+    float4 xh, o;
+    xh.x = d[0] * rstd; xh.y = d[1] * rstd; xh.z = d[2] * rstd; xh.w = d[3] * rstd;
+    o.x = fmaf(xh.x, gm.x, bt.x); o.y = fmaf(xh.y, gm.y, bt.y); o.z = fmaf(xh.z, gm.z, bt.z); o.w = fmaf(xh.w, gm.w, bt.w);
+    reinterpret_cast<float4*>(a.out + (int64_t)row * kD)[lane] = o;
+    if (a.xhat_out) reinterpret_cast<float4*>(a.xhat_out + (int64_t)row * kD)[lane] = xh;
+    if (a.rstd_out && lane == 0) a.rstd_out[row] = rstd;
+}
+// gx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)); each block (4 rows) also leaves its partial column sums of
+// g*xhat and g in `partial` [blocks][2][256]; dpn_ln_colsum_kernel adds the blocks up in a fixed order -> dgamma, dbeta.
+__global__ __launch_bounds__(256) void dpn_add_ln_bwd_kernel(LnArgs a, float* partial) {
+    __shared__ float4 pg[4][64], pb[4][64];
+    const int w = threadIdx.x >> 6, row = blockIdx.x * 4 + w, lane = threadIdx.x & 63;
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    if (row < a.rows) {
+        const float4 gv = reinterpret_cast<const float4*>(a.g + (int64_t)row * kD)[lane];
+        const float4 xh = reinterpret_cast<const float4*>(a.xhat + (int64_t)row * kD)[lane];
+        const float4 gm = reinterpret_cast<const float4*>(a.gamma)[lane];
+        const float t[4] = {gv.x * gm.x, gv.y * gm.y, gv.z * gm.z, gv.w * gm.w};
+        const float xs[4] = {xh.x, xh.y, xh.z, xh.w};
+        const float m1 = wave_sum64((t[0] + t[1]) + (t[2] + t[3])) * (1.f / kD);
+        const float m2 = wave_sum64(fmaf(t[0], xs[0], t[1] * xs[1]) + fmaf(t[2], xs[2], t[3] * xs[3])) * (1.f / kD);
+        const float rstd = a.rstd[row];
+        float4 o;
+        o.x = rstd * (t[0] - m1 - xs[0] * m2); o.y = rstd * (t[1] - m1 - xs[1] * m2);
+        o.z = rstd * (t[2] - m1 - xs[2] * m2); o.w = rstd * (t[3] - m1 - xs[3] * m2);
+        reinterpret_cast<float4*>(a.gx + (int64_t)row * kD)[lane] = o;
+        dg = make_float4(gv.x * xh.x, gv.y * xh.y, gv.z * xh.z, gv.w * xh.w);
+        db = gv;
+    }
+    pg[w][lane] = dg; pb[w][lane] = db;
+    __syncthreads();
+    if (w == 0) {
+        float4 s1 = pg[0][lane], s2 = pb[0][lane];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            s1.x += pg[k][lane].x; s1.y += pg[k][lane].y; s1.z += pg[k][lane].z; s1.w += pg[k][lane].w;
+            s2.x += pb[k][lane].x; s2.y += pb[k][lane].y; s2.z += pb[k][lane].z; s2.w += pb[k][lane].w;
+        }
+        reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * 512)[lane] = s1;
+        reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * 512 + 256)[lane] = s2;
+    }
+}
+__global__ __launch_bounds__(256) void dpn_ln_colsum_kernel(const float* partial, int nblocks, float* dgamma, float* dbeta) {
+    const int c = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < nblocks; ++b) { s1 += partial[(int64_t)b * 512 + c]; s2 += partial[(int64_t)b * 512 + 256 + c]; }
+    dgamma[c] = s1;
+    dbeta[c] = s2;
+}
+
+constexpr int kAttnLds = 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4 + 4 * 32 * 33 * 4;       // 134,144 B
+constexpr int kDkvLds = 2 * kLmax * 33 * 4 + 4 * 32 * 33 * 4;                                       // 92,928 B
+
+}  // namespace
+
+extern "C" {
+
+int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, float* out, float* P, void* stream) {
+    if (!q || !k || !v || !out || !P || L <= 0 || L > kLmax) return -1;
+    AttnArgs a{};
+    a.q = q; a.k = k; a.v = v; a.out = out; a.P = P; a.L = L; a.scale = 1.0f / sqrtf((float)kE);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); once = true; }
+    hipLaunchKernelGGL(dpn_attn_fwd_kernel, dim3((L + 31) / 32, kH), dim3(256), kAttnLds, s, a);
+    return (int)hipGetLastError();
+}
+
+int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L,
+                 float* dq, float* dk, float* dv, float* dS_scratch, void* stream) {
+    if (!q || !k || !v || !o || !P || !go || !dq || !dk || !dv || !dS_scratch || L <= 0 || L > kLmax) return -1;
+    AttnArgs a{};
+    a.q = q; a.k = k; a.v = v; a.o = o; a.go = go; a.P = const_cast<float*>(P); a.dS = dS_scratch; a.dq = dq; a.dk = dk; a.dv = dv; a.L = L;
+    a.scale = 1.0f / sqrtf((float)kE);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvLds);
+        once = true;
+    }
+    hipLaunchKernelGGL(dpn_attn_bwd_dq_kernel, dim3((L + 31) / 32, kH), dim3(256), kAttnLds, s, a);
+    hipLaunchKernelGGL(dpn_attn_bwd_dkv_kernel, dim3((L + 31) / 32, kH), dim3(256), kDkvLds, s, a);
+    return (int)hipGetLastError();
+}
+
+int dpn_add_ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, int rows, float* out, float* xhat, float* rstd,
+                   void* stream) {
+    if (!x || !gamma || !beta || !out || rows <= 0) return -1;
+    LnArgs a{};
+    a.x = x; a.r = r; a.gamma = gamma; a.beta = beta; a.out = out; a.xhat_out = xhat; a.rstd_out = rstd; a.rows = rows;
+    hipLaunchKernelGGL(dpn_add_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const float* gamma, int rows, float* gx, float* dgamma, float* dbeta,
+                   float* scratch, void* stream) {
+    if (!g || !xhat || !rstd || !gamma || !gx || !dgamma || !dbeta || !scratch || rows <= 0) return -1;
+    LnArgs a{};
+    a.g = g; a.xhat = xhat; a.rstd = rstd; a.gamma = gamma; a.gx = gx; a.dgamma = dgamma; a.dbeta = dbeta; a.rows = rows;
+    const int nb = (rows + 3) / 4;
+    hipLaunchKernelGGL(dpn_add_ln_bwd_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, scratch);
+    hipLaunchKernelGGL(dpn_ln_colsum_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const float*)scratch, nb, dgamma, dbeta);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

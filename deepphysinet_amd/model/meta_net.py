@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..encoder_ops import add_layer_norm, attention
 from ..linear import linear, linear_multi
 from ..utils.position_encoding import SineCosPE
 
@@ -73,10 +74,9 @@ class FullAttention(nn.Module):
         self.output_attention = output_attention
 
     def forward(self, queries, keys, values, attn_mask=None):
-        # [B, L, H, E] -> fused SDPA on [B, H, L, E]
-        q, k, v = (z.transpose(1, 2) for z in (queries, keys, values))
-        out = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
-        return out.transpose(1, 2).contiguous(), None
+        if self.scale is not None:
+            raise NotImplementedError('a custom softmax scale is never used by the reference model (transformer_net.py:112)')
+        return attention(queries, keys, values), None            # [B, L, H, E]; HIP kernel on device tensors
 
 
 class AttentionLayer(nn.Module):
@@ -124,11 +124,11 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, attn_mask=None):
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask)
-        x = self.norm1(x + new_x)
+        x = add_layer_norm(x, new_x, self.norm1)
         # kernel-size-1 convolutions over the token axis are per-token linear maps: run them as GEMMs
         y = self.activation(linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias))
         y = linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias)
-        return self.norm2(x + y), attn
+        return add_layer_norm(x, y, self.norm2), attn
 
 
 class Encoder(nn.Module):
@@ -146,7 +146,7 @@ class Encoder(nn.Module):
             x, a = layer(x, attn_mask=attn_mask)
             attns.append(a)
         if self.norm is not None:
-            x = self.norm(x)
+            x = add_layer_norm(x, None, self.norm)
         return x, attns
 
 

@@ -142,6 +142,20 @@ typedef struct DpnGemmProblem {
 } DpnGemmProblem;
 int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems /* host array */, void* stream);
 
+/* FullAttention of the encoder (model/attn.py:50-68): o = softmax(q k^T / sqrt(32)) v for 8 heads x 32 over L <= 288 tokens.
+ * q,k,v,o,go,dq,dk,dv: [L][256] fp32 row-major (head h = columns 32h..32h+31).  P (saved probabilities) and dS_scratch:
+ * [8][288][288] fp32. */
+int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, float* out, float* P, void* stream);
+int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L,
+                 float* dq, float* dk, float* dv, float* dS_scratch, void* stream);
+
+/* out = LayerNorm_256(x + r) * gamma + beta (eps 1e-5), r may be NULL (transformer_net.py:37,44,68); saves xhat [rows][256] and rstd [rows].
+ * Backward: gx = d/d(x + r) (the same tensor is the gradient of x and of r), dgamma, dbeta [256]. */
+int dpn_add_ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, int rows, float* out, float* xhat, float* rstd,
+                   void* stream);
+int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const float* gamma, int rows, float* gx, float* dgamma, float* dbeta,
+                   float* scratch /* ceil(rows/4) * 512 floats */, void* stream);
+
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step (interface_physics.py:514-515; cfg:151-155: L2-in-gradient weight decay)
  * over a list of fp32 tensors.  The pointer arrays and `numel` are HOST arrays of length n_tensors (device pointers inside);
  * sumsq_dev (double), step_dev (int, the Adam step counter, incremented on the device) and out_norm_dev (float, may be NULL)
