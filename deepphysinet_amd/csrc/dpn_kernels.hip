@@ -64,6 +64,13 @@ DEV void frag_set2(Frag<NS>& f, const int p, float a, float b) {      // element
     if constexpr (NS == 2) f.w[1][p] = pack2(a - bf_lo(hi), b - bf_hi(hi));
 }
 
+// max(x, 0) as ONE v_max_f32: fmaxf() makes hipcc canonicalise its operand first (an extra v_max x,x per element on MFMA results)
+DEV float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 // Cody-Waite reduction by pi/2 + minimax polynomials, |err| ~1e-7 for |theta| up to a few hundred.
@@ -280,7 +287,9 @@ DEV void lds_wait_block(WBlock<NS>& b) {
     else
         asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(b.w[0][0]), "+v"(b.w[0][1]), "+v"(b.w[1][0]), "+v"(b.w[1][1]), "+v"(b.w[2][0]), "+v"(b.w[2][1]),
                      "+v"(b.w[3][0]), "+v"(b.w[3][1]) : "n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);          // hipcc would otherwise hoist register-only MFMAs above the asm wait
+    // hipcc would otherwise hoist register-only MFMAs above the asm wait.  VALU / SALU / VMEM / transcendental instructions
+    // (the previous tile's epilogue) MAY cross: they are what fills the issue slots in the shadow of the MFMAs.
+    __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x400);
 }
 
 template <int NS, bool SWAP, int KS0>
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
         for (int r = 0; r < 16; r += 2) {
             const float p0 = acc[T][r], p1 = acc[T][r + 1];
             m1w[T >> 1] |= ((p0 > 0.f) ? (1u << (16 * (T & 1) + r)) : 0u) | ((p1 > 0.f) ? (2u << (16 * (T & 1) + r)) : 0u);
-            frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, fmaxf(p0, 0.f), fmaxf(p1, 0.f));
+            frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, relu1(p0), relu1(p1));
         }
     };
     {
@@ -626,8 +635,8 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
                 const int r = 4 * q + i;
                 const float p0 = acc[T][r], p1 = acc[T][r + 1];
                 const bool on0 = p0 > 0.f, on1 = p1 > 0.f;
-                adot = fmaf(fmaxf(p0, 0.f), uu[i], adot);
-                adot = fmaf(fmaxf(p1, 0.f), uu[i + 1], adot);
+                adot = fmaf(relu1(p0), uu[i], adot);
+                adot = fmaf(relu1(p1), uu[i + 1], adot);
                 frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, on0 ? uu[i] : 0.f, on1 ? uu[i + 1] : 0.f);
                 const u32 mw = (on0 ? 0x3F80u : 0u) | (on1 ? 0x3F800000u : 0u);
                 if (r < 8) mk0.w[0][(r & 7) >> 1] = mw; else mk1.w[0][(r & 7) >> 1] = mw;
