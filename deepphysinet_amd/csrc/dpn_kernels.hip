@@ -726,7 +726,7 @@ struct ResArgs {
     int64_t n;
     DpnGeometry geo;
     DpnPhysics ph;
-    const float* gl;
+    const float *gl, *gtot;
     double* loss_sums;
     float *g_out, *g_jxi;
 };
@@ -789,7 +789,11 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
     float g[6];
     const float inv_n = 1.0f / (float)a.n;
 #pragma unroll
-    for (int e = 0; e < 6; ++e) g[e] = 2.0f * a.ph.factor[e] * (a.gl ? a.gl[e] : 1.f) * r[e] * inv_n;     // d(factor*mean(r^2))/dr
+    for (int e = 0; e < 6; ++e) {
+        // upstream weight of loss e: cotangent of losses[e] plus cotangent of the in-kernel total (1 when neither is given)
+        const float w = (a.gl || a.gtot) ? ((a.gl ? a.gl[e] : 0.f) + (a.gtot ? a.gtot[0] : 0.f)) : 1.f;
+        g[e] = 2.0f * a.ph.factor[e] * w * r[e] * inv_n;     // d(factor*mean(r^2))/dr
+    }
     const float ir = 1.f / rho, ire = 1.f / (rho + EPS);
     float gv[6], gJ[6][3];
     gv[0] = g[0] * J[0][0] + g[1] * (J[1][0] + fc) + g[2] * J[5][0] + g[3] * (C_P * J[3][0] - J[2][0] * ire + L_V * J[4][0]) + g[4] * (-J[2][0] * K + J[4][0]);
@@ -817,8 +821,13 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
 }
 
 __global__ void dpn_residual_finish_kernel(const double* sums, int64_t n, DpnPhysics ph, float* losses) {
-    const int e = threadIdx.x;
-    if (e < 6) losses[e] = (float)((double)(float)(sums[e] / (double)n) * (double)ph.factor[e]);   // .float() * factor (:104)
+    // losses[0..5]: the six scaled terms; losses[6]: their sum in the reference's order of additions (:301)
+    if (threadIdx.x == 0) {
+        float l[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { l[e] = (float)((double)(float)(sums[e] / (double)n) * (double)ph.factor[e]); losses[e] = l[e]; }   // .float() * factor (:104)
+        losses[6] = ((((l[0] + l[1]) + l[3]) + l[2]) + l[4]) + l[5];          // montion_u + montion_v + energy + continous + vapor + gas
+    }
 }
 
 __global__ __launch_bounds__(256) void dpn_smooth_l1_kernel(const float* out_n, const float* labels, int64_t n, float beta, float scale,
@@ -1581,9 +1590,9 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
 }
 
 int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t n, const DpnGeometry* geo, const DpnPhysics* phys,
-                 const float* gl, double* loss_sums, float* g_out, float* g_jxi, void* stream) {
+                 const float* gl, const float* gtot, double* loss_sums, float* g_out, float* g_jxi, void* stream) {
     if (!out_n || !jac_n || !f || !geo || !phys || n <= 0 || (g_out && !g_jxi)) return -1;
-    ResArgs a{out_n, jac_n, f, n, *geo, *phys, gl, loss_sums, g_out, g_jxi};
+    ResArgs a{out_n, jac_n, f, n, *geo, *phys, gl, gtot, loss_sums, g_out, g_jxi};
     hipLaunchKernelGGL(dpn_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return ck(hipGetLastError());
 }

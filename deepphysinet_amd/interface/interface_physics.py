@@ -161,20 +161,20 @@ class InterfacePhysics(nn.Module):
         if not (isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean'):
             raise NotImplementedError('the fused residual kernel implements nn.MSELoss(reduction="mean") (cfg:137); got %r' % (criterion,))
 
-    def pde_loss_terms(self, x, y, t, f, field_data, input_data, forecast_h, loss_factor=None, use_cache=False):
+    def pde_loss_terms(self, x, y, t, f, field_data, input_data, forecast_h, loss_factor=None, use_cache=False, with_total=False):
         """The six scaled residual losses as a [6] tensor (motion_u, motion_v, continuous, energy, vapor, gas)."""
         cfg = self.point_config(loss_factor)
         heads, evec, statics = self.physics_net.field_weights(field_data, forecast_h, use_cache=use_cache)
-        return pde_losses(cfg, x, y, t, f, input_data, heads, evec, statics)
+        return pde_losses(cfg, x, y, t, f, input_data, heads, evec, statics, with_total=with_total)
 
     def place_one_batch(self, x, y, t, f, field_data, input_data, forecast_h, criterion, loss_factor, global_step, local_rank, device,
                         summary=None, prefix='inter', log_step=100, use_cache=False):
         """:271-320.  Same arguments and return value; the fields, the Jacobian, the residuals and their backward run in HIP."""
         self._check_pde_criterion(criterion)
         f, x, y, t = f.to(device), x.to(device), y.to(device), t.to(device)
-        terms = self.pde_loss_terms(x, y, t, f, field_data, input_data, forecast_h, loss_factor, use_cache=use_cache)
-        mu, mv, co, en, va, ga = terms.unbind(0)
-        train_loss = mu + mv + en + co + va + ga                  # reference order of the additions (:301)
+        # train_loss = mu + mv + en + co + va + ga in the reference's order of additions (:301), formed inside the residual kernel
+        terms, train_loss = self.pde_loss_terms(x, y, t, f, field_data, input_data, forecast_h, loss_factor, use_cache=use_cache,
+                                                with_total=True)
         if summary is not None and global_step % log_step == 1 and local_rank == 0:
             names = ('montion_u_loss', 'montion_v_loss', 'continous_loss', 'energy_loss', 'vapor_loss', 'gas_loss')
             vals = terms.detach().cpu().tolist()

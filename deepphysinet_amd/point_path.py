@@ -200,27 +200,31 @@ class _PdeLossFn(torch.autograd.Function):
         nets = _net_ptrs(hd_, ev_, st)
         out_n, jac_n = _forward_points(cfg, ws, nets, x_, y_, t_, None, cd_, want_jac=True, want_saved=need_grad)
         sums = torch.zeros(6, dtype=torch.float64, device=dev)
-        losses = torch.empty(6, dtype=torch.float32, device=dev)
+        losses7 = torch.empty(7, dtype=torch.float32, device=dev)
         geo, ph = cfg.geometry(), cfg.physics()
-        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, _ptr(sums),
+        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, None, _ptr(sums),
                                  None, None, _stream()), 'dpn_residual')
-        L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses), _stream()), 'dpn_residual_finish')
+        L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses7), _stream()), 'dpn_residual_finish')
         ctx.cfg, ctx.ws = cfg, ws
         ctx.keep = (x_, y_, t_, f_, cd_, hd_, ev_, st, out_n, jac_n)
-        return losses
+        ctx.set_materialize_grads(False)
+        return losses7[:6], losses7[6]
 
     @staticmethod
-    def backward(ctx, g_losses):
+    def backward(ctx, g_losses, g_total):
         lib = L.load()
         cfg = ctx.cfg
         x_, y_, t_, f_, cd_, hd_, ev_, st, out_n, jac_n = ctx.keep
         n = cd_.shape[0]
         dev = cd_.device
-        gl = _f32c(g_losses)
+        gl = None if g_losses is None else _f32c(g_losses)
+        gt = None if g_total is None else _f32c(g_total).reshape(1)
+        if gl is None and gt is None:
+            return (None,) * (8 + len(st))
         g_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
         g_jxi = torch.empty((n, 6, 3), dtype=torch.float32, device=dev)
         geo, ph = cfg.geometry(), cfg.physics()
-        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), _ptr(gl), None,
+        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), _ptr(gl), _ptr(gt), None,
                                  _ptr(g_out), _ptr(g_jxi), _stream()), 'dpn_residual(grad)')
         nets = _net_ptrs(hd_, ev_, st)
         ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st)
@@ -237,9 +241,10 @@ def point_fields(cfg: PointConfig, coord_data, heads, evec, statics, x=None, y=N
     return _PointFieldsFn.apply(cfg, x, y, t, pe_in, coord_data, heads, evec, *statics)
 
 
-def pde_losses(cfg: PointConfig, x, y, t, f, coord_data, heads, evec, statics):
-    """The six scaled residual losses [6] of place_one_batch."""
-    return _PdeLossFn.apply(cfg, x, y, t, f, coord_data, heads, evec, *statics)
+def pde_losses(cfg: PointConfig, x, y, t, f, coord_data, heads, evec, statics, with_total=False):
+    """The six scaled residual losses [6] of place_one_batch (and, with_total, their sum in the reference's order as a 0-dim tensor)."""
+    terms, total = _PdeLossFn.apply(cfg, x, y, t, f, coord_data, heads, evec, *statics)
+    return (terms, total) if with_total else terms
 
 
 def pde_fields_and_jacobian(cfg: PointConfig, x, y, t, coord_data, heads, evec, statics):

@@ -97,11 +97,11 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
 
 /* inverse_norm + six residual losses (interface_physics.py:97-185,232-262).
  *   loss_sums [6] fp64: sum over points of residual^2 (un-normalised; the caller zeroes it);
- *   losses    [6] fp32: factor_i * loss_sums_i / N, written by dpn_residual_finish;
- *   when g_out != NULL also writes d(sum_i gl_i * loss_i)/d out_n  [N][6] and
- *   d(...)/d J_xi [N][6][3] (cotangent of the Jacobian w.r.t. the NORMALISED coordinates xi). */
+ *   losses    [7] fp32: [0..5] = factor_i * loss_sums_i / N, [6] = their sum in the reference's order (:301); dpn_residual_finish;
+ *   when g_out != NULL also writes d(sum_i w_i * loss_i)/d out_n  [N][6] and d(...)/d J_xi [N][6][3] (cotangent of the
+ *   Jacobian w.r.t. the NORMALISED coordinates xi), with w_i = gl[i] + gtot[0] (either may be NULL; both NULL: w_i = 1). */
 int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t n_points, const DpnGeometry* geo,
-                 const DpnPhysics* phys, const float* gl /*[6] or NULL*/, double* loss_sums,
+                 const DpnPhysics* phys, const float* gl /*[6] or NULL*/, const float* gtot /*[1] or NULL*/, double* loss_sums,
                  float* g_out, float* g_jxi, void* stream);
 int dpn_residual_finish(const double* loss_sums, int64_t n_points, const DpnPhysics* phys, float* losses, void* stream);
 

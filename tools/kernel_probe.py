@@ -25,7 +25,7 @@ with torch.no_grad():
     geo, ph = cfg.geometry(), cfg.physics()
     g_out = torch.empty((n, 6), device=dev); g_jxi = torch.empty((n, 6, 3), device=dev)
     s = PP._stream()
-    L.check(lib.dpn_residual(PP._ptr(out_n), PP._ptr(jac_n), PP._ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, None, PP._ptr(g_out), PP._ptr(g_jxi), s), 'res')
+    L.check(lib.dpn_residual(PP._ptr(out_n), PP._ptr(jac_n), PP._ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, None, None, PP._ptr(g_out), PP._ptr(g_jxi), s), 'res')
     operands = torch.empty(ws.sizes.operands, dtype=torch.uint8, device=dev)
     partials = torch.empty(ws.sizes.partials, dtype=torch.uint8, device=dev)
     fr = PP._freqs(dev)
