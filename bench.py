@@ -26,6 +26,9 @@ ALG_FLOP_FWD_JAC = 11_218_944          # algorithmic FLOP per co
 ALG_FLOP_STEP = 31_887_360             # fwd + Jacobian + bwd
 EXEC_MAC_FWD = 409_600                 # MACs per point per net actually issued by dpn_fwd_kernel
 MFMA_PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
+# HBM bytes per dpn_fwd_kernel launch at 37 265 points from the rocprofv3 PMC passes committed in profiles/
+# (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 FETCH_SIZE correction of the guide applied); bench.py cannot collect PMCs itself.
+PMC_TRAFFIC_FWD = {('bf16', 257 * 145): (2 * 57486.6 + 383619.4) * 1024}
 
 
 def synth_batch(n_points, device, seed, lon=257, lat=145, dx=27000.0, dy=27000.0):
@@ -103,45 +106,66 @@ def main():
     crit = torch.nn.MSELoss()
     sync = D.GradientAllReduce() if world > 1 else None
 
+    split_step = world > 1 or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1'
+
     def make_step(m, opt):
+        """Returns (compute, finish): compute = zero_grad + place_one_batch + backward (hipGraph-captured);
+        finish = gradient all-reduce (N > 1) + global-norm clip + Adam.  With one GPU both are captured in a single graph."""
         lf = m.train_cfg['losses']['loss_factor']
         params = list(m.physics_net.parameters())
 
-        def step():
+        def compute():
             opt.zero_grad(set_to_none=True)
             loss = m.place_one_batch(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'],
                                      batch['forecast_h'], crit, lf, 0, 0, dev)
             loss.backward()
+            return loss
+
+        def finish():
             if sync is not None:
                 sync(params)
             opt.step()                                 # global-norm clip (2.5e7) + Adam in the HIP library
-            return loss
-        return step
+
+        return compute, finish
 
     def run(prec, steps, warmup, use_graph):
         m, opt = build(prec)
-        step = make_step(m, opt)
+        compute, finish = make_step(m, opt)
+
+        def whole():
+            compute()
+            finish()
         graph = None
-        if use_graph and world == 1:
+        if use_graph:
+            # one GPU: the whole step is one graph.  N > 1: the compute part is a graph, the collective + optimiser run eagerly
+            # after it (a dozen launches), so no RCCL call is ever captured.
+            captured = compute if split_step else whole
             try:
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     for _ in range(2):
-                        step()
+                        whole()
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    static_loss = step()
+                    captured()
             except Exception as e:                 # noqa
                 if rank == 0:
                     print('[bench] hipGraph capture failed (%s: %s); running eager' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
                 m, opt = build(prec)
-                step = make_step(m, opt)
-        fn = graph.replay if graph is not None else step
+                compute, finish = make_step(m, opt)
+        if graph is None:
+            fn = whole
+        elif split_step:
+            def fn():
+                graph.replay()
+                finish()
+        else:
+            fn = graph.replay
         for _ in range(warmup):
             fn()
         if world > 1:
@@ -212,7 +236,8 @@ def main():
         nsplit = 3 if args.prec == 'bf16x2' else 1
         out['roofline'] = {'bound': 'mfma', 'kernel': 'dpn_fwd_kernel<%d>' % (2 if args.prec == 'bf16x2' else 1),
                            'achieved': ach / 1e12, 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_BF16,
-                           'traffic': None, 'kernel_ms': k_ms,
+                           'traffic': PMC_TRAFFIC_FWD.get((args.prec, args.points)), 'traffic_source': 'profiles/round1_pmc_bf16_eager_step.txt',
+                           'kernel_ms': k_ms,
                            'algorithmic_flop_per_point': ALG_FLOP_FWD_JAC,
                            'executed_mfma_tflops': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / 1e12,
                            'step_frac_of_peak': pts_per_s / world * ALG_FLOP_STEP / MFMA_PEAK_BF16}

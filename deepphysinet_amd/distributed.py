@@ -51,16 +51,17 @@ class GradientAllReduce:
             buckets.append(cur)
         work = []
         for b in buckets:
-            flat = torch.cat([g.reshape(-1) for g in b])
+            flat = torch.cat([g.reshape(-1) for g in b])                # one launch per bucket
             work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, b))
         for w, flat, b in work:
             w.wait()
             flat.div_(world)
-            off = 0
+            views, off = [], 0
             for g in b:
                 n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
+                views.append(flat[off:off + n].view_as(g))
                 off += n
+            torch._foreach_copy_(b, views)                              # multi-tensor copy back: a few launches, not one per tensor
 
 
 def broadcast_parameters(module, src=0, group=None):
