@@ -2,7 +2,7 @@
 library is missing or no MI355X is visible, every point-path call raises."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DPN_LIB', os.path.join(_HERE, 'libdpn_hip.so'))    # DPN_LIB: experiment builds only
@@ -38,6 +38,15 @@ class DpnGemmProblem(Structure):
                 ('nterms', c_int32)]
 
 
+class DpnSampler(Structure):
+    _fields_ = [('lon', c_int32), ('lat', c_int32), ('lon_in', c_int32), ('lat_in', c_int32), ('t_in', c_int32), ('t_hours', c_int32),
+                ('cells_x', c_double), ('cells_y', c_double), ('t_step_hours', c_double), ('begin_lat', c_double), ('dlat', c_double),
+                ('dx', c_float), ('dy', c_float)]
+
+
+SAMPLE_INTERIOR, SAMPLE_MARGIN, SAMPLE_EXPLICIT = 0, 1, 2
+
+
 class DpnSizes(Structure):
     _fields_ = [('n_pad', c_int64), ('packed', c_int64), ('saved', c_int64), ('operands', c_int64), ('partials', c_int64),
                 ('k_splits', c_int32)]
@@ -66,6 +75,9 @@ EXPORTS = {
     'dpn_add_ln_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_clip_adam': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                               c_float, c_float, c_void_p, c_void_p]),
+    'dpn_sample_points': (c_int, [POINTER(DpnSampler), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_uint64,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_grid_maps': (c_int, [c_void_p, c_int, c_int, POINTER(DpnPhysics), c_int, c_void_p, c_void_p]),
     'dpn_selftest': (c_int, [c_void_p, c_void_p]),
 }
 

@@ -8,7 +8,8 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, 'csrc', 'dpn_kernels.hip'), os.path.join(HERE, 'csrc', 'dpn_encoder.hip')]
+SRCS = [os.path.join(HERE, 'csrc', 'dpn_kernels.hip'), os.path.join(HERE, 'csrc', 'dpn_encoder.hip'),
+        os.path.join(HERE, 'csrc', 'dpn_sampler.hip')]
 DEPS = SRCS + [os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h')]
 LIB = os.path.join(HERE, 'libdpn_hip.so')
 

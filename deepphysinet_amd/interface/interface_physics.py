@@ -192,6 +192,26 @@ class InterfacePhysics(nn.Module):
         fields = self.physics_net.forward_xyt(field_data, x, y, t, input_data, forecast_h, use_cache=use_cache)
         return smooth_l1_data_loss(torch.cat(fields, dim=1), labels, beta=beta, factor=1.0).float() * margin_factor
 
+    @torch.no_grad()
+    def predict_grid(self, field_data, x, y, t, input_data, forecast_h, with_clip=False, use_cache=False):
+        """Full-grid evaluation of the visualisation branch (:536-591): the six fields at all lon*lat nodes, given in the
+        reference's node order (x outer, y inner; e.g. CollocationSampler.full_grid), de-normalised (the reference switches
+        the clip off there, :533) and scattered into maps [6, lat, lon] (u, v, P, T, q, rho) on the device."""
+        import ctypes
+        from .. import _lib as L
+        from ..point_path import point_fields, _ptr, _stream
+        cfg = self.point_config()
+        n = self.lon_size * self.lat_size
+        if x.numel() != n:
+            raise ValueError('predict_grid needs all %d x %d nodes (got %d points)' % (self.lon_size, self.lat_size, x.numel()))
+        heads, evec, statics = self.physics_net.field_weights(field_data, forecast_h, use_cache=use_cache)
+        out_n = point_fields(cfg, input_data, heads, evec, statics, x=x, y=y, t=t)
+        maps = torch.empty((6, self.lat_size, self.lon_size), dtype=torch.float32, device=out_n.device)
+        ph = cfg.physics()
+        L.check(L.load().dpn_grid_maps(_ptr(out_n), self.lon_size, self.lat_size, ctypes.byref(ph), int(bool(with_clip)), _ptr(maps),
+                                       _stream()), 'dpn_grid_maps')
+        return maps
+
     def training_step(self, batch: dict, optimizer, with_pde=True, max_norm=2.5e7, grad_sync=None):
         """One step body (:443-515 / :990-1065): data loss on the margin points, PDE losses on interior and margin points,
         backward, clip_grad_norm_(2.5e7), optimizer step.  `batch` holds device tensors: field_data [1,159,2405],

@@ -164,6 +164,35 @@ int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads
                   const int64_t* numel, double* sumsq_dev, int* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float max_norm, float* out_norm_dev, void* stream);
 
+/* ---------------------------------------------------------------- collocation sampler + full-grid gather
+ * Geometry of the fine (label) grid and the coarse forecast cube (dataset/physics_dataset.py:104-126): the fine grid has
+ * lon x lat nodes, dlat degrees apart, starting at begin_lat; one fine cell is cells_x / cells_y coarse cells wide
+ * (0.25 deg / 1 deg = 0.25 for the shipped data); the coarse cube has t_in time slices, t_step_hours apart
+ * (input_time_step = 6, input_time_step_nums + 1 = 5), and collocation times are whole hours in [0, t_hours]. */
+typedef struct DpnSampler {
+    int32_t lon, lat;                 /* fine grid (label_lon_size, label_lat_size) = (257, 145)     */
+    int32_t lon_in, lat_in, t_in;     /* coarse cube (65, 37, 5)                                       */
+    int32_t t_hours;                  /* input_time_step * input_time_step_nums = 24                   */
+    double cells_x, cells_y;          /* coarse cells per fine cell                                    */
+    double t_step_hours;              /* 6                                                             */
+    double begin_lat, dlat;           /* degrees                                                       */
+    float dx, dy;                     /* metres per fine cell                                          */
+} DpnSampler;
+#define DPN_SAMPLE_INTERIOR 0   /* get_inter_data       (physics_dataset.py:431-499): x, y continuous uniform, t integer hours */
+#define DPN_SAMPLE_MARGIN   1   /* get_item_label_data  (:323-429): x, y integer grid nodes, + label gather                    */
+#define DPN_SAMPLE_EXPLICIT 2   /* get_margin_grid      (:528-587): node indices xi, yi and hour ti given by the caller         */
+/* Draws n collocation points (Philox-4x32-10, counter = offset + point index, key = seed), interpolates the coarse cube
+ * cube[6][lat_in][lon_in][t_in] (fp32, variable order u10,v10,pres,t2,q2,rio) tri-linearly at them (fp64 weights, result
+ * cast to fp32: what xarray's .interp + .float() produce) and writes x, y (metres), t (seconds), f (Coriolis),
+ * coord_data[n][6].  labels[t_hours+1][6][lat][lon] / label_out[n][6] (node modes only) and raw[n][3] (the draws as
+ * doubles: x index, y index, hour) are optional (NULL). */
+int dpn_sample_points(const DpnSampler* s, const float* cube, const float* labels, int mode, const int32_t* xi, const int32_t* yi,
+                      const int32_t* ti, int64_t n, uint64_t seed, uint64_t offset, float* x, float* y, float* t, float* f,
+                      float* coord_data, float* label_out, double* raw, void* stream);
+/* Normalised fields of all lon*lat nodes in the reference's node order (x outer, y inner; interface_physics.py:538-543),
+ * out_n[lon*lat][6] -> de-normalised maps[6][lat][lon] (inverse_norm :232-262 + the scatter loop :583-591). */
+int dpn_grid_maps(const float* out_n, int lon, int lat, const DpnPhysics* phys, int with_clip, float* maps, void* stream);
+
 /* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
 int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);
 
