@@ -1483,8 +1483,18 @@ __global__ __launch_bounds__(256) void dpn_gradnorm_kernel(AdamTable t, double* 
     const int ti = adam_find(t, blockIdx.x);
     const int base = (blockIdx.x - t.chunk_start[ti]) * kAdamChunk;
     const float* g = t.g[ti];
+    const int end = min(base + kAdamChunk, t.numel[ti]);
     float s = 0.f;
-    for (int i = base + threadIdx.x; i < base + kAdamChunk && i < t.numel[ti]; i += 256) s = fmaf(g[i], g[i], s);
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {                         // 16-byte loads over the aligned body, scalars for the tail
+        const int end4 = base + ((end - base) & ~3);
+        for (int i = base + 4 * threadIdx.x; i < end4; i += 1024) {
+            const float4 q = *reinterpret_cast<const float4*>(g + i);
+            s = fmaf(q.x, q.x, s); s = fmaf(q.y, q.y, s); s = fmaf(q.z, q.z, s); s = fmaf(q.w, q.w, s);
+        }
+        for (int i = end4 + threadIdx.x; i < end; i += 256) s = fmaf(g[i], g[i], s);
+    } else {
+        for (int i = base + threadIdx.x; i < end; i += 256) s = fmaf(g[i], g[i], s);
+    }
     double d = (double)s;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
@@ -1504,13 +1514,28 @@ __global__ __launch_bounds__(256) void dpn_adam_kernel(AdamTable t, const double
     const int ti = adam_find(t, blockIdx.x);
     const int base = (blockIdx.x - t.chunk_start[ti]) * kAdamChunk;
     float* p = t.p[ti]; const float* g = t.g[ti]; float* m = t.m[ti]; float* v = t.v[ti];
-    for (int i = base + threadIdx.x; i < base + kAdamChunk && i < t.numel[ti]; i += 256) {
-        const float pi = p[i];
-        const float gi = fmaf(wd, pi, g[i] * coef);
-        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);                   // lerp(m, g, 1-b1)
-        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
-        m[i] = mi; v[i] = vi;
-        p[i] = pi - step_size * mi / (sqrtf(vi) / bc2s + eps);
+    const int end = min(base + kAdamChunk, t.numel[ti]);
+    auto upd = [&](float& pi, const float graw, float& mi, float& vi) __attribute__((always_inline)) {
+        const float gi = fmaf(wd, pi, graw * coef);
+        mi = fmaf(b1, mi, (1.f - b1) * gi);                                  // lerp(m, g, 1-b1)
+        vi = fmaf(b2, vi, (1.f - b2) * gi * gi);
+        pi = pi - step_size * mi / (sqrtf(vi) / bc2s + eps);
+    };
+    int scalar_from = base;
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        const int end4 = base + ((end - base) & ~3);
+        for (int i = base + 4 * threadIdx.x; i < end4; i += 1024) {
+            float4 P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i), V = *reinterpret_cast<float4*>(v + i);
+            const float4 G = *reinterpret_cast<const float4*>(g + i);
+            upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
+            *reinterpret_cast<float4*>(p + i) = P; *reinterpret_cast<float4*>(m + i) = M; *reinterpret_cast<float4*>(v + i) = V;
+        }
+        scalar_from = end4;
+    }
+    for (int i = scalar_from + threadIdx.x; i < end; i += 256) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        upd(pi, g[i], mi, vi);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 
@@ -1541,10 +1566,12 @@ static inline int choose_splits(int64_t n_pad) {
 #ifdef DPN_EXP_SPLITS
     return DPN_EXP_SPLITS;
 #endif
-    // 24 workgroups (4 products x 6 nets) per split; two 8-wave workgroups fit on a CU -> ~2 x 256 CUs / 24
+    // 24 workgroups (4 products x 6 nets) per split and one 8-wave workgroup per CU (LDS ring): 10 splits = 240 workgroups is
+    // the largest single round on 256 CUs.  Measured at 37 265 points: 10 -> 19.3 M points/s, 11 -> 18.1 M (tail round),
+    // 21 -> 18.7 M (two rounds, twice the partials for dpn_finish_rows to reduce).
     int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
-    if (c > 21) c = 21;
+    if (c > 10) c = 10;
     return (int)c;
 }
 static inline int ck(hipError_t e) { return (int)e; }
