@@ -35,7 +35,10 @@ class DpnPhysics(Structure):
 class DpnGemmProblem(Structure):
     _fields_ = [('A', c_void_p * 3), ('B', c_void_p * 3), ('lda', c_int32 * 3), ('ldb', c_int32 * 3), ('bias', c_void_p), ('C', c_void_p),
                 ('asum', c_void_p), ('M', c_int32), ('N', c_int32), ('K', c_int32), ('ldc', c_int32), ('ta', c_int32), ('tb', c_int32),
-                ('nterms', c_int32)]
+                ('nterms', c_int32), ('aux', c_void_p), ('aux_out', c_void_p), ('epi', c_int32)]
+
+
+EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_ADD = 0, 1, 2, 3
 
 
 class DpnSampler(Structure):

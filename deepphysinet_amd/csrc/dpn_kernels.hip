@@ -776,14 +776,21 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
     r[4] = -omega * K + B;                                                                 // :146-175
     r[5] = p - rho * (1.f + 0.608f * q) * R_D * T;                                         // :177-179
     if (a.loss_sums) {
+        // fp64 partial sums (residual^2 spans 1e-20..1e+20 across equations): wave shuffle tree, then the four waves of the block
+        // in a fixed order -> one [6] row per block.  No atomics: dpn_residual_finish adds the rows in a fixed order, so the
+        // losses are run-to-run deterministic (and 3.5k serialised fp64 atomics are gone from the step).
+        __shared__ double wsum[4][6];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
-            // fp64 partial sums: residual^2 spans 1e-20..1e+20 across equations
             double s = valid ? (double)r[e] * (double)r[e] : 0.0;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&a.loss_sums[e], s);
+            if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][e] = s;
         }
+        __syncthreads();
+        if (threadIdx.x < 6)
+            a.loss_sums[(int64_t)blockIdx.x * 6 + threadIdx.x] =
+                ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
     }
     if (!a.g_out || !valid) return;
     float g[6];
@@ -820,14 +827,19 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
     }
 }
 
-__global__ void dpn_residual_finish_kernel(const double* sums, int64_t n, DpnPhysics ph, float* losses) {
-    // losses[0..5]: the six scaled terms; losses[6]: their sum in the reference's order of additions (:301)
-    if (threadIdx.x == 0) {
-        float l[6];
+__global__ __launch_bounds__(384) void dpn_residual_finish_kernel(const double* partials, int64_t n, DpnPhysics ph, float* losses) {
+    // partials: [ceil(n/256)][6] block rows of dpn_residual.  Wave e adds equation e (lane l takes rows l, l+64, ... in order, then a
+    // fixed shuffle tree).  losses[0..5]: the six scaled terms; losses[6]: their sum in the reference's order of additions (:301)
+    __shared__ float l[6];
+    const int e = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nblk = (n + 255) / 256;
+    double s = 0.0;
+    for (int64_t b = lane; b < nblk; b += 64) s += partials[b * 6 + e];
 #pragma unroll
-        for (int e = 0; e < 6; ++e) { l[e] = (float)((double)(float)(sums[e] / (double)n) * (double)ph.factor[e]); losses[e] = l[e]; }   // .float() * factor (:104)
-        losses[6] = ((((l[0] + l[1]) + l[3]) + l[2]) + l[4]) + l[5];          // montion_u + montion_v + energy + continous + vapor + gas
-    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) { l[e] = (float)((double)(float)(s / (double)n) * (double)ph.factor[e]); losses[e] = l[e]; }   // .float() * factor (:104)
+    __syncthreads();
+    if (threadIdx.x == 0) losses[6] = ((((l[0] + l[1]) + l[3]) + l[2]) + l[4]) + l[5];   // montion_u + montion_v + energy + continous + vapor + gas
 }
 
 __global__ __launch_bounds__(256) void dpn_smooth_l1_kernel(const float* out_n, const float* labels, int64_t n, float beta, float scale,
@@ -1369,7 +1381,17 @@ struct SgemmProblem {
     const float* bias;
     float *C, *asum;
     int M, N, K, ldc, ta, tb, nterms;
+    const float* aux;          // epilogue operand [M][ldc] (epi 2, 3)
+    float* aux_out;            // pre-activation output [M][ldc] (epi 1, optional)
+    int epi;                   // DPN_EPI_*
 };
+// exact-erf GELU and its derivative, the formulas of torch's GeluCUDAKernelImpl / GeluBackwardCUDAKernelImpl (approximate='none')
+DEV float gelu_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+DEV float gelu_exact_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;      // M_2_SQRTPI * M_SQRT1_2 * 0.5
+    return cdf + x * pdf;
+}
 struct SgemmBatch {
     SgemmProblem p[kBatchMaxProblems];
     int n;
@@ -1387,9 +1409,11 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     const SgemmProblem& a = batch.p[blockIdx.z];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= a.M || n0 >= a.N) return;
+    // 66 KB of LDS: two workgroups per CU.  The split-K partial tiles (16.5 KB) reuse the A staging buffers after the last k-tile.
     __shared__ float As[2][BK][BM + 1];
     __shared__ float Bs[2][BK][BN + 1];
-    __shared__ float part[4][32 * 33];
+    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(&As[0][0][0]);
+    static_assert(sizeof(As) >= 4 * 32 * 33 * sizeof(float), "partial tiles must fit in the A staging buffers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     f32x16 acc = (f32x16)0.f;
@@ -1452,8 +1476,13 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     for (int e = threadIdx.x; e < 1024; e += 256) {
         const int r = e >> 5, c = e & 31, o = r * 33 + c;
         if (m0 + r < a.M && n0 + c < a.N) {
-            const float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
-            a.C[(int64_t)(m0 + r) * a.ldc + n0 + c] = v + (a.bias ? a.bias[n0 + c] : 0.f);
+            float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+            v += a.bias ? a.bias[n0 + c] : 0.f;
+            const int64_t idx = (int64_t)(m0 + r) * a.ldc + n0 + c;
+            if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = v; v = gelu_exact(v); }
+            else if (a.epi == DPN_EPI_MUL_GELU_GRAD) v *= gelu_exact_grad(a.aux[idx]);
+            else if (a.epi == DPN_EPI_ADD) v += a.aux[idx];
+            a.C[idx] = v;
         }
     }
     if (do_asum && threadIdx.x < BM && m0 + threadIdx.x < a.M) a.asum[m0 + threadIdx.x] = rs;
@@ -1626,7 +1655,7 @@ int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t
 
 int dpn_residual_finish(const double* loss_sums, int64_t n, const DpnPhysics* phys, float* losses, void* stream) {
     if (!loss_sums || !phys || !losses) return -1;
-    hipLaunchKernelGGL(dpn_residual_finish_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), loss_sums, n, *phys, losses);
+    hipLaunchKernelGGL(dpn_residual_finish_kernel, dim3(1), dim3(384), 0, reinterpret_cast<hipStream_t>(stream), loss_sums, n, *phys, losses);
     return ck(hipGetLastError());
 }
 
@@ -1714,9 +1743,10 @@ int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream
     for (int i = 0; i < n_problems; ++i) {
         const DpnGemmProblem& q = problems[i];
         if (q.nterms < 1 || q.nterms > kBatchMaxTerms || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0) return -1;
+        if (q.epi < 0 || q.epi > DPN_EPI_ADD || ((q.epi == DPN_EPI_MUL_GELU_GRAD || q.epi == DPN_EPI_ADD) && !q.aux)) return -1;
         SgemmProblem& p = b.p[i];
         for (int t = 0; t < kBatchMaxTerms; ++t) { p.A[t] = q.A[t]; p.B[t] = q.B[t]; p.lda[t] = q.lda[t]; p.ldb[t] = q.ldb[t]; }
-        p.bias = q.bias; p.C = q.C; p.asum = q.asum; p.M = q.M; p.N = q.N; p.K = q.K; p.ldc = q.ldc; p.ta = q.ta; p.tb = q.tb; p.nterms = q.nterms;
+        p.bias = q.bias; p.C = q.C; p.asum = q.asum; p.aux = q.aux; p.aux_out = q.aux_out; p.epi = q.epi; p.M = q.M; p.N = q.N; p.K = q.K; p.ldc = q.ldc; p.ta = q.ta; p.tb = q.tb; p.nterms = q.nterms;
         gx = gx > (q.N + 31) / 32 ? gx : (q.N + 31) / 32;
         gy = gy > (q.M + 31) / 32 ? gy : (q.M + 31) / 32;
     }

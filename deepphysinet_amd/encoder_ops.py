@@ -93,3 +93,96 @@ def add_layer_norm(x, r, norm: torch.nn.LayerNorm):
     if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and norm.elementwise_affine and norm.eps == 1e-5:
         return _AddLayerNormFn.apply(x, r, norm.weight, norm.bias)
     return norm(x if r is None else x + r)
+
+
+class _EncoderLayerFn(torch.autograd.Function):
+    """One EncoderLayer (model/transformer_net.py:28-44 + attn.py:177-196) as a single autograd node with a hand-scheduled backward:
+        x1 = LN1(x + out_proj(attention(q(x), k(x), v(x))));  out = LN2(x1 + conv2(gelu(conv1(x1))))
+    7 launches forward, 9 backward.  GELU and its derivative ride in the GEMM epilogues, and each residual-branch gradient joins
+    the input gradient inside the GEMM that produces it (DPN_EPI_ADD), so no separate elementwise kernel sits on the dependency
+    chain of the step.  x: [L, 256]; conv weights as [d_ff, 256] / [256, d_ff] matrices."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, wc1, bc1, wc2, bc2, g2, be2):
+        from .linear import _launch, _problem
+        lib = L.load()
+        x = _c(x)
+        wq, wk, wv, wo, wc1, wc2 = (_c(w) for w in (wq, wk, wv, wo, wc1, wc2))
+        n, D = x.shape
+        Fh = wc1.shape[0]
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        q, k, v = new(n, D), new(n, D), new(n, D)
+        _launch([_problem(n, D, D, [(x, D, w, D)], y, D, 0, 1, bias=b) for w, b, y in ((wq, bq, q), (wk, bk, k), (wv, bv, v))])
+        o, P = new(n, D), new(8, 288, 288)
+        L.check(lib.dpn_attn_fwd(_p(q), _p(k), _p(v), n, _p(o), _p(P), _s()), 'dpn_attn_fwd')
+        a = new(n, D)
+        _launch([_problem(n, D, D, [(o, D, wo, D)], a, D, 0, 1, bias=bo)])
+        x1, xhat1, rstd1 = new(n, D), new(n, D), new(n)
+        L.check(lib.dpn_add_ln_fwd(_p(x), _p(a), _p(g1), _p(be1), n, _p(x1), _p(xhat1), _p(rstd1), _s()), 'dpn_add_ln_fwd')
+        pre, act = new(n, Fh), new(n, Fh)
+        _launch([_problem(n, Fh, D, [(x1, D, wc1, D)], act, Fh, 0, 1, bias=bc1, epi=L.EPI_GELU, aux_out=pre)])
+        y = new(n, D)
+        _launch([_problem(n, D, Fh, [(act, Fh, wc2, Fh)], y, D, 0, 1, bias=bc2)])
+        out, xhat2, rstd2 = new(n, D), new(n, D), new(n)
+        L.check(lib.dpn_add_ln_fwd(_p(x1), _p(y), _p(g2), _p(be2), n, _p(out), _p(xhat2), _p(rstd2), _s()), 'dpn_add_ln_fwd')
+        ctx.save_for_backward(x, q, k, v, o, P, x1, pre, act, xhat1, rstd1, xhat2, rstd2, wq, wk, wv, wo, wc1, wc2, g1, g2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .linear import _launch, _problem
+        lib = L.load()
+        x, q, k, v, o, P, x1, pre, act, xhat1, rstd1, xhat2, rstd2, wq, wk, wv, wo, wc1, wc2, g1, g2 = ctx.saved_tensors
+        n, D = x.shape
+        Fh = wc1.shape[0]
+        dev = x.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        scratch = new(((n + 3) // 4) * 512)
+        # LN2
+        gs2, dg2, dbe2 = new(n, D), new(D), new(D)
+        L.check(lib.dpn_add_ln_bwd(_p(_c(g)), _p(xhat2), _p(rstd2), _p(g2), n, _p(gs2), _p(dg2), _p(dbe2), _p(scratch), _s()), 'dpn_add_ln_bwd')
+        # conv2: d(pre) = (gs2 W_c2) * gelu'(pre) ; dW_c2 = gs2^T act ; db_c2 = sum_rows gs2
+        dpre, dwc2, dbc2 = new(n, Fh), new(D, Fh), new(D)
+        _launch([_problem(n, Fh, D, [(gs2, D, wc2, Fh)], dpre, Fh, 0, 0, epi=L.EPI_MUL_GELU_GRAD, aux=pre),
+                 _problem(D, Fh, n, [(gs2, D, act, Fh)], dwc2, Fh, 1, 0, asum=dbc2)])
+        # conv1: d(x1) = dpre W_c1 + gs2 (the residual branch) ; dW_c1 = dpre^T x1
+        dx1, dwc1, dbc1 = new(n, D), new(Fh, D), new(Fh)
+        _launch([_problem(n, D, Fh, [(dpre, Fh, wc1, D)], dx1, D, 0, 0, epi=L.EPI_ADD, aux=gs2),
+                 _problem(Fh, D, n, [(dpre, Fh, x1, D)], dwc1, D, 1, 0, asum=dbc1)])
+        # LN1
+        gs1, dg1, dbe1 = new(n, D), new(D), new(D)
+        scratch1 = new(((n + 3) // 4) * 512)
+        L.check(lib.dpn_add_ln_bwd(_p(dx1), _p(xhat1), _p(rstd1), _p(g1), n, _p(gs1), _p(dg1), _p(dbe1), _p(scratch1), _s()), 'dpn_add_ln_bwd')
+        # out projection
+        do, dwo, dbo = new(n, D), new(D, D), new(D)
+        _launch([_problem(n, D, D, [(gs1, D, wo, D)], do, D, 0, 0), _problem(D, D, n, [(gs1, D, o, D)], dwo, D, 1, 0, asum=dbo)])
+        # attention
+        dq, dk, dv, dS = new(n, D), new(n, D), new(n, D), new(8, 288, 288)
+        L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(do), n, _p(dq), _p(dk), _p(dv), _p(dS), _s()), 'dpn_attn_bwd')
+        # q/k/v projections: dx = dq Wq + dk Wk + dv Wv + gs1 (the residual branch)
+        dx, dwq, dwk, dwv, dbq, dbk, dbv = new(n, D), new(D, D), new(D, D), new(D, D), new(D), new(D), new(D)
+        _launch([_problem(n, D, D, [(dq, D, wq, D), (dk, D, wk, D), (dv, D, wv, D)], dx, D, 0, 0, epi=L.EPI_ADD, aux=gs1),
+                 _problem(D, D, n, [(dq, D, x, D)], dwq, D, 1, 0, asum=dbq),
+                 _problem(D, D, n, [(dk, D, x, D)], dwk, D, 1, 0, asum=dbk),
+                 _problem(D, D, n, [(dv, D, x, D)], dwv, D, 1, 0, asum=dbv)])
+        return dx, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg1, dbe1, dwc1, dbc1, dwc2, dbc2, dg2, dbe2
+
+
+def encoder_layer_fused(x, layer):
+    """EncoderLayer.forward for [1, L, 256] fp32 device tensors with the shipped shapes (8 heads x 32, gelu, LayerNorm eps 1e-5,
+    all biases present); returns None when the layer does not fit, so that the caller takes the per-op path."""
+    att = layer.attention
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] == 1 and x.shape[2] == 256 and x.shape[1] <= 288):
+        return None
+    if not (att.n_heads == 8 and not att.mix and layer.activation is F.gelu and layer.norm1.eps == 1e-5 and layer.norm2.eps == 1e-5
+            and layer.norm1.elementwise_affine and layer.norm2.elementwise_affine and layer.conv1.weight.shape[1] == 256
+            and layer.conv2.weight.shape[0] == 256 and att.query_projection.weight.shape == (256, 256)
+            and all(m.bias is not None for m in (att.query_projection, att.key_projection, att.value_projection, att.out_projection,
+                                                 layer.conv1, layer.conv2))):
+        return None
+    out = _EncoderLayerFn.apply(x.view(x.shape[1], 256), att.query_projection.weight, att.query_projection.bias, att.key_projection.weight,
+                                att.key_projection.bias, att.value_projection.weight, att.value_projection.bias,
+                                att.out_projection.weight, att.out_projection.bias, layer.norm1.weight, layer.norm1.bias,
+                                layer.conv1.weight.squeeze(-1), layer.conv1.bias, layer.conv2.weight.squeeze(-1), layer.conv2.bias,
+                                layer.norm2.weight, layer.norm2.bias)
+    return out.view(1, -1, 256)              # views, not x[0]: a select's backward is a zero fill + a copy

@@ -16,8 +16,9 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def _problem(M, N, K, terms, C, ldc, ta, tb, bias=None, asum=None):
+def _problem(M, N, K, terms, C, ldc, ta, tb, bias=None, asum=None, epi=0, aux=None, aux_out=None):
     q = L.DpnGemmProblem()
+    q.epi, q.aux, q.aux_out = epi, _p(aux), _p(aux_out)
     for i, (A, lda, B, ldb) in enumerate(terms):
         q.A[i], q.lda[i], q.B[i], q.ldb[i] = A.data_ptr(), lda, B.data_ptr(), ldb
     q.bias, q.C, q.asum = _p(bias), C.data_ptr(), _p(asum)

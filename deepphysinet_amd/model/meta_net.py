@@ -1,10 +1,11 @@
 """Grid encoder ("MetaNet") with the reference's module tree and state_dict names.
 
 Reference: model/meta_net.py:13-20, model/transformer_net.py:17-44,47-72,95-129, model/embed.py:16-64,
-model/attn.py:43-68,161-196.  Same parameters, same math, different execution: the whole encoder is <2 % of the
-step's FLOPs, so it runs on library GEMMs (rocBLAS/hipBLASLt through torch) with the attention, the 1x1
-convolutions and the layer norms issued as fused torch ops, and its output is cached across the calls of one
-training step (the model has no dropout, so the three forwards the reference does per step are identical).
+model/attn.py:43-68,161-196.  Same parameters, same math, different execution: every GEMM (linears, 1x1 convolutions, the
+circular token-embedding convolution), the attention and the layer norms run on the library's own exact-fp32 MFMA kernels
+(csrc/dpn_kernels.hip dpn_sgemm_batch, csrc/dpn_encoder.hip); a whole EncoderLayer is one autograd node with a hand-scheduled
+backward (encoder_ops._EncoderLayerFn).  The encoder output is cached across the calls of one training step (the model has
+no dropout, so the three forwards the reference does per step are identical).
 """
 import math
 
@@ -12,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..encoder_ops import add_layer_norm, attention
+from ..encoder_ops import add_layer_norm, attention, encoder_layer_fused
 from ..linear import linear, linear_multi
 from ..utils.position_encoding import SineCosPE
 
@@ -123,6 +124,10 @@ class EncoderLayer(nn.Module):
         self.activation = F.relu if activation == 'relu' else F.gelu
 
     def forward(self, x, attn_mask=None):
+        if attn_mask is None and not getattr(self.attention.inner_attention, 'output_attention', False):
+            fused = encoder_layer_fused(x, self)            # whole layer = one autograd node (7 launches fwd, 9 bwd)
+            if fused is not None:
+                return fused, None
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask)
         x = add_layer_norm(x, new_x, self.norm1)
         # kernel-size-1 convolutions over the token axis are per-token linear maps: run them as GEMMs

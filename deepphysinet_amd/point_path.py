@@ -199,7 +199,7 @@ class _PdeLossFn(torch.autograd.Function):
         ws = _Workspace(n, cfg.prec, dev)
         nets = _net_ptrs(hd_, ev_, st)
         out_n, jac_n = _forward_points(cfg, ws, nets, x_, y_, t_, None, cd_, want_jac=True, want_saved=need_grad)
-        sums = torch.zeros(6, dtype=torch.float64, device=dev)
+        sums = torch.empty(((n + 255) // 256) * 6, dtype=torch.float64, device=dev)      # per-block rows, reduced by dpn_residual_finish
         losses7 = torch.empty(7, dtype=torch.float32, device=dev)
         geo, ph = cfg.geometry(), cfg.physics()
         L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, None, _ptr(sums),

@@ -96,8 +96,9 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
             float* out_n, float* jac_n, void* saved, void* stream);
 
 /* inverse_norm + six residual losses (interface_physics.py:97-185,232-262).
- *   loss_sums [6] fp64: sum over points of residual^2 (un-normalised; the caller zeroes it);
- *   losses    [7] fp32: [0..5] = factor_i * loss_sums_i / N, [6] = their sum in the reference's order (:301); dpn_residual_finish;
+ *   loss_sums [ceil(N/256)][6] fp64: per-block sums over points of residual^2 (written, not accumulated: no zeroing, no atomics;
+ *             dpn_residual_finish adds the rows in a fixed order -> deterministic losses);
+ *   losses    [7] fp32: [0..5] = factor_i * sum_i / N, [6] = their sum in the reference's order (:301); dpn_residual_finish;
  *   when g_out != NULL also writes d(sum_i w_i * loss_i)/d out_n  [N][6] and d(...)/d J_xi [N][6][3] (cotangent of the
  *   Jacobian w.r.t. the NORMALISED coordinates xi), with w_i = gl[i] + gtot[0] (either may be NULL; both NULL: w_i = 1). */
 int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t n_points, const DpnGeometry* geo,
@@ -135,10 +136,16 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
 /* Up to 4 independent small fp32 GEMMs in one launch; each C[M][N] = sum_{t<nterms} op(A_t)[M][K] op(B_t)[K][N] (+ bias[N]),
  * asum as in dpn_sgemm.  Used for the q/k/v projections (attn.py:183-185) and for the paired input-/weight-gradient GEMMs
  * of every encoder linear. */
+#define DPN_EPI_NONE 0
+#define DPN_EPI_GELU 1            /* C = gelu(v) (exact erf, transformer_net.py:26,41); aux_out (optional) receives v                    */
+#define DPN_EPI_MUL_GELU_GRAD 2   /* C = v * gelu'(aux): backward of the activation folded into the GEMM that feeds it                 */
+#define DPN_EPI_ADD 3             /* C = v + aux: the residual-branch gradient joins the input gradient without a separate add kernel  */
 typedef struct DpnGemmProblem {
     const float* A[3]; const float* B[3]; int32_t lda[3], ldb[3];
     const float* bias; float* C; float* asum;
     int32_t M, N, K, ldc, ta, tb, nterms;
+    const float* aux; float* aux_out;   /* [M][ldc], see DPN_EPI_* */
+    int32_t epi;
 } DpnGemmProblem;
 int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems /* host array */, void* stream);
 
