@@ -33,7 +33,8 @@ class DpnPhysics(Structure):
 
 
 class DpnGemmProblem(Structure):
-    _fields_ = [('A', c_void_p * 3), ('B', c_void_p * 3), ('lda', c_int32 * 3), ('ldb', c_int32 * 3), ('bias', c_void_p), ('C', c_void_p),
+    _fields_ = [('A', c_void_p * 12), ('B', c_void_p * 12), ('lda', c_int32 * 12), ('ldb', c_int32 * 12), ('k_term', c_int32 * 12),
+                ('bias', c_void_p), ('C', c_void_p),
                 ('asum', c_void_p), ('M', c_int32), ('N', c_int32), ('K', c_int32), ('ldc', c_int32), ('ta', c_int32), ('tb', c_int32),
                 ('nterms', c_int32), ('aux', c_void_p), ('aux_out', c_void_p), ('epi', c_int32)]
 
@@ -78,6 +79,9 @@ EXPORTS = {
     'dpn_add_ln_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_clip_adam': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                               c_float, c_float, c_void_p, c_void_p]),
+    'dpn_lead_pe': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'dpn_im2col_circ3': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'dpn_embed_assemble': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_sample_points': (c_int, [POINTER(DpnSampler), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_uint64,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_grid_maps': (c_int, [c_void_p, c_int, c_int, POINTER(DpnPhysics), c_int, c_void_p, c_void_p]),

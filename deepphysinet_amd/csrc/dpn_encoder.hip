@@ -285,6 +285,34 @@ __global__ __launch_bounds__(256) void dpn_ln_colsum_kernel(const float* partial
     dbeta[c] = s2;
 }
 
+
+// ---------------------------------------------------------------- data embedding pieces (model/embed.py:36-64)
+// SineCosPE of one scalar (include_input=False): out[2f] = sin(h * freq[f]), out[2f+1] = cos(h * freq[f])   (position_encoding.py:35-50)
+__global__ void dpn_lead_pe_kernel(const float* h, const float* fa, int na, float* oa, const float* fb, int nb, float* ob) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float hv = h[0];
+    if (i < na) { const float s = hv * fa[i]; oa[2 * i] = sinf(s); oa[2 * i + 1] = cosf(s); }
+    else if (i < na + nb) { const int j = i - na; const float s = hv * fb[j]; ob[2 * j] = sinf(s); ob[2 * j + 1] = cosf(s); }
+}
+// im2col of the circular k=3 convolution along the token axis: out[t][c*3 + tap] = x[(t + tap - 1) mod T][c], so that the conv is
+// out . W^T with the Conv1d weight [d_model][C][3] read in place as [d_model][3C] (no permuted copy, and the weight gradient of
+// that GEMM is already in the parameter's layout).
+__global__ __launch_bounds__(256) void dpn_im2col_circ3_kernel(const float* x, int T, int C, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)T * C * 3) return;
+    const int t = (int)(i / (3 * C)), r = (int)(i - (int64_t)t * 3 * C), c = r / 3, tap = r - 3 * c;
+    int ts = t + tap - 1;
+    ts = ts < 0 ? ts + T : (ts >= T ? ts - T : ts);
+    out[i] = x[(int64_t)ts * C + c];
+}
+// x0 = cat(learnable_token, value_embedding) + positional table + lead-time embedding (embed.py:60-64, transformer_net.py:124-126)
+__global__ __launch_bounds__(256) void dpn_embed_assemble_kernel(const float* token, int n_tok, const float* emb, int n_emb, const float* pos,
+                                                                  const float* te, float* out) {
+    const int row = blockIdx.x, c = threadIdx.x;
+    const float v = row < n_tok ? token[(int64_t)row * kD + c] : emb[(int64_t)(row - n_tok) * kD + c];
+    out[(int64_t)row * kD + c] = (v + pos[(int64_t)row * kD + c]) + te[c];
+}
+
 constexpr int kAttnLds = 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4 + 4 * 32 * 33 * 4;       // 134,144 B
 constexpr int kDkvLds = 2 * kLmax * 33 * 4 + 4 * 32 * 33 * 4;                                       // 92,928 B
 
@@ -338,6 +366,27 @@ int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const f
     const int nb = (rows + 3) / 4;
     hipLaunchKernelGGL(dpn_add_ln_bwd_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, scratch);
     hipLaunchKernelGGL(dpn_ln_colsum_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const float*)scratch, nb, dgamma, dbeta);
+    return (int)hipGetLastError();
+}
+
+int dpn_lead_pe(const float* h_dev, const float* freqs_a, int n_a, float* out_a, const float* freqs_b, int n_b, float* out_b, void* stream) {
+    if (!h_dev || !freqs_a || !out_a || n_a <= 0 || n_b < 0 || (n_b > 0 && (!freqs_b || !out_b))) return -1;
+    hipLaunchKernelGGL(dpn_lead_pe_kernel, dim3((n_a + n_b + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), h_dev, freqs_a, n_a,
+                       out_a, freqs_b, n_b, out_b);
+    return (int)hipGetLastError();
+}
+
+int dpn_im2col_circ3(const float* x, int T, int C, float* out, void* stream) {
+    if (!x || !out || T <= 0 || C <= 0) return -1;
+    const int64_t total = (int64_t)T * C * 3;
+    hipLaunchKernelGGL(dpn_im2col_circ3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, T, C, out);
+    return (int)hipGetLastError();
+}
+
+int dpn_embed_assemble(const float* token, int n_tok, const float* emb, int n_emb, const float* pos, const float* te, float* out, void* stream) {
+    if (!token || !emb || !pos || !te || !out || n_tok < 0 || n_emb <= 0) return -1;
+    hipLaunchKernelGGL(dpn_embed_assemble_kernel, dim3(n_tok + n_emb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), token, n_tok, emb, n_emb,
+                       pos, te, out);
     return (int)hipGetLastError();
 }
 

@@ -1373,17 +1373,18 @@ __global__ __launch_bounds__(256) void dpn_sgemm_reduce_kernel(SgemmArgs a, int 
 // Several independent small GEMMs in ONE launch (blockIdx.z = problem), each optionally a sum of up to 3 products
 // (C = sum_t op(A_t) op(B_t)): the three q/k/v projections of an attention layer, or the input- and weight-gradient
 // GEMMs of a linear layer, cost one launch instead of 2-6.  Two k-tiles are kept in flight in registers.
-constexpr int kBatchMaxProblems = 4, kBatchMaxTerms = 3;
+constexpr int kBatchMaxProblems = 20, kBatchMaxTerms = 12, kBatchTermPool = 32;
+struct SgemmTerm {
+    const float* A;
+    const float* B;
+    int lda, ldb, K, pad;
+};
 struct SgemmProblem {
-    const float* A[kBatchMaxTerms];
-    const float* B[kBatchMaxTerms];
-    int lda[kBatchMaxTerms], ldb[kBatchMaxTerms];
     const float* bias;
     float *C, *asum;
-    int M, N, K, ldc, ta, tb, nterms;
     const float* aux;          // epilogue operand [M][ldc] (epi 2, 3)
     float* aux_out;            // pre-activation output [M][ldc] (epi 1, optional)
-    int epi;                   // DPN_EPI_*
+    int M, N, ldc, ta, tb, nterms, term0, epi;
 };
 // exact-erf GELU and its derivative, the formulas of torch's GeluCUDAKernelImpl / GeluBackwardCUDAKernelImpl (approximate='none')
 DEV float gelu_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -1394,6 +1395,7 @@ DEV float gelu_exact_grad(float x) {
 }
 struct SgemmBatch {
     SgemmProblem p[kBatchMaxProblems];
+    SgemmTerm t[kBatchTermPool];          // the accumulated A.B terms of all problems (problem i owns t[term0 .. term0+nterms))
     int n;
 };
 
@@ -1419,27 +1421,32 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     f32x16 acc = (f32x16)0.f;
     float rs = 0.f;
     const bool do_asum = a.asum != nullptr && blockIdx.x == 0;
-    const int ktiles = (a.K + BK - 1) / BK, total = ktiles * a.nterms;
+    int total = 0;
+    for (int t = 0; t < a.nterms; ++t) total += (batch.t[a.term0 + t].K + BK - 1) / BK;
+    const int ktiles0 = (batch.t[a.term0].K + BK - 1) / BK;
     float ra[NL], rb[NL];
-    auto gload = [&](int it) __attribute__((always_inline)) {
-        const int t = it / ktiles, k0 = (it - t * ktiles) * BK;
-        const float* A = a.A[t];
-        const float* B = a.B[t];
-        const int lda = a.lda[t], ldb = a.ldb[t];
+    int lt = 0, lk0 = 0;                     // load cursor: term, k offset inside the term (terms may have different K)
+    auto gload = [&]() __attribute__((always_inline)) {
+        const SgemmTerm& T = batch.t[a.term0 + lt];
+        const float* A = T.A;
+        const float* B = T.B;
+        const int lda = T.lda, ldb = T.ldb, K = T.K, k0 = lk0;
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
             const int e = threadIdx.x + 256 * q;
             {
                 const int kk = a.ta ? (e >> 5) : (e & (BK - 1)), mm = a.ta ? (e & 31) : (e / BK);
                 const int gm = m0 + mm, gk = k0 + kk;
-                ra[q] = (gm < a.M && gk < a.K) ? (a.ta ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
+                ra[q] = (gm < a.M && gk < K) ? (a.ta ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
             }
             {
                 const int kk = a.tb ? (e & (BK - 1)) : (e >> 5), nn = a.tb ? (e / BK) : (e & 31);
                 const int gk = k0 + kk, gn = n0 + nn;
-                rb[q] = (gk < a.K && gn < a.N) ? (a.tb ? B[(int64_t)gn * ldb + gk] : B[(int64_t)gk * ldb + gn]) : 0.f;
+                rb[q] = (gk < K && gn < a.N) ? (a.tb ? B[(int64_t)gn * ldb + gk] : B[(int64_t)gk * ldb + gn]) : 0.f;
             }
         }
+        lk0 += BK;
+        if (lk0 >= K) { lk0 = 0; ++lt; }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -1449,20 +1456,20 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
             Bs[buf][a.tb ? (e & (BK - 1)) : (e >> 5)][a.tb ? (e / BK) : (e & 31)] = rb[q];
         }
     };
-    gload(0);
+    gload();
     lstore(0);
-    if (total > 1) gload(1);
+    if (total > 1) gload();
     __syncthreads();
     for (int it = 0; it < total; ++it) {
         const int buf = it & 1;
         if (it + 1 < total) lstore(buf ^ 1);                      // tile it+1 (loaded during the previous iteration) -> other LDS buffer
-        if (it + 2 < total) gload(it + 2);                        // tile it+2 in flight under the MFMAs
+        if (it + 2 < total) gload();                              // tile it+2 in flight under the MFMAs
 #pragma unroll
         for (int u = 0; u < BK / 8; ++u) {
             const int kk = wave * (BK / 4) + 2 * u + h;
             acc = mfma_f32(As[buf][kk][i], Bs[buf][kk][i], acc);
         }
-        if (do_asum && it < ktiles && threadIdx.x < BM) {
+        if (do_asum && it < ktiles0 && threadIdx.x < BM) {
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) rs += As[buf][kk][threadIdx.x];
         }
@@ -1739,14 +1746,21 @@ int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream
     if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems) return -1;
     SgemmBatch b;
     b.n = n_problems;
-    int gx = 0, gy = 0;
+    int gx = 0, gy = 0, pool = 0;
     for (int i = 0; i < n_problems; ++i) {
         const DpnGemmProblem& q = problems[i];
-        if (q.nterms < 1 || q.nterms > kBatchMaxTerms || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0) return -1;
+        if (q.nterms < 1 || q.nterms > kBatchMaxTerms || pool + q.nterms > kBatchTermPool || !q.C || q.M <= 0 || q.N <= 0) return -1;
         if (q.epi < 0 || q.epi > DPN_EPI_ADD || ((q.epi == DPN_EPI_MUL_GELU_GRAD || q.epi == DPN_EPI_ADD) && !q.aux)) return -1;
+        if (q.asum && q.nterms != 1) return -1;                       // row sums of A are defined for a single term
         SgemmProblem& p = b.p[i];
-        for (int t = 0; t < kBatchMaxTerms; ++t) { p.A[t] = q.A[t]; p.B[t] = q.B[t]; p.lda[t] = q.lda[t]; p.ldb[t] = q.ldb[t]; }
-        p.bias = q.bias; p.C = q.C; p.asum = q.asum; p.aux = q.aux; p.aux_out = q.aux_out; p.epi = q.epi; p.M = q.M; p.N = q.N; p.K = q.K; p.ldc = q.ldc; p.ta = q.ta; p.tb = q.tb; p.nterms = q.nterms;
+        p.term0 = pool;
+        for (int t = 0; t < q.nterms; ++t) {
+            const int kt = q.k_term[t] > 0 ? q.k_term[t] : q.K;
+            if (!q.A[t] || !q.B[t] || kt <= 0) return -1;
+            b.t[pool++] = SgemmTerm{q.A[t], q.B[t], q.lda[t], q.ldb[t], kt, 0};
+        }
+        p.bias = q.bias; p.C = q.C; p.asum = q.asum; p.aux = q.aux; p.aux_out = q.aux_out; p.epi = q.epi;
+        p.M = q.M; p.N = q.N; p.ldc = q.ldc; p.ta = q.ta; p.tb = q.tb; p.nterms = q.nterms;
         gx = gx > (q.N + 31) / 32 ? gx : (q.N + 31) / 32;
         gy = gy > (q.M + 31) / 32 ? gy : (q.M + 31) / 32;
     }

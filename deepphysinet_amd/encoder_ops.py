@@ -186,3 +186,137 @@ def encoder_layer_fused(x, layer):
                                 layer.conv1.weight.squeeze(-1), layer.conv1.bias, layer.conv2.weight.squeeze(-1), layer.conv2.bias,
                                 layer.norm2.weight, layer.norm2.bias)
     return out.view(1, -1, 256)              # views, not x[0]: a select's backward is a zero fill + a copy
+
+
+def lead_time_pe(h, freq_bands):
+    """SineCosPE(1, include_input=False) of the scalar lead time h (a device tensor with one element) -> [2 * N_freqs]."""
+    out = torch.empty(2 * freq_bands.numel(), dtype=torch.float32, device=h.device)
+    L.check(L.load().dpn_lead_pe(_p(_c(h.detach().float())), _p(_c(freq_bands)), freq_bands.numel(), _p(out), None, 0, None, _s()), 'dpn_lead_pe')
+    return out
+
+
+class _DataEmbeddingFn(torch.autograd.Function):
+    """DataEmbedding + learnable tokens (model/embed.py:60-64, transformer_net.py:124-126) for one field sample:
+    x0 = cat(token, circular_conv3(field)) + pos + time_embedding(h).  Five launches forward (im2col, two-pass long-K GEMM, lead-time
+    PE, assemble); backward = one GEMM for the conv weight (already in the parameter's [256][C][3] layout) with its bias sum."""
+
+    @staticmethod
+    def forward(ctx, field, conv_w, conv_b, token, pos, h, freq_bands):
+        from .linear import _sgemm_splitk
+        lib = L.load()
+        x = _c(field.detach().reshape(field.shape[-2], field.shape[-1]).float())      # [T, C]
+        T, C = x.shape
+        D = conv_w.shape[0]
+        dev = x.device
+        xu = torch.empty((T, 3 * C), dtype=torch.float32, device=dev)
+        L.check(lib.dpn_im2col_circ3(_p(x), T, C, _p(xu), _s()), 'dpn_im2col_circ3')
+        w2 = _c(conv_w).view(D, 3 * C)
+        emb = torch.empty((T, D), dtype=torch.float32, device=dev)
+        _sgemm_splitk(0, 1, T, D, 3 * C, xu, 3 * C, w2, 3 * C, emb, D, bias=conv_b)
+        te = lead_time_pe(h, freq_bands)
+        n_tok = token.shape[-2]
+        out = torch.empty((n_tok + T, D), dtype=torch.float32, device=dev)
+        L.check(lib.dpn_embed_assemble(_p(_c(token)), n_tok, _p(emb), T, _p(_c(pos)), _p(te), _p(out), _s()), 'dpn_embed_assemble')
+        ctx.save_for_backward(xu)
+        ctx.n_tok, ctx.w_shape, ctx.tok_shape = n_tok, conv_w.shape, token.shape
+        return out.view(1, n_tok + T, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .linear import _launch, _problem
+        (xu,) = ctx.saved_tensors
+        T, K3 = xu.shape
+        D = ctx.w_shape[0]
+        g2 = _c(g.reshape(-1, D))
+        g_emb = g2[ctx.n_tok:]                                   # contiguous row range
+        dw = torch.empty((D, K3), dtype=torch.float32, device=g.device)
+        db = torch.empty((D,), dtype=torch.float32, device=g.device)
+        _launch([_problem(D, K3, T, [(g_emb, D, xu, K3)], dw, K3, 1, 0, asum=db)])
+        return None, dw.view(ctx.w_shape), db, g2[:ctx.n_tok].view(ctx.tok_shape), None, None, None
+
+
+def data_embedding_fused(field, emb_module, token, h):
+    """-> [1, n_tok + T, 256] or None when the module does not fit the kernels (then the caller takes the per-op path)."""
+    conv = emb_module.value_embedding.tokenConv
+    if not (field.is_cuda and field.dim() == 3 and field.shape[0] == 1 and conv.weight.shape[0] == 256 and conv.kernel_size == (3,)
+            and conv.bias is not None and token.shape[-1] == 256 and h.numel() == 1):
+        return None
+    n = token.shape[-2] + field.shape[1]
+    pos = emb_module.position_embedding.pe[0, :n]
+    return _DataEmbeddingFn.apply(field, conv.weight, conv.bias, token, pos, h, emb_module.time_embending.freq_bands)
+
+
+HEAD_WIDTHS = (193,) * 6 + (257,) * 6                  # coord_input_fc (w1 | b1) of the six nets, then coord_hidden_fc (w2 | b2)
+HEADS_COLS = sum(HEAD_WIDTHS)
+
+
+class _HeadsFn(torch.autograd.Function):
+    """The twelve hyper-network heads and the six lead-time embeddings of a PhysicsNet (model/variable_net.py:57-65,75-78) as ONE
+    launch forward (18 GEMM problems reading the encoder output transposed in place) and ONE launch backward (the input gradient as a
+    12-term problem, twelve weight gradients with their bias sums, six outer products).
+    inputs: meta [1, L, 256] (tokens 0..255 are used), pe_h [192], 12 head weights, 12 head biases, 6 fore_h_fc weights, 6 biases
+    -> heads [256, 2700] = [w1b1 of nets 0..5 | w2b2 of nets 0..5] per hidden channel, evec [6, 256]."""
+
+    @staticmethod
+    def forward(ctx, meta, pe_h, *wb):
+        from .linear import _launch, _problem
+        hw, hb, fw, fb = wb[0:12], wb[12:24], wb[24:30], wb[30:36]
+        hw = [_c(w) for w in hw]
+        fw = [_c(w) for w in fw]
+        m2 = _c(meta.reshape(meta.shape[-2], 256))               # [L tokens][256 channels]
+        dev = m2.device
+        heads = torch.empty((256, HEADS_COLS), dtype=torch.float32, device=dev)
+        evec = torch.empty((6, 256), dtype=torch.float32, device=dev)
+        problems, off = [], 0
+        for w, b in zip(hw, hb):                                 # heads[c][off + j] = sum_tok meta[tok][c] W[j][tok] + b[j]
+            n_k = w.shape[0]
+            q = _problem(256, n_k, 256, [(m2, 256, w, 256)], heads, HEADS_COLS, 1, 1, bias=b)
+            q.C = heads.data_ptr() + off * 4
+            problems.append(q)
+            off += n_k
+        for k, (w, b) in enumerate(zip(fw, fb)):                 # evec[k] = fore_h_fc_k(pe_h)
+            q = _problem(1, 256, 192, [(pe_h, 192, w, 192)], evec, 256, 0, 1, bias=b)
+            q.C = evec.data_ptr() + k * 256 * 4
+            problems.append(q)
+        _launch(problems)
+        ctx.save_for_backward(m2, pe_h, *hw)
+        ctx.meta_shape = meta.shape
+        return heads, evec
+
+    @staticmethod
+    def backward(ctx, g_heads, g_evec):
+        from .linear import _launch, _problem
+        m2, pe_h, *hw = ctx.saved_tensors
+        dev = m2.device
+        gh, ge = _c(g_heads), _c(g_evec)
+        d_meta = torch.zeros(m2.shape, dtype=torch.float32, device=dev)          # tokens >= 256 feed nothing
+        terms, off = [], 0
+        offs = []
+        for w in hw:                                             # d_meta[tok][c] = sum_k sum_j W_k[j][tok] g[c][off_k + j]
+            n_k = w.shape[0]
+            terms.append((w, 256, gh, HEADS_COLS, n_k, off))
+            offs.append(off)
+            off += n_k
+        q0 = _problem(256, 256, 256, [t[:5] for t in terms], d_meta, 256, 1, 1)
+        for i, t in enumerate(terms):
+            q0.B[i] = gh.data_ptr() + t[5] * 4
+        problems = [q0]
+        dws, dbs = [], []
+        for w, o in zip(hw, offs):                               # dW_k[j][tok] = sum_c g[c][off + j] meta[tok][c] ; db_k[j] = sum_c g[c][off + j]
+            n_k = w.shape[0]
+            dw = torch.empty((n_k, 256), dtype=torch.float32, device=dev)
+            db = torch.empty((n_k,), dtype=torch.float32, device=dev)
+            q = _problem(n_k, 256, 256, [(gh, HEADS_COLS, m2, 256)], dw, 256, 1, 1, asum=db)
+            q.A[0] = gh.data_ptr() + o * 4
+            problems.append(q)
+            dws.append(dw)
+            dbs.append(db)
+        dfw = []
+        for k in range(6):                                       # d fore_h_fc_k.weight = g_evec[k] (outer) pe_h ; bias gradient = g_evec[k]
+            dw = torch.empty((256, 192), dtype=torch.float32, device=dev)
+            q = _problem(256, 192, 1, [(ge, 256, pe_h, 192)], dw, 192, 1, 0)
+            q.A[0] = ge.data_ptr() + k * 256 * 4
+            problems.append(q)
+            dfw.append(dw)
+        _launch(problems)
+        return (d_meta.view(ctx.meta_shape), None, *dws, *dbs, *dfw, *[ge[k] for k in range(6)])

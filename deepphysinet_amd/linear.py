@@ -19,8 +19,10 @@ def _p(t):
 def _problem(M, N, K, terms, C, ldc, ta, tb, bias=None, asum=None, epi=0, aux=None, aux_out=None):
     q = L.DpnGemmProblem()
     q.epi, q.aux, q.aux_out = epi, _p(aux), _p(aux_out)
-    for i, (A, lda, B, ldb) in enumerate(terms):
+    for i, term in enumerate(terms):                 # (A, lda, B, ldb) or (A, lda, B, ldb, K_t) when the terms reduce over different lengths
+        A, lda, B, ldb = term[:4]
         q.A[i], q.lda[i], q.B[i], q.ldb[i] = A.data_ptr(), lda, B.data_ptr(), ldb
+        q.k_term[i] = term[4] if len(term) > 4 else 0
     q.bias, q.C, q.asum = _p(bias), C.data_ptr(), _p(asum)
     q.M, q.N, q.K, q.ldc, q.ta, q.tb, q.nterms = M, N, K, ldc, ta, tb, len(terms)
     return q
@@ -93,8 +95,7 @@ class _MultiLinearFn(torch.autograd.Function):
             problems.append(_problem(N, K, M, [(g, N, x2, K)], gw, K, 1, 0, asum=gb))                        # gw = g^T x ; gb = sum_m g
             gws.append(gw)
             gbs.append(gb)
-        for i in range(0, len(problems), 4):
-            _launch(problems[i:i + 4])
+        _launch(problems)
         return (gx.reshape(ctx.x_shape) if gx is not None else None, *gws, *gbs)
 
 

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..encoder_ops import add_layer_norm, attention, encoder_layer_fused
+from ..encoder_ops import add_layer_norm, attention, data_embedding_fused, encoder_layer_fused
 from ..linear import linear, linear_multi
 from ..utils.position_encoding import SineCosPE
 
@@ -60,6 +60,9 @@ class DataEmbedding(nn.Module):
         self.time_embending = SineCosPE(input_dim=1, include_input=False, N_freqs=d_model // 2)   # (sic) embed.py:58
 
     def forward(self, x, forecast_h, learnable_token):
+        fused = data_embedding_fused(x, self, learnable_token, forecast_h)
+        if fused is not None:
+            return fused
         x = torch.cat([learnable_token, self.value_embedding(x)], dim=1)
         return x + self.position_embedding(x) + self.time_embending(forecast_h)
 

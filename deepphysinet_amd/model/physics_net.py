@@ -58,14 +58,22 @@ class PhysicsNet(nn.Module):
         (variable_net.py:75-78) are one GEMV batch."""
         meta_out = self.encode_field(field_x, forecast_h, use_cache=use_cache)
         nets = self.nets_in_output_order()
-        m_t = torch.squeeze(meta_out, dim=0)[0:nets[0].token_num].T                    # [256 channels, 256 tokens]
-        w_cat = torch.cat([n.coord_input_fc.weight for n in nets] + [n.coord_hidden_fc.weight for n in nets], dim=0)
-        b_cat = torch.cat([n.coord_input_fc.bias for n in nets] + [n.coord_hidden_fc.bias for n in nets], dim=0)
-        heads = linear(m_t, w_cat, b_cat)                                              # [256, 2700]
-        pe_h = nets[0].pe_fore_h(forecast_h.squeeze(dim=-1))                           # [1, 192] (same encoder in every net)
-        wf = torch.cat([n.fore_h_fc.weight for n in nets], dim=0)                      # [6*256, 192]
-        bf = torch.cat([n.fore_h_fc.bias for n in nets], dim=0)
-        evec = linear(pe_h, wf, bf).view(6, 256)
+        if meta_out.is_cuda and meta_out.shape[0] == 1:
+            from ..encoder_ops import _HeadsFn, lead_time_pe
+            pe_h = lead_time_pe(forecast_h, nets[0].pe_fore_h.freq_bands)              # [192] (same encoder in every net)
+            heads, evec = _HeadsFn.apply(meta_out, pe_h,
+                                         *[n.coord_input_fc.weight for n in nets], *[n.coord_hidden_fc.weight for n in nets],
+                                         *[n.coord_input_fc.bias for n in nets], *[n.coord_hidden_fc.bias for n in nets],
+                                         *[n.fore_h_fc.weight for n in nets], *[n.fore_h_fc.bias for n in nets])
+        else:
+            m_t = torch.squeeze(meta_out, dim=0)[0:nets[0].token_num].T                # [256 channels, 256 tokens]
+            w_cat = torch.cat([n.coord_input_fc.weight for n in nets] + [n.coord_hidden_fc.weight for n in nets], dim=0)
+            b_cat = torch.cat([n.coord_input_fc.bias for n in nets] + [n.coord_hidden_fc.bias for n in nets], dim=0)
+            heads = linear(m_t, w_cat, b_cat)                                          # [256, 2700]
+            pe_h = nets[0].pe_fore_h(forecast_h.squeeze(dim=-1))                       # [1, 192]
+            wf = torch.cat([n.fore_h_fc.weight for n in nets], dim=0)                  # [6*256, 192]
+            bf = torch.cat([n.fore_h_fc.bias for n in nets], dim=0)
+            evec = linear(pe_h, wf, bf).view(6, 256)
         statics = [p for n in nets for p in n.static_params()]
         return heads, evec, statics
 

@@ -133,15 +133,19 @@ int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, flo
 int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
               const float* bias, float* asum, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Up to 4 independent small fp32 GEMMs in one launch; each C[M][N] = sum_{t<nterms} op(A_t)[M][K] op(B_t)[K][N] (+ bias[N]),
- * asum as in dpn_sgemm.  Used for the q/k/v projections (attn.py:183-185) and for the paired input-/weight-gradient GEMMs
- * of every encoder linear. */
+/* Up to 20 independent small fp32 GEMMs in one launch (exact-fp32 MFMA, fixed reduction order); each
+ * C[M][N] = epilogue(sum_{t<nterms} op(A_t)[M][K_t] op(B_t)[K_t][N] + bias[N]); asum as in dpn_sgemm (single-term problems only).
+ * Used for the q/k/v projections (attn.py:183-185), the paired input-/weight-gradient GEMMs of every encoder linear, and the
+ * twelve hyper-network heads + six lead-time embeddings of the VariableNets (variable_net.py:59-65,75-78) and their backward. */
 #define DPN_EPI_NONE 0
 #define DPN_EPI_GELU 1            /* C = gelu(v) (exact erf, transformer_net.py:26,41); aux_out (optional) receives v                    */
 #define DPN_EPI_MUL_GELU_GRAD 2   /* C = v * gelu'(aux): backward of the activation folded into the GEMM that feeds it                 */
 #define DPN_EPI_ADD 3             /* C = v + aux: the residual-branch gradient joins the input gradient without a separate add kernel  */
+#define DPN_GEMM_MAX_TERMS 12      /* per problem */
+#define DPN_GEMM_MAX_PROBLEMS 20   /* per launch; at most 32 terms per launch in total */
 typedef struct DpnGemmProblem {
-    const float* A[3]; const float* B[3]; int32_t lda[3], ldb[3];
+    const float* A[DPN_GEMM_MAX_TERMS]; const float* B[DPN_GEMM_MAX_TERMS]; int32_t lda[DPN_GEMM_MAX_TERMS], ldb[DPN_GEMM_MAX_TERMS];
+    int32_t k_term[DPN_GEMM_MAX_TERMS];   /* reduction length of term t; 0 = K */
     const float* bias; float* C; float* asum;
     int32_t M, N, K, ldc, ta, tb, nterms;
     const float* aux; float* aux_out;   /* [M][ldc], see DPN_EPI_* */
@@ -162,6 +166,16 @@ int dpn_add_ln_fwd(const float* x, const float* r, const float* gamma, const flo
                    void* stream);
 int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const float* gamma, int rows, float* gx, float* dgamma, float* dbeta,
                    float* scratch /* ceil(rows/4) * 512 floats */, void* stream);
+
+/* Data embedding of the encoder (model/embed.py:36-64, transformer_net.py:124-126), d_model = 256:
+ *   dpn_lead_pe        SineCosPE of the scalar lead time for one or two frequency tables: out[2f] = sin(h f), out[2f+1] = cos(h f)
+ *                      (encoder time embedding, N_freqs = 128, embed.py:58; VariableNet lead-time PE, N_freqs = 96, variable_net.py:46);
+ *   dpn_im2col_circ3   out[T][3C], out[t][3c + tap] = x[(t + tap - 1) mod T][c]: the circular k=3 TokenEmbedding conv becomes
+ *                      out . W^T with the Conv1d weight [256][C][3] read in place;
+ *   dpn_embed_assemble out[n_tok + n_emb][256] = cat(learnable_token, value_embedding) + positional table + lead-time embedding. */
+int dpn_lead_pe(const float* h_dev, const float* freqs_a, int n_a, float* out_a, const float* freqs_b, int n_b, float* out_b, void* stream);
+int dpn_im2col_circ3(const float* x, int T, int C, float* out, void* stream);
+int dpn_embed_assemble(const float* token, int n_tok, const float* emb, int n_emb, const float* pos, const float* te, float* out, void* stream);
 
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step (interface_physics.py:514-515; cfg:151-155: L2-in-gradient weight decay)
  * over a list of fp32 tensors.  The pointer arrays and `numel` are HOST arrays of length n_tensors (device pointers inside);
