@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
     loss.backward()
     GradientAllReduce(bucket_mb=0.0001)(list(lin.parameters()))     # tiny buckets: exercises the multi-bucket path
     g = torch.cat([p.grad.reshape(-1) for p in lin.parameters()])
-    q.put((rank, w0, g))
+    q.put((rank, w0.tolist(), g.tolist()))      # by value: a tensor would travel as a shared-memory handle owned by this (exiting) process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,7 +50,7 @@ def test_gradient_allreduce_equals_union_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, w_a, g_a), (_, w_b, g_b) = out
+    (_, w_a, g_a), (_, w_b, g_b) = [(r, torch.tensor(w), torch.tensor(g)) for r, w, g in out]
     assert torch.equal(w_a, w_b)                    # broadcast made the replicas identical
     assert torch.allclose(g_a, g_b, rtol=0, atol=0)
     # reference: single process, whole batch (equal shard sizes -> mean of shard means == batch mean)
