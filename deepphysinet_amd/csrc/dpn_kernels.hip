@@ -1403,17 +1403,20 @@ struct SgemmBatch {
 typedef float f32x1;
 DEV f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
+template <int BK, int NBUF>
 __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     // one workgroup = one 32x32 output tile.  K is walked in 32-wide tiles that are loaded COALESCED (the fast index follows each
     // operand's contiguous dimension) into double-buffered LDS, two tiles ahead in registers; inside a tile the four waves take
     // BK/4 k-values each (v_mfma_f32_32x32x2_f32, exact fp32) and their partial tiles are summed through LDS in a fixed order.
-    constexpr int BM = 32, BN = 32, BK = 128, NL = BK * 32 / 256;   // NL loads per operand per thread per k-tile
+    // <128, 2>: double-buffered LDS, two k-tiles in flight (long / multi-term reductions).  <256, 1>: the whole K of a 256-wide encoder
+    // GEMM is ONE tile -- one LDS stage, one barrier pair, 32 loads per operand in flight (used when every problem is a single tile).
+    constexpr int BM = 32, BN = 32, NL = BK * 32 / 256;   // NL loads per operand per thread per k-tile
     const SgemmProblem& a = batch.p[blockIdx.z];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= a.M || n0 >= a.N) return;
     // 66 KB of LDS: two workgroups per CU.  The split-K partial tiles (16.5 KB) reuse the A staging buffers after the last k-tile.
-    __shared__ float As[2][BK][BM + 1];
-    __shared__ float Bs[2][BK][BN + 1];
+    __shared__ float As[NBUF][BK][BM + 1];
+    __shared__ float Bs[NBUF][BK][BN + 1];
     float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(&As[0][0][0]);
     static_assert(sizeof(As) >= 4 * 32 * 33 * sizeof(float), "partial tiles must fit in the A staging buffers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1456,24 +1459,43 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
             Bs[buf][a.tb ? (e & (BK - 1)) : (e >> 5)][a.tb ? (e / BK) : (e & 31)] = rb[q];
         }
     };
-    gload();
-    lstore(0);
-    if (total > 1) gload();
-    __syncthreads();
-    for (int it = 0; it < total; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < total) lstore(buf ^ 1);                      // tile it+1 (loaded during the previous iteration) -> other LDS buffer
-        if (it + 2 < total) gload();                              // tile it+2 in flight under the MFMAs
-#pragma unroll
-        for (int u = 0; u < BK / 8; ++u) {
-            const int kk = wave * (BK / 4) + 2 * u + h;
-            acc = mfma_f32(As[buf][kk][i], Bs[buf][kk][i], acc);
-        }
-        if (do_asum && it < ktiles0 && threadIdx.x < BM) {
-#pragma unroll
-            for (int kk = 0; kk < BK; ++kk) rs += As[buf][kk][threadIdx.x];
-        }
+    if constexpr (NBUF == 2) {
+        gload();
+        lstore(0);
+        if (total > 1) gload();
         __syncthreads();
+        for (int it = 0; it < total; ++it) {
+            const int buf = it & 1;
+            if (it + 1 < total) lstore(buf ^ 1);                  // tile it+1 (loaded during the previous iteration) -> other LDS buffer
+            if (it + 2 < total) gload();                          // tile it+2 in flight under the MFMAs
+#pragma unroll
+            for (int u = 0; u < BK / 8; ++u) {
+                const int kk = wave * (BK / 4) + 2 * u + h;
+                acc = mfma_f32(As[buf][kk][i], Bs[buf][kk][i], acc);
+            }
+            if (do_asum && it < ktiles0 && threadIdx.x < BM) {
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) rs += As[buf][kk][threadIdx.x];
+            }
+            __syncthreads();
+        }
+    } else {
+        gload();
+        for (int it = 0; it < total; ++it) {
+            lstore(0);
+            __syncthreads();
+            if (it + 1 < total) gload();                          // next tile in flight under the MFMAs
+#pragma unroll 8
+            for (int u = 0; u < BK / 8; ++u) {
+                const int kk = wave * (BK / 4) + 2 * u + h;
+                acc = mfma_f32(As[0][kk][i], Bs[0][kk][i], acc);
+            }
+            if (do_asum && it < ktiles0 && threadIdx.x < BM) {
+#pragma unroll 8
+                for (int kk = 0; kk < BK; ++kk) rs += As[0][kk][threadIdx.x];
+            }
+            __syncthreads();
+        }
     }
     // ---- fixed-order reduction over the four waves
 #pragma unroll
@@ -1764,7 +1786,11 @@ int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream
         gx = gx > (q.N + 31) / 32 ? gx : (q.N + 31) / 32;
         gy = gy > (q.M + 31) / 32 ? gy : (q.M + 31) / 32;
     }
-    hipLaunchKernelGGL(dpn_sgemm_batch_kernel, dim3(gx, gy, n_problems), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    bool single_tile = true;
+    for (int i = 0; i < pool; ++i) single_tile = single_tile && b.t[i].K <= 256;
+    for (int i = 0; i < n_problems; ++i) single_tile = single_tile && b.p[i].nterms == 1;
+    if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1>), dim3(gx, gy, n_problems), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<128, 2>), dim3(gx, gy, n_problems), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
     return ck(hipGetLastError());
 }
 
