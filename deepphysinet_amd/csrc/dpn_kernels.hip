@@ -1536,7 +1536,9 @@ DEV int adam_find(const AdamTable& t, int blk) {
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.chunk_start[mid] <= blk) lo = mid; else hi = mid - 1; }
     return lo;
 }
-__global__ __launch_bounds__(256) void dpn_gradnorm_kernel(AdamTable t, double* sumsq, int* step, int bump_step) {
+__global__ __launch_bounds__(256) void dpn_gradnorm_kernel(AdamTable t, double* partial, int* step, int bump_step) {
+    // one fp64 partial per block (no atomics: 2.7k serialised fp64 atomics on one address cost more than reading the gradients);
+    // dpn_gradnorm_reduce_kernel adds them in a fixed order -> the clip coefficient is run-to-run deterministic
     if (bump_step && blockIdx.x == 0 && threadIdx.x == 0) *step += 1;       // device-side step counter: graph replays advance it
     const int ti = adam_find(t, blockIdx.x);
     const int base = (blockIdx.x - t.chunk_start[ti]) * kAdamChunk;
@@ -1559,7 +1561,17 @@ __global__ __launch_bounds__(256) void dpn_gradnorm_kernel(AdamTable t, double* 
     __shared__ double red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void dpn_gradnorm_reduce_kernel(const double* partial, int n, double* sumsq) {
+    double d = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) d += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) *sumsq = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ __launch_bounds__(256) void dpn_adam_kernel(AdamTable t, const double* sumsq, const int* step, float lr, float b1, float b2, float eps,
                                                        float wd, float max_norm, float* out_norm) {
@@ -1794,13 +1806,22 @@ int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream
     return ck(hipGetLastError());
 }
 
+int64_t dpn_clip_adam_scratch_doubles(int n_tensors, const int64_t* numel) {
+    if (n_tensors <= 0 || !numel) return -1;
+    int64_t chunks = 0;
+    for (int i = 0; i < n_tensors; ++i) chunks += (numel[i] + kAdamChunk - 1) / kAdamChunk;
+    return 1 + chunks;
+}
+
 int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                  const int64_t* numel, double* sumsq_dev, int* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  const int64_t* numel, double* scratch_dev, int* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float max_norm, float* out_norm_dev, void* stream) {
-    if (n_tensors <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !sumsq_dev || !step_dev) return -1;
+    if (n_tensors <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !scratch_dev || !step_dev) return -1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(sumsq_dev, 0, sizeof(double), s) != hipSuccess) return -2;
+    double* sumsq = scratch_dev;                 // [0]: sum of squares of all gradients; [1 ..]: one partial per 2048-element chunk
+    double* partial = scratch_dev + 1;
     for (int pass = 0; pass < 2; ++pass) {
+        int base_chunk = 0;
         for (int t0 = 0; t0 < n_tensors; t0 += kAdamMaxTensors) {
             AdamTable t;
             t.n = (n_tensors - t0 < kAdamMaxTensors) ? n_tensors - t0 : kAdamMaxTensors;
@@ -1813,10 +1834,12 @@ int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads
                 chunks += (t.numel[i] + kAdamChunk - 1) / kAdamChunk;
             }
             t.chunk_start[t.n] = chunks;
-            if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel, dim3(chunks), dim3(256), 0, s, t, sumsq_dev, step_dev, t0 == 0 ? 1 : 0);
-            else hipLaunchKernelGGL(dpn_adam_kernel, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq_dev, (const int*)step_dev, lr, beta1,
+            if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
+            else hipLaunchKernelGGL(dpn_adam_kernel, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr, beta1,
                                     beta2, eps, weight_decay, max_norm, out_norm_dev);
+            base_chunk += chunks;
         }
+        if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, base_chunk, sumsq);
     }
     return ck(hipGetLastError());
 }

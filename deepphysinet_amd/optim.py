@@ -1,7 +1,7 @@
 """Fused clip_grad_norm_ + Adam on the HIP library (reference: interface_physics.py:514-515, cfg:151-155).
 
 Same arithmetic as `torch.nn.utils.clip_grad_norm_(params, max_norm)` followed by `torch.optim.Adam(lr, betas, eps,
-weight_decay)` (weight decay added to the gradient), but four kernel launches for the whole model instead of ~60, and
+weight_decay)` (weight decay added to the gradient), but seven kernel launches for the whole model instead of ~60, and
 hipGraph-capturable (the step counter lives on the device).
 """
 import ctypes
@@ -22,10 +22,11 @@ class FusedClipAdam:
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         n = len(self.params)
         self._numel = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
+        # [0] = sum of squares of all gradients, then one fp64 partial per 2048-element chunk (fixed-order reduction, no atomics)
+        self._sumsq = torch.zeros(int(L.load().dpn_clip_adam_scratch_doubles(n, self._numel)), dtype=torch.float64, device=dev)
         self._p = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
         self._m = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self.exp_avg])
         self._v = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self.exp_avg_sq])

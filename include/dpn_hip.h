@@ -179,10 +179,13 @@ int dpn_embed_assemble(const float* token, int n_tok, const float* emb, int n_em
 
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step (interface_physics.py:514-515; cfg:151-155: L2-in-gradient weight decay)
  * over a list of fp32 tensors.  The pointer arrays and `numel` are HOST arrays of length n_tensors (device pointers inside);
- * sumsq_dev (double), step_dev (int, the Adam step counter, incremented on the device) and out_norm_dev (float, may be NULL)
- * are device scalars.  Four launches for the 155 tensors of a PhysicsNet. */
+ * scratch_dev: dpn_clip_adam_scratch_doubles(n_tensors, numel) doubles on the device ([0] receives the sum of squares of all
+ * gradients, the rest are per-block partials added in a fixed order: the norm is deterministic and there are no atomics);
+ * step_dev (int, the Adam step counter, incremented on the device) and out_norm_dev (float, may be NULL) are device scalars.
+ * Seven launches for the 155 tensors of a PhysicsNet. */
+int64_t dpn_clip_adam_scratch_doubles(int n_tensors, const int64_t* numel);
 int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                  const int64_t* numel, double* sumsq_dev, int* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  const int64_t* numel, double* scratch_dev, int* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float max_norm, float* out_norm_dev, void* stream);
 
 /* ---------------------------------------------------------------- collocation sampler + full-grid gather

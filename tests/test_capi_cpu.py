@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
     from deepphysinet_amd import _lib
     lib = _lib.load()
     header = open(os.path.join(ROOT, 'include', 'dpn_hip.h')).read()
-    declared = set(re.findall(r'^\s*int\s+(dpn_\w+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^\s*(?:int|int64_t)\s+(dpn_\w+)\s*\(', header, flags=re.M))
     assert len(declared) >= 12
     for name in declared:
         assert hasattr(lib, name), name
