@@ -82,7 +82,7 @@ EXPORTS = {
                               c_float, c_float, c_void_p, c_void_p]),
     'dpn_lead_pe': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'dpn_im2col_circ3': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    'dpn_embed_assemble': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_embed_assemble': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_sample_points': (c_int, [POINTER(DpnSampler), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_uint64,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_grid_maps': (c_int, [c_void_p, c_int, c_int, POINTER(DpnPhysics), c_int, c_void_p, c_void_p]),

@@ -305,11 +305,19 @@ __global__ __launch_bounds__(256) void dpn_im2col_circ3_kernel(const float* x, i
     ts = ts < 0 ? ts + T : (ts >= T ? ts - T : ts);
     out[i] = x[(int64_t)ts * C + c];
 }
-// x0 = cat(learnable_token, value_embedding) + positional table + lead-time embedding (embed.py:60-64, transformer_net.py:124-126)
-__global__ __launch_bounds__(256) void dpn_embed_assemble_kernel(const float* token, int n_tok, const float* emb, int n_emb, const float* pos,
-                                                                  const float* te, float* out) {
+// x0 = cat(learnable_token, value_embedding) + positional table + lead-time embedding (embed.py:60-64, transformer_net.py:124-126).
+// The value embedding arrives as n_parts split-K partial products [n_parts][n_emb][256] (added here in a fixed order) plus the conv bias.
+__global__ __launch_bounds__(256) void dpn_embed_assemble_kernel(const float* token, int n_tok, const float* emb_parts, int n_parts, int n_emb,
+                                                                  const float* bias, const float* pos, const float* te, float* out) {
     const int row = blockIdx.x, c = threadIdx.x;
-    const float v = row < n_tok ? token[(int64_t)row * kD + c] : emb[(int64_t)(row - n_tok) * kD + c];
+    float v;
+    if (row < n_tok) v = token[(int64_t)row * kD + c];
+    else {
+        const int64_t o = (int64_t)(row - n_tok) * kD + c;
+        v = emb_parts[o];
+        for (int p = 1; p < n_parts; ++p) v += emb_parts[(int64_t)p * n_emb * kD + o];
+        v += bias ? bias[c] : 0.f;
+    }
     out[(int64_t)row * kD + c] = (v + pos[(int64_t)row * kD + c]) + te[c];
 }
 
@@ -383,10 +391,11 @@ int dpn_im2col_circ3(const float* x, int T, int C, float* out, void* stream) {
     return (int)hipGetLastError();
 }
 
-int dpn_embed_assemble(const float* token, int n_tok, const float* emb, int n_emb, const float* pos, const float* te, float* out, void* stream) {
-    if (!token || !emb || !pos || !te || !out || n_tok < 0 || n_emb <= 0) return -1;
-    hipLaunchKernelGGL(dpn_embed_assemble_kernel, dim3(n_tok + n_emb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), token, n_tok, emb, n_emb,
-                       pos, te, out);
+int dpn_embed_assemble(const float* token, int n_tok, const float* emb_parts, int n_parts, int n_emb, const float* bias, const float* pos,
+                       const float* te, float* out, void* stream) {
+    if (!token || !emb_parts || !pos || !te || !out || n_tok < 0 || n_emb <= 0 || n_parts <= 0) return -1;
+    hipLaunchKernelGGL(dpn_embed_assemble_kernel, dim3(n_tok + n_emb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), token, n_tok, emb_parts,
+                       n_parts, n_emb, bias, pos, te, out);
     return (int)hipGetLastError();
 }
 

@@ -197,12 +197,12 @@ def lead_time_pe(h, freq_bands):
 
 class _DataEmbeddingFn(torch.autograd.Function):
     """DataEmbedding + learnable tokens (model/embed.py:60-64, transformer_net.py:124-126) for one field sample:
-    x0 = cat(token, circular_conv3(field)) + pos + time_embedding(h).  Five launches forward (im2col, two-pass long-K GEMM, lead-time
-    PE, assemble); backward = one GEMM for the conv weight (already in the parameter's [256][C][3] layout) with its bias sum."""
+    x0 = cat(token, circular_conv3(field)) + pos + time_embedding(h).  Four launches forward (im2col, one 16-way split-K MFMA GEMM launch, lead-time
+    PE, assemble + split reduction); backward = one GEMM for the conv weight (already in the parameter's [256][C][3] layout) with its bias sum."""
 
     @staticmethod
     def forward(ctx, field, conv_w, conv_b, token, pos, h, freq_bands):
-        from .linear import _sgemm_splitk
+        from .linear import _launch, _problem
         lib = L.load()
         x = _c(field.detach().reshape(field.shape[-2], field.shape[-1]).float())      # [T, C]
         T, C = x.shape
@@ -211,12 +211,23 @@ class _DataEmbeddingFn(torch.autograd.Function):
         xu = torch.empty((T, 3 * C), dtype=torch.float32, device=dev)
         L.check(lib.dpn_im2col_circ3(_p(x), T, C, _p(xu), _s()), 'dpn_im2col_circ3')
         w2 = _c(conv_w).view(D, 3 * C)
-        emb = torch.empty((T, D), dtype=torch.float32, device=dev)
-        _sgemm_splitk(0, 1, T, D, 3 * C, xu, 3 * C, w2, 3 * C, emb, D, bias=conv_b)
+        # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one MFMA launch; their partial products are
+        # added (fixed order) together with the bias by the assemble kernel
+        K3, parts = 3 * C, 16
+        ks = (K3 + parts - 1) // parts
+        bounds = [(k0, min(k0 + ks, K3)) for k0 in range(0, K3, ks)]
+        emb_parts = torch.empty((len(bounds), T, D), dtype=torch.float32, device=dev)
+        problems = []
+        for i, (k0, k1) in enumerate(bounds):
+            q = _problem(T, D, k1 - k0, [(xu, K3, w2, K3)], emb_parts, D, 0, 1)
+            q.A[0], q.B[0], q.C = xu.data_ptr() + k0 * 4, w2.data_ptr() + k0 * 4, emb_parts.data_ptr() + i * T * D * 4
+            problems.append(q)
+        _launch(problems)
         te = lead_time_pe(h, freq_bands)
         n_tok = token.shape[-2]
         out = torch.empty((n_tok + T, D), dtype=torch.float32, device=dev)
-        L.check(lib.dpn_embed_assemble(_p(_c(token)), n_tok, _p(emb), T, _p(_c(pos)), _p(te), _p(out), _s()), 'dpn_embed_assemble')
+        L.check(lib.dpn_embed_assemble(_p(_c(token)), n_tok, _p(emb_parts), len(bounds), T, _p(conv_b), _p(_c(pos)), _p(te), _p(out), _s()),
+                'dpn_embed_assemble')
         ctx.save_for_backward(xu)
         ctx.n_tok, ctx.w_shape, ctx.tok_shape = n_tok, conv_w.shape, token.shape
         return out.view(1, n_tok + T, D)

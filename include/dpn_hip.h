@@ -172,10 +172,12 @@ int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const f
  *                      (encoder time embedding, N_freqs = 128, embed.py:58; VariableNet lead-time PE, N_freqs = 96, variable_net.py:46);
  *   dpn_im2col_circ3   out[T][3C], out[t][3c + tap] = x[(t + tap - 1) mod T][c]: the circular k=3 TokenEmbedding conv becomes
  *                      out . W^T with the Conv1d weight [256][C][3] read in place;
- *   dpn_embed_assemble out[n_tok + n_emb][256] = cat(learnable_token, value_embedding) + positional table + lead-time embedding. */
+ *   dpn_embed_assemble out[n_tok + n_emb][256] = cat(learnable_token, value_embedding) + positional table + lead-time embedding, where the
+ *                      value embedding is given as n_parts split-K partial products [n_parts][n_emb][256] (+ bias[256], may be NULL). */
 int dpn_lead_pe(const float* h_dev, const float* freqs_a, int n_a, float* out_a, const float* freqs_b, int n_b, float* out_b, void* stream);
 int dpn_im2col_circ3(const float* x, int T, int C, float* out, void* stream);
-int dpn_embed_assemble(const float* token, int n_tok, const float* emb, int n_emb, const float* pos, const float* te, float* out, void* stream);
+int dpn_embed_assemble(const float* token, int n_tok, const float* emb_parts, int n_parts, int n_emb, const float* bias, const float* pos,
+                       const float* te, float* out, void* stream);
 
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step (interface_physics.py:514-515; cfg:151-155: L2-in-gradient weight decay)
  * over a list of fp32 tensors.  The pointer arrays and `numel` are HOST arrays of length n_tensors (device pointers inside);
