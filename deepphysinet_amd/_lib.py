@@ -80,6 +80,7 @@ EXPORTS = {
     'dpn_clip_adam_scratch_doubles': (c_int64, [c_int, c_void_p]),
     'dpn_clip_adam': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                               c_float, c_float, c_void_p, c_void_p]),
+    'dpn_sum_parts': (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     'dpn_lead_pe': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'dpn_im2col_circ3': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dpn_embed_assemble': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -321,6 +321,15 @@ __global__ __launch_bounds__(256) void dpn_embed_assemble_kernel(const float* to
     out[(int64_t)row * kD + c] = (v + pos[(int64_t)row * kD + c]) + te[c];
 }
 
+__global__ __launch_bounds__(256) void dpn_sum_parts_kernel(const float* parts, int n_parts, int64_t count, int64_t zero_tail, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) {
+        float v = parts[i];
+        for (int p = 1; p < n_parts; ++p) v += parts[(int64_t)p * count + i];
+        out[i] = v;
+    } else if (i < count + zero_tail) out[i] = 0.f;
+}
+
 constexpr int kAttnLds = 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4 + 4 * 32 * 33 * 4;       // 134,144 B
 constexpr int kDkvLds = 2 * kLmax * 33 * 4 + 4 * 32 * 33 * 4;                                       // 92,928 B
 
@@ -374,6 +383,13 @@ int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const f
     const int nb = (rows + 3) / 4;
     hipLaunchKernelGGL(dpn_add_ln_bwd_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, scratch);
     hipLaunchKernelGGL(dpn_ln_colsum_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const float*)scratch, nb, dgamma, dbeta);
+    return (int)hipGetLastError();
+}
+
+int dpn_sum_parts(const float* parts, int n_parts, int64_t count, int64_t zero_tail, float* out, void* stream) {
+    if (!parts || !out || n_parts <= 0 || count <= 0 || zero_tail < 0) return -1;
+    hipLaunchKernelGGL(dpn_sum_parts_kernel, dim3((unsigned)((count + zero_tail + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), parts,
+                       n_parts, count, zero_tail, out);
     return (int)hipGetLastError();
 }
 

@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(256) void dpn_sgemm_reduce_kernel(SgemmArgs a, int 
 // Several independent small GEMMs in ONE launch (blockIdx.z = problem), each optionally a sum of up to 3 products
 // (C = sum_t op(A_t) op(B_t)): the three q/k/v projections of an attention layer, or the input- and weight-gradient
 // GEMMs of a linear layer, cost one launch instead of 2-6.  Two k-tiles are kept in flight in registers.
-constexpr int kBatchMaxProblems = 20, kBatchMaxTerms = 12, kBatchTermPool = 32;
+constexpr int kBatchMaxProblems = 24, kBatchMaxTerms = 12, kBatchTermPool = 32;
 struct SgemmTerm {
     const float* A;
     const float* B;

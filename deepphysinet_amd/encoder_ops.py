@@ -263,8 +263,8 @@ HEADS_COLS = sum(HEAD_WIDTHS)
 
 class _HeadsFn(torch.autograd.Function):
     """The twelve hyper-network heads and the six lead-time embeddings of a PhysicsNet (model/variable_net.py:57-65,75-78) as ONE
-    launch forward (18 GEMM problems reading the encoder output transposed in place) and ONE launch backward (the input gradient as a
-    12-term problem, twelve weight gradients with their bias sums, six outer products).
+    launch forward (18 GEMM problems reading the encoder output transposed in place) and two launches backward (the input gradient as four
+    3-term problems joined by dpn_sum_parts, twelve weight gradients with their bias sums, six outer products).
     inputs: meta [1, L, 256] (tokens 0..255 are used), pe_h [192], 12 head weights, 12 head biases, 6 fore_h_fc weights, 6 biases
     -> heads [256, 2700] = [w1b1 of nets 0..5 | w2b2 of nets 0..5] per hidden channel, evec [6, 256]."""
 
@@ -300,7 +300,8 @@ class _HeadsFn(torch.autograd.Function):
         m2, pe_h, *hw = ctx.saved_tensors
         dev = m2.device
         gh, ge = _c(g_heads), _c(g_evec)
-        d_meta = torch.zeros(m2.shape, dtype=torch.float32, device=dev)          # tokens >= 256 feed nothing
+        lib = L.load()
+        d_meta = torch.empty(m2.shape, dtype=torch.float32, device=dev)
         terms, off = [], 0
         offs = []
         for w in hw:                                             # d_meta[tok][c] = sum_k sum_j W_k[j][tok] g[c][off_k + j]
@@ -308,10 +309,16 @@ class _HeadsFn(torch.autograd.Function):
             terms.append((w, 256, gh, HEADS_COLS, n_k, off))
             offs.append(off)
             off += n_k
-        q0 = _problem(256, 256, 256, [t[:5] for t in terms], d_meta, 256, 1, 1)
-        for i, t in enumerate(terms):
-            q0.B[i] = gh.data_ptr() + t[5] * 4
-        problems = [q0]
+        # a 12-term problem would walk 24 k-tiles in sequence: four 3-term problems run side by side and dpn_sum_parts joins them
+        parts = torch.empty((4, 256, 256), dtype=torch.float32, device=dev)
+        problems = []
+        for p_ in range(4):
+            grp = terms[3 * p_:3 * p_ + 3]
+            q0 = _problem(256, 256, 256, [t[:5] for t in grp], parts, 256, 1, 1)
+            q0.C = parts.data_ptr() + p_ * 256 * 256 * 4
+            for i, t in enumerate(grp):
+                q0.B[i] = gh.data_ptr() + t[5] * 4
+            problems.append(q0)
         dws, dbs = [], []
         for w, o in zip(hw, offs):                               # dW_k[j][tok] = sum_c g[c][off + j] meta[tok][c] ; db_k[j] = sum_c g[c][off + j]
             n_k = w.shape[0]
@@ -330,4 +337,6 @@ class _HeadsFn(torch.autograd.Function):
             problems.append(q)
             dfw.append(dw)
         _launch(problems)
+        n_tail = (m2.shape[0] - 256) * 256                       # tokens >= 256 feed no VariableNet: their gradient rows are zero
+        L.check(lib.dpn_sum_parts(_p(parts), 4, 256 * 256, n_tail, _p(d_meta), _s()), 'dpn_sum_parts')
         return (d_meta.view(ctx.meta_shape), None, *dws, *dbs, *dfw, *[ge[k] for k in range(6)])

@@ -133,7 +133,7 @@ int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, flo
 int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
               const float* bias, float* asum, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Up to 20 independent small fp32 GEMMs in one launch (exact-fp32 MFMA, fixed reduction order); each
+/* Up to 24 independent small fp32 GEMMs in one launch (exact-fp32 MFMA, fixed reduction order); each
  * C[M][N] = epilogue(sum_{t<nterms} op(A_t)[M][K_t] op(B_t)[K_t][N] + bias[N]); asum as in dpn_sgemm (single-term problems only).
  * Used for the q/k/v projections (attn.py:183-185), the paired input-/weight-gradient GEMMs of every encoder linear, and the
  * twelve hyper-network heads + six lead-time embeddings of the VariableNets (variable_net.py:59-65,75-78) and their backward. */
@@ -142,7 +142,7 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
 #define DPN_EPI_MUL_GELU_GRAD 2   /* C = v * gelu'(aux): backward of the activation folded into the GEMM that feeds it                 */
 #define DPN_EPI_ADD 3             /* C = v + aux: the residual-branch gradient joins the input gradient without a separate add kernel  */
 #define DPN_GEMM_MAX_TERMS 12      /* per problem */
-#define DPN_GEMM_MAX_PROBLEMS 20   /* per launch; at most 32 terms per launch in total */
+#define DPN_GEMM_MAX_PROBLEMS 24   /* per launch; at most 32 terms per launch in total */
 typedef struct DpnGemmProblem {
     const float* A[DPN_GEMM_MAX_TERMS]; const float* B[DPN_GEMM_MAX_TERMS]; int32_t lda[DPN_GEMM_MAX_TERMS], ldb[DPN_GEMM_MAX_TERMS];
     int32_t k_term[DPN_GEMM_MAX_TERMS];   /* reduction length of term t; 0 = K */
@@ -174,6 +174,8 @@ int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const f
  *                      out . W^T with the Conv1d weight [256][C][3] read in place;
  *   dpn_embed_assemble out[n_tok + n_emb][256] = cat(learnable_token, value_embedding) + positional table + lead-time embedding, where the
  *                      value embedding is given as n_parts split-K partial products [n_parts][n_emb][256] (+ bias[256], may be NULL). */
+/* out[0 .. count) = sum_p parts[p][0 .. count) (fixed order), out[count .. count + zero_tail) = 0: joins split-K partial products. */
+int dpn_sum_parts(const float* parts, int n_parts, int64_t count, int64_t zero_tail, float* out, void* stream);
 int dpn_lead_pe(const float* h_dev, const float* freqs_a, int n_a, float* out_a, const float* freqs_b, int n_b, float* out_b, void* stream);
 int dpn_im2col_circ3(const float* x, int T, int C, float* out, void* stream);
 int dpn_embed_assemble(const float* token, int n_tok, const float* emb_parts, int n_parts, int n_emb, const float* bias, const float* pos,
