@@ -114,11 +114,13 @@ def main():
         lf = m.train_cfg['losses']['loss_factor']
         params = list(m.physics_net.parameters())
 
+        one = torch.ones((), dtype=torch.float32, device=dev)
+
         def compute():
             opt.zero_grad(set_to_none=True)
             loss = m.place_one_batch(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'],
                                      batch['forecast_h'], crit, lf, 0, 0, dev)
-            loss.backward()
+            loss.backward(one)                         # persistent seed: no ones_like fill per step
             return loss
 
         def finish():

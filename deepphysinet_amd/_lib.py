@@ -42,6 +42,10 @@ class DpnGemmProblem(Structure):
 EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_ADD = 0, 1, 2, 3
 
 
+class DpnColsumJob(Structure):
+    _fields_ = [('partial', c_void_p), ('out_a', c_void_p), ('out_b', c_void_p), ('n_blocks', c_int32)]
+
+
 class DpnSampler(Structure):
     _fields_ = [('lon', c_int32), ('lat', c_int32), ('lon_in', c_int32), ('lat_in', c_int32), ('t_in', c_int32), ('t_hours', c_int32),
                 ('cells_x', c_double), ('cells_y', c_double), ('t_step_hours', c_double), ('begin_lat', c_double), ('dlat', c_double),
@@ -72,6 +76,7 @@ EXPORTS = {
     'dpn_smooth_l1': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'dpn_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                           c_void_p, c_int64, c_void_p]),
+    'dpn_sgemm_batch_jobs': (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'dpn_sgemm_batch': (c_int, [c_int, POINTER(DpnGemmProblem), c_void_p]),
     'dpn_attn_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'dpn_attn_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

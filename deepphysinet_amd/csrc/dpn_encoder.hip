@@ -377,12 +377,13 @@ int dpn_add_ln_fwd(const float* x, const float* r, const float* gamma, const flo
 
 int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const float* gamma, int rows, float* gx, float* dgamma, float* dbeta,
                    float* scratch, void* stream) {
-    if (!g || !xhat || !rstd || !gamma || !gx || !dgamma || !dbeta || !scratch || rows <= 0) return -1;
+    if (!g || !xhat || !rstd || !gamma || !gx || !scratch || rows <= 0 || ((dgamma == nullptr) != (dbeta == nullptr))) return -1;
     LnArgs a{};
     a.g = g; a.xhat = xhat; a.rstd = rstd; a.gamma = gamma; a.gx = gx; a.dgamma = dgamma; a.dbeta = dbeta; a.rows = rows;
     const int nb = (rows + 3) / 4;
     hipLaunchKernelGGL(dpn_add_ln_bwd_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, scratch);
-    hipLaunchKernelGGL(dpn_ln_colsum_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const float*)scratch, nb, dgamma, dbeta);
+    if (dgamma)   // NULL: the caller reduces `scratch` itself (dpn_sgemm_batch_jobs)
+        hipLaunchKernelGGL(dpn_ln_colsum_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const float*)scratch, nb, dgamma, dbeta);
     return (int)hipGetLastError();
 }
 

@@ -132,34 +132,8 @@ DEV float pack_src(const DpnNetPtrs& P, int kb, int lane, int e) {
     }
 }
 
-__global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
-    const int net = blockIdx.y;
-    const DpnNetPtrs& P = a.net[net];
-    const int ns = a.ns;
-    uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
-    const int total = kPackKB * 64;                   // (kb, lane) pairs
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < total; u += gridDim.x * 256) {
-        const int kb = u >> 6, lane = u & 63;
-        u16 hi[8], lo[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = pack_src(P, kb, lane, e);
-            hi[e] = f2bf(x);
-            lo[e] = f2bf(x - bf2f(hi[e]));
-        }
-        uint4 w;
-        w.x = hi[0] | (hi[1] << 16); w.y = hi[2] | (hi[3] << 16); w.z = hi[4] | (hi[5] << 16); w.w = hi[6] | (hi[7] << 16);
-        dst[(kb * ns) * 64 + lane] = w;
-        if (ns == 2) {
-            w.x = lo[0] | (lo[1] << 16); w.y = lo[2] | (lo[3] << 16); w.z = lo[4] | (lo[5] << 16); w.w = lo[6] | (lo[7] << 16);
-            dst[(kb * ns + 1) * 64 + lane] = w;
-        }
-    }
-}
-
 // vectors in [h][T][r] order (channel 32T + drow32(r,h)); u = W2^T wo; const0 = wo.bf2 + bo
-__global__ __launch_bounds__(256) void dpn_pack_vectors_kernel(PackArgs a) {
-    const int net = blockIdx.x;
+DEV void pack_vectors(const PackArgs& a, const int net) {
     const DpnNetPtrs& P = a.net[net];
     float* vec = reinterpret_cast<float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
     const int idx = threadIdx.x;
@@ -183,6 +157,32 @@ __global__ __launch_bounds__(256) void dpn_pack_vectors_kernel(PackArgs a) {
     if (idx == 0) {
         vec[kNumVecs * 256 + 0] = red[0] + P.bo[0];
         vec[kNumVecs * 256 + 1] = 0.f; vec[kNumVecs * 256 + 2] = 0.f; vec[kNumVecs * 256 + 3] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
+    if (blockIdx.x == gridDim.x - 1) { pack_vectors(a, blockIdx.y); return; }      // last block column: the fp32 vectors of this net
+    const int net = blockIdx.y;
+    const DpnNetPtrs& P = a.net[net];
+    const int ns = a.ns;
+    uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
+    const int total = kPackKB * 64;                   // (kb, lane) pairs
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < total; u += (gridDim.x - 1) * 256) {     // the last block column packs the vectors
+        const int kb = u >> 6, lane = u & 63;
+        u16 hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = pack_src(P, kb, lane, e);
+            hi[e] = f2bf(x);
+            lo[e] = f2bf(x - bf2f(hi[e]));
+        }
+        uint4 w;
+        w.x = hi[0] | (hi[1] << 16); w.y = hi[2] | (hi[3] << 16); w.z = hi[4] | (hi[5] << 16); w.w = hi[6] | (hi[7] << 16);
+        dst[(kb * ns) * 64 + lane] = w;
+        if (ns == 2) {
+            w.x = lo[0] | (lo[1] << 16); w.y = lo[2] | (lo[3] << 16); w.z = lo[4] | (lo[5] << 16); w.w = lo[6] | (lo[7] << 16);
+            dst[(kb * ns + 1) * 64 + lane] = w;
+        }
     }
 }
 
@@ -1393,9 +1393,11 @@ DEV float gelu_exact_grad(float x) {
     const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;      // M_2_SQRTPI * M_SQRT1_2 * 0.5
     return cdf + x * pdf;
 }
+struct SgemmColsum { const float* partial; float* out_a; float* out_b; int nblocks, pad; };
 struct SgemmBatch {
     SgemmProblem p[kBatchMaxProblems];
     SgemmTerm t[kBatchTermPool];          // the accumulated A.B terms of all problems (problem i owns t[term0 .. term0+nterms))
+    SgemmColsum job[2];                   // ride-along column sums (LayerNorm parameter gradients): blockIdx.z = n, n + 1
     int n;
 };
 
@@ -1411,6 +1413,19 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     // <128, 2>: double-buffered LDS, two k-tiles in flight (long / multi-term reductions).  <256, 1>: the whole K of a 256-wide encoder
     // GEMM is ONE tile -- one LDS stage, one barrier pair, 32 loads per operand in flight (used when every problem is a single tile).
     constexpr int BM = 32, BN = 32, NL = BK * 32 / 256;   // NL loads per operand per thread per k-tile
+    if ((int)blockIdx.z >= batch.n) {
+        // ride-along job: out_a[c] = sum_b partial[b][c], out_b[c] = sum_b partial[b][256 + c] (fixed order) -- the reduction of
+        // dpn_add_ln_bwd's per-block partial sums, finished in the shadow of the GEMM tiles instead of in a launch of its own
+        if (blockIdx.x || blockIdx.y) return;
+        const SgemmColsum& j = batch.job[blockIdx.z - batch.n];
+        const int c = threadIdx.x;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < j.nblocks; ++b) { s1 += j.partial[(int64_t)b * 512 + c]; s2 += j.partial[(int64_t)b * 512 + 256 + c]; }
+        j.out_a[c] = s1;
+        j.out_b[c] = s2;
+        return;
+    }
     const SgemmProblem& a = batch.p[blockIdx.z];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= a.M || n0 >= a.N) return;
@@ -1669,8 +1684,7 @@ int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, vo
     a.packed = reinterpret_cast<char*>(packed);
     a.ns = prec;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(40, kNets), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(dpn_pack_vectors_kernel, dim3(kNets), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(40 + 1, kNets), dim3(256), 0, s, a);
     return ck(hipGetLastError());
 }
 
@@ -1776,8 +1790,8 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
     return ck(hipGetLastError());
 }
 
-int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream) {
-    if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems) return -1;
+static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream) {
+    if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems || n_jobs < 0 || n_jobs > 2 || (n_jobs && !jobs)) return -1;
     SgemmBatch b;
     b.n = n_problems;
     int gx = 0, gy = 0, pool = 0;
@@ -1798,12 +1812,25 @@ int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream
         gx = gx > (q.N + 31) / 32 ? gx : (q.N + 31) / 32;
         gy = gy > (q.M + 31) / 32 ? gy : (q.M + 31) / 32;
     }
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!jobs[i].partial || !jobs[i].out_a || !jobs[i].out_b || jobs[i].n_blocks <= 0) return -1;
+        b.job[i] = SgemmColsum{jobs[i].partial, jobs[i].out_a, jobs[i].out_b, jobs[i].n_blocks, 0};
+    }
+    const int gz = n_problems + n_jobs;
     bool single_tile = true;
     for (int i = 0; i < pool; ++i) single_tile = single_tile && b.t[i].K <= 256;
     for (int i = 0; i < n_problems; ++i) single_tile = single_tile && b.p[i].nterms == 1;
-    if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1>), dim3(gx, gy, n_problems), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
-    else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<128, 2>), dim3(gx, gy, n_problems), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<128, 2>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
     return ck(hipGetLastError());
+}
+
+int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream) {
+    return sgemm_batch_launch(n_problems, problems, 0, nullptr, stream);
+}
+
+int dpn_sgemm_batch_jobs(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream) {
+    return sgemm_batch_launch(n_problems, problems, n_jobs, jobs, stream);
 }
 
 int64_t dpn_clip_adam_scratch_doubles(int n_tensors, const int64_t* numel) {

@@ -138,13 +138,13 @@ class _EncoderLayerFn(torch.autograd.Function):
         dev = x.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         scratch = new(((n + 3) // 4) * 512)
-        # LN2
+        # LN2 (its parameter sums ride along in the next GEMM launch)
         gs2, dg2, dbe2 = new(n, D), new(D), new(D)
-        L.check(lib.dpn_add_ln_bwd(_p(_c(g)), _p(xhat2), _p(rstd2), _p(g2), n, _p(gs2), _p(dg2), _p(dbe2), _p(scratch), _s()), 'dpn_add_ln_bwd')
+        L.check(lib.dpn_add_ln_bwd(_p(_c(g)), _p(xhat2), _p(rstd2), _p(g2), n, _p(gs2), None, None, _p(scratch), _s()), 'dpn_add_ln_bwd')
         # conv2: d(pre) = (gs2 W_c2) * gelu'(pre) ; dW_c2 = gs2^T act ; db_c2 = sum_rows gs2
         dpre, dwc2, dbc2 = new(n, Fh), new(D, Fh), new(D)
         _launch([_problem(n, Fh, D, [(gs2, D, wc2, Fh)], dpre, Fh, 0, 0, epi=L.EPI_MUL_GELU_GRAD, aux=pre),
-                 _problem(D, Fh, n, [(gs2, D, act, Fh)], dwc2, Fh, 1, 0, asum=dbc2)])
+                 _problem(D, Fh, n, [(gs2, D, act, Fh)], dwc2, Fh, 1, 0, asum=dbc2)], colsum_jobs=[(scratch, n, dg2, dbe2)])
         # conv1: d(x1) = dpre W_c1 + gs2 (the residual branch) ; dW_c1 = dpre^T x1
         dx1, dwc1, dbc1 = new(n, D), new(Fh, D), new(Fh)
         _launch([_problem(n, D, Fh, [(dpre, Fh, wc1, D)], dx1, D, 0, 0, epi=L.EPI_ADD, aux=gs2),
@@ -152,10 +152,11 @@ class _EncoderLayerFn(torch.autograd.Function):
         # LN1
         gs1, dg1, dbe1 = new(n, D), new(D), new(D)
         scratch1 = new(((n + 3) // 4) * 512)
-        L.check(lib.dpn_add_ln_bwd(_p(dx1), _p(xhat1), _p(rstd1), _p(g1), n, _p(gs1), _p(dg1), _p(dbe1), _p(scratch1), _s()), 'dpn_add_ln_bwd')
+        L.check(lib.dpn_add_ln_bwd(_p(dx1), _p(xhat1), _p(rstd1), _p(g1), n, _p(gs1), None, None, _p(scratch1), _s()), 'dpn_add_ln_bwd')
         # out projection
         do, dwo, dbo = new(n, D), new(D, D), new(D)
-        _launch([_problem(n, D, D, [(gs1, D, wo, D)], do, D, 0, 0), _problem(D, D, n, [(gs1, D, o, D)], dwo, D, 1, 0, asum=dbo)])
+        _launch([_problem(n, D, D, [(gs1, D, wo, D)], do, D, 0, 0), _problem(D, D, n, [(gs1, D, o, D)], dwo, D, 1, 0, asum=dbo)],
+                colsum_jobs=[(scratch1, n, dg1, dbe1)])
         # attention
         dq, dk, dv, dS = new(n, D), new(n, D), new(n, D), new(8, 288, 288)
         L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(do), n, _p(dq), _p(dk), _p(dv), _p(dS), _s()), 'dpn_attn_bwd')

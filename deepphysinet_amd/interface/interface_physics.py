@@ -235,7 +235,9 @@ class InterfacePhysics(nn.Module):
         for v in parts.values():
             train_loss = train_loss + v
         optimizer.zero_grad()
-        train_loss.backward()
+        if getattr(self, '_seed', None) is None or self._seed.device != train_loss.device:
+            self._seed = torch.ones((), dtype=train_loss.dtype, device=train_loss.device)      # persistent backward seed: no fill per step
+        train_loss.backward(self._seed)
         self.physics_net.clear_field_cache()
         if grad_sync is not None:
             grad_sync(self.physics_net.parameters())

@@ -28,10 +28,16 @@ def _problem(M, N, K, terms, C, ldc, ta, tb, bias=None, asum=None, epi=0, aux=No
     return q
 
 
-def _launch(problems):
+def _launch(problems, colsum_jobs=()):
+    """One dpn_sgemm_batch launch; colsum_jobs: up to two (scratch, rows, dgamma, dbeta) LayerNorm parameter reductions riding along."""
     lib = L.load()
     arr = (L.DpnGemmProblem * len(problems))(*problems)
-    L.check(lib.dpn_sgemm_batch(len(problems), arr, torch.cuda.current_stream().cuda_stream), 'dpn_sgemm_batch')
+    if not colsum_jobs:
+        L.check(lib.dpn_sgemm_batch(len(problems), arr, torch.cuda.current_stream().cuda_stream), 'dpn_sgemm_batch')
+        return
+    jobs = (L.DpnColsumJob * len(colsum_jobs))(*[L.DpnColsumJob(s.data_ptr(), a.data_ptr(), b.data_ptr(), (rows + 3) // 4)
+                                                for s, rows, a, b in colsum_jobs])
+    L.check(lib.dpn_sgemm_batch_jobs(len(problems), arr, len(colsum_jobs), jobs, torch.cuda.current_stream().cuda_stream), 'dpn_sgemm_batch_jobs')
 
 
 def _sgemm_splitk(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, asum=None):

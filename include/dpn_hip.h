@@ -152,6 +152,11 @@ typedef struct DpnGemmProblem {
     int32_t epi;
 } DpnGemmProblem;
 int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems /* host array */, void* stream);
+/* The same launch with up to two ride-along column-sum jobs: out_a[c] = sum_b partial[b][c], out_b[c] = sum_b partial[b][256 + c],
+ * c < 256, b < n_blocks (fixed order) -- the LayerNorm parameter gradients from dpn_add_ln_bwd's scratch (n_blocks = ceil(rows/4)),
+ * finished inside a GEMM launch that follows it instead of in a launch of their own. */
+typedef struct DpnColsumJob { const float* partial; float* out_a; float* out_b; int32_t n_blocks; } DpnColsumJob;
+int dpn_sgemm_batch_jobs(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs /* host array, <= 2 */, void* stream);
 
 /* FullAttention of the encoder (model/attn.py:50-68): o = softmax(q k^T / sqrt(32)) v for 8 heads x 32 over L <= 288 tokens.
  * q,k,v,o,go,dq,dk,dv: [L][256] fp32 row-major (head h = columns 32h..32h+31).  P (saved probabilities) and dS_scratch:
@@ -161,7 +166,8 @@ int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  float* dq, float* dk, float* dv, float* dS_scratch, void* stream);
 
 /* out = LayerNorm_256(x + r) * gamma + beta (eps 1e-5), r may be NULL (transformer_net.py:37,44,68); saves xhat [rows][256] and rstd [rows].
- * Backward: gx = d/d(x + r) (the same tensor is the gradient of x and of r), dgamma, dbeta [256]. */
+ * Backward: gx = d/d(x + r) (the same tensor is the gradient of x and of r), dgamma, dbeta [256].  With dgamma = dbeta = NULL only gx and the
+ * per-block partial sums in `scratch` ([ceil(rows/4)][512]) are produced, to be reduced by a DpnColsumJob of dpn_sgemm_batch_jobs. */
 int dpn_add_ln_fwd(const float* x, const float* r, const float* gamma, const float* beta, int rows, float* out, float* xhat, float* rstd,
                    void* stream);
 int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const float* gamma, int rows, float* gx, float* dgamma, float* dbeta,
