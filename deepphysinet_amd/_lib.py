@@ -79,7 +79,7 @@ EXPORTS = {
     'dpn_sgemm_batch_jobs': (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'dpn_sgemm_batch': (c_int, [c_int, POINTER(DpnGemmProblem), c_void_p]),
     'dpn_attn_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    'dpn_attn_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_attn_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_add_ln_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_add_ln_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_clip_adam_scratch_doubles': (c_int64, [c_int, c_void_p]),

@@ -126,9 +126,10 @@ __global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------- attention backward
-// pass 1, per (query tile, head): D = rowsum(gO * O), dP = gO V^T, dS = P * (dP - D) * scale (saved), dQ = dS K.
-__global__ __launch_bounds__(256) void dpn_attn_bwd_dq_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// ONE launch, grid (tiles of 32, heads, 2 roles); both roles are independent of each other (the key/value role recomputes its
+// columns of dS instead of waiting for the query role to publish them), so the backward of the attention is one graph node.
+// role 0, per (query tile, head): D = rowsum(gO * O), dP = gO V^T, dS = P * (dP - D) * scale, dQ = dS K.
+DEV void attn_bwd_query_role(const AttnArgs& a, char* smem) {
     float (*Ks)[33] = reinterpret_cast<float (*)[33]>(smem);
     float (*Vs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);
     float (*Gs)[33] = reinterpret_cast<float (*)[33]>(smem + 2 * kLmax * 33 * 4);             // gO tile [32][33]
@@ -168,9 +169,7 @@ __global__ __launch_bounds__(256) void dpn_attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = drow32(r, h), col = ct * 32 + i;
-            const float ds = Ss[row][col] * (acc[r] - Drow[row]) * a.scale;
-            Ss[row][col] = ds;
-            if (q0 + row < L) a.dS[((int64_t)head * kLmax + q0 + row) * kLmax + col] = ds;
+            Ss[row][col] = Ss[row][col] * (acc[r] - Drow[row]) * a.scale;
         }
     }
     __syncthreads();
@@ -181,30 +180,56 @@ __global__ __launch_bounds__(256) void dpn_attn_bwd_dq_kernel(AttnArgs a) {
     });
 }
 
-// pass 2, per (key tile, head): dK = dS^T Q, then dV = P^T gO  (reductions over all queries; the two LDS images are reused)
-__global__ __launch_bounds__(256) void dpn_attn_bwd_dkv_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float (*Rs)[33] = reinterpret_cast<float (*)[33]>(smem);                                  // [288][33] all rows of Q, then of gO
-    float (*Cs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);                 // [288][33]: dS[:, key tile], then P[:, key tile]
-    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem + 2 * kLmax * 33 * 4);
+// role 1, per (key tile, head): dV = P^T gO; then its own 288 x 32 block of dS (same expression, same order of operations as role 0);
+// dK = dS^T Q.  Reductions over all queries.
+DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
+    float (*Rs)[33] = reinterpret_cast<float (*)[33]>(smem);                                  // [288][33]: all rows of gO, later of Q
+    float (*Cs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);                 // [288][33]: P[:, key tile], later dS[:, key tile]
+    float (*Vt)[33] = reinterpret_cast<float (*)[33]>(smem + 2 * kLmax * 33 * 4);             // [32][33]: V rows of the key tile
+    float* Dl = reinterpret_cast<float*>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4);            // [288]
+    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4 + kLmax * 4);
     const int head = blockIdx.y, j0 = blockIdx.x * 32, L = a.L;
-    load_head_rows(Rs, a.q, head, 0, kLmax, L);
-    load_rows16<kLmax>(Cs, a.dS + (int64_t)head * kLmax * kLmax, kLmax, j0, 0, L);
-    __syncthreads();
-    f32x16 acc = (f32x16)0.f;
-    mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dK[j][e] = sum_i dS[i][j] Q[i][e]
-    reduce_tile(acc, part, [&](int r, int c, float v) {
-        if (j0 + r < L) a.dk[(int64_t)(j0 + r) * kD + head * kE + c] = v;
-    });
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     load_head_rows(Rs, a.go, head, 0, kLmax, L);
     load_rows16<kLmax>(Cs, a.P + (int64_t)head * kLmax * kLmax, kLmax, j0, 0, L);
+    load_head_rows(Vt, a.v, head, j0, 32, L);
+    for (int r = threadIdx.x; r < kLmax; r += 256) {
+        float d = 0.f;
+        if (r < L)
+            for (int c = 0; c < kE; ++c) d = fmaf(a.go[(int64_t)r * kD + head * kE + c], a.o[(int64_t)r * kD + head * kE + c], d);
+        Dl[r] = d;
+    }
     __syncthreads();
-    acc = (f32x16)0.f;
+    f32x16 acc = (f32x16)0.f;
     mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dV[j][e] = sum_i P[i][j] gO[i][e]
     reduce_tile(acc, part, [&](int r, int c, float v) {
         if (j0 + r < L) a.dv[(int64_t)(j0 + r) * kD + head * kE + c] = v;
     });
+    __syncthreads();
+    for (int rt = wave; rt < kLmax / 32; rt += 4) {                                            // dS[rows of tile rt][key tile]
+        f32x16 dp = (f32x16)0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dp = mfma_f32(Rs[rt * 32 + i][2 * u + h], Vt[i][2 * u + h], dp);              // dP[row][j] = sum_e gO[row][e] V[j][e]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rt * 32 + drow32(r, h);
+            Cs[row][i] = Cs[row][i] * (dp[r] - Dl[row]) * a.scale;
+        }
+    }
+    __syncthreads();
+    load_head_rows(Rs, a.q, head, 0, kLmax, L);
+    __syncthreads();
+    acc = (f32x16)0.f;
+    mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dK[j][e] = sum_i dS[i][j] Q[i][e]
+    reduce_tile(acc, part, [&](int r, int c, float v) {
+        if (j0 + r < L) a.dk[(int64_t)(j0 + r) * kD + head * kE + c] = v;
+    });
+}
+
+__global__ __launch_bounds__(256) void dpn_attn_bwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.z == 0) attn_bwd_query_role(a, smem);
+    else attn_bwd_key_role(a, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------- add + LayerNorm
@@ -331,7 +356,7 @@ __global__ __launch_bounds__(256) void dpn_sum_parts_kernel(const float* parts, 
 }
 
 constexpr int kAttnLds = 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4 + 4 * 32 * 33 * 4;       // 134,144 B
-constexpr int kDkvLds = 2 * kLmax * 33 * 4 + 4 * 32 * 33 * 4;                                       // 92,928 B
+static_assert(2 * kLmax * 33 * 4 + 32 * 33 * 4 + kLmax * 4 + 4 * 32 * 33 * 4 <= kAttnLds, "the key role fits in the query role's LDS");
 
 }  // namespace
 
@@ -349,20 +374,15 @@ int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, float* o
 }
 
 int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L,
-                 float* dq, float* dk, float* dv, float* dS_scratch, void* stream) {
-    if (!q || !k || !v || !o || !P || !go || !dq || !dk || !dv || !dS_scratch || L <= 0 || L > kLmax) return -1;
+                 float* dq, float* dk, float* dv, void* stream) {
+    if (!q || !k || !v || !o || !P || !go || !dq || !dk || !dv || L <= 0 || L > kLmax) return -1;
     AttnArgs a{};
-    a.q = q; a.k = k; a.v = v; a.o = o; a.go = go; a.P = const_cast<float*>(P); a.dS = dS_scratch; a.dq = dq; a.dk = dk; a.dv = dv; a.L = L;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.go = go; a.P = const_cast<float*>(P); a.dq = dq; a.dk = dk; a.dv = dv; a.L = L;
     a.scale = 1.0f / sqrtf((float)kE);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvLds);
-        once = true;
-    }
-    hipLaunchKernelGGL(dpn_attn_bwd_dq_kernel, dim3((L + 31) / 32, kH), dim3(256), kAttnLds, s, a);
-    hipLaunchKernelGGL(dpn_attn_bwd_dkv_kernel, dim3((L + 31) / 32, kH), dim3(256), kDkvLds, s, a);
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); once = true; }
+    hipLaunchKernelGGL(dpn_attn_bwd_kernel, dim3((L + 31) / 32, kH, 2), dim3(256), kAttnLds, s, a);
     return (int)hipGetLastError();
 }
 

@@ -40,8 +40,7 @@ class _AttentionFn(torch.autograd.Function):
         q, k, v, o, P = ctx.saved_tensors
         go = _c(go)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-        dS = torch.empty_like(P)
-        L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(go), q.shape[0], _p(dq), _p(dk), _p(dv), _p(dS), _s()), 'dpn_attn_bwd')
+        L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(go), q.shape[0], _p(dq), _p(dk), _p(dv), _s()), 'dpn_attn_bwd')
         return dq, dk, dv
 
 
@@ -158,8 +157,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         _launch([_problem(n, D, D, [(gs1, D, wo, D)], do, D, 0, 0), _problem(D, D, n, [(gs1, D, o, D)], dwo, D, 1, 0, asum=dbo)],
                 colsum_jobs=[(scratch1, n, dg1, dbe1)])
         # attention
-        dq, dk, dv, dS = new(n, D), new(n, D), new(n, D), new(8, 288, 288)
-        L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(do), n, _p(dq), _p(dk), _p(dv), _p(dS), _s()), 'dpn_attn_bwd')
+        dq, dk, dv = new(n, D), new(n, D), new(n, D)
+        L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(do), n, _p(dq), _p(dk), _p(dv), _s()), 'dpn_attn_bwd')
         # q/k/v projections: dx = dq Wq + dk Wk + dv Wv + gs1 (the residual branch)
         dx, dwq, dwk, dwv, dbq, dbk, dbv = new(n, D), new(D, D), new(D, D), new(D, D), new(D), new(D), new(D)
         _launch([_problem(n, D, D, [(dq, D, wq, D), (dk, D, wk, D), (dv, D, wv, D)], dx, D, 0, 0, epi=L.EPI_ADD, aux=gs1),

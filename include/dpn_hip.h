@@ -159,11 +159,11 @@ typedef struct DpnColsumJob { const float* partial; float* out_a; float* out_b; 
 int dpn_sgemm_batch_jobs(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs /* host array, <= 2 */, void* stream);
 
 /* FullAttention of the encoder (model/attn.py:50-68): o = softmax(q k^T / sqrt(32)) v for 8 heads x 32 over L <= 288 tokens.
- * q,k,v,o,go,dq,dk,dv: [L][256] fp32 row-major (head h = columns 32h..32h+31).  P (saved probabilities) and dS_scratch:
- * [8][288][288] fp32. */
+ * q,k,v,o,go,dq,dk,dv: [L][256] fp32 row-major (head h = columns 32h..32h+31).  P (saved probabilities): [8][288][288] fp32.
+ * The backward is one launch: query-tile blocks produce dq, key-tile blocks produce dk and dv (recomputing their columns of dS). */
 int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, float* out, float* P, void* stream);
 int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L,
-                 float* dq, float* dk, float* dv, float* dS_scratch, void* stream);
+                 float* dq, float* dk, float* dv, void* stream);
 
 /* out = LayerNorm_256(x + r) * gamma + beta (eps 1e-5), r may be NULL (transformer_net.py:37,44,68); saves xhat [rows][256] and rstd [rows].
  * Backward: gx = d/d(x + r) (the same tensor is the gradient of x and of r), dgamma, dbeta [256].  With dgamma = dbeta = NULL only gx and the
