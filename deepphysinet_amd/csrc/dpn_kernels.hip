@@ -1790,6 +1790,9 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
     return ck(hipGetLastError());
 }
 
+// measured on the encoder backward (A2 phase): threshold 1 -> 778 us, 2 -> 804 us, 3 -> 798 us: multi-tile problems want the
+// double-buffered <128,2> pipeline
+constexpr int kSingleStageMaxTiles = 1;
 static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream) {
     if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems || n_jobs < 0 || n_jobs > 2 || (n_jobs && !jobs)) return -1;
     SgemmBatch b;
@@ -1817,9 +1820,13 @@ static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, in
         b.job[i] = SgemmColsum{jobs[i].partial, jobs[i].out_a, jobs[i].out_b, jobs[i].n_blocks, 0};
     }
     const int gz = n_problems + n_jobs;
+    // <256,1> (one LDS stage of 256 k) when every problem is a single such tile
     bool single_tile = true;
-    for (int i = 0; i < pool; ++i) single_tile = single_tile && b.t[i].K <= 256;
-    for (int i = 0; i < n_problems; ++i) single_tile = single_tile && b.p[i].nterms == 1;
+    for (int i = 0; i < n_problems; ++i) {
+        int tiles = 0;
+        for (int t = 0; t < b.p[i].nterms; ++t) tiles += (b.t[b.p[i].term0 + t].K + 255) / 256;
+        single_tile = single_tile && tiles <= kSingleStageMaxTiles;
+    }
     if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
     else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<128, 2>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
     return ck(hipGetLastError());
