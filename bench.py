@@ -86,7 +86,10 @@ def main():
     args = ap.parse_args()
 
     from deepphysinet_amd import distributed as D
-    rank, world, local = D.init_from_env()
+    # DPN_BENCH_BACKEND=gloo + DPN_BENCH_ONE_DEVICE=1: exercise the N > 1 code path with every rank on GPU 0 (test boxes have one GPU)
+    rank, world, local = D.init_from_env(os.environ.get('DPN_BENCH_BACKEND'))
+    if os.environ.get('DPN_BENCH_ONE_DEVICE') == '1':
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the point path)')
     torch.cuda.set_device(local)
