@@ -853,10 +853,14 @@ __global__ __launch_bounds__(256) void dpn_smooth_l1_kernel(const float* out_n, 
         l = (ad < beta) ? 0.5f * d * d / beta : ad - 0.5f * beta;    // nn.SmoothL1Loss(beta), weights_loss.py:15-19
         if (g_out) g_out[i] = scale * ((ad < beta) ? d / beta : (d > 0.f ? 1.f : -1.f));
     }
-    double s = (double)l;
+    if (!loss_sum) return;
+    double s = (double)l;                          // one fp64 partial per block, fixed order, no atomics: the caller adds the blocks up
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (loss_sum && (threadIdx.x & 63) == 0) atomicAdd(loss_sum, s);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_sum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------------ backward, stage 1

@@ -269,11 +269,11 @@ class _SmoothL1Fn(torch.autograd.Function):
         lib = L.load()
         o, l = _f32c(out_n), _f32c(labels)
         n = o.shape[0]
-        s = torch.zeros(1, dtype=torch.float64, device=o.device)
+        s = torch.empty((n * 6 + 255) // 256, dtype=torch.float64, device=o.device)      # per-block partial sums
         g = torch.empty_like(o)
         L.check(lib.dpn_smooth_l1(_ptr(o), _ptr(l), n, beta, factor / (6.0 * n), _ptr(s), _ptr(g), _stream()), 'dpn_smooth_l1')
         ctx.save_for_backward(g)
-        return ((s[0] / (6.0 * n)).float() * factor)
+        return ((s.sum() / (6.0 * n)).float() * factor)
 
     @staticmethod
     def backward(ctx, gl):

@@ -120,8 +120,8 @@ int dpn_wgrad(int64_t n_points, int prec, const float* g_out, const void* saved,
 int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n_points, int prec,
                      const void* partials, const DpnNetGradPtrs grads[DPN_NETS], void* stream);
 
-/* SmoothL1(beta) data loss on the normalised fields (losses/weights_loss.py:17-20): sum -> loss_sum[0] (fp64),
- * g_out = gl * factor/(6N) * dSmoothL1 (may be NULL). */
+/* SmoothL1(beta) data loss on the normalised fields (losses/weights_loss.py:17-20): per-block sums -> loss_sum[ceil(6N/256)] (fp64,
+ * written not accumulated; the caller adds them in a fixed order), g_out = scale * dSmoothL1 (may be NULL). */
 int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, float beta, float scale,
                   double* loss_sum, float* g_out, void* stream);
 
