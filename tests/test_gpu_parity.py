@@ -420,3 +420,21 @@ def test_fused_encoder_nodes_vs_torch_autograd():
     for a_, b_ in zip(g1, g2):
         assert a_.shape == b_.shape and rel(a_, b_) < 1e-4
     assert float(g1[0][0, 256:].abs().max()) == 0.0            # tokens 256..286 feed no VariableNet (variable_net.py:58)
+
+
+def test_full_grid_step_is_bitwise_deterministic():
+    """No kernel on the path uses atomics (loss, weight-gradient and gradient-norm reductions are fixed-order): two executions of the
+    full-size step from the same state give bit-identical losses and gradients -- a size-independent property at BASELINE's size."""
+    m = _model('bf16')
+    g = _gpu(synthetic_inputs(257 * 145, GEO.lon, GEO.lat, GEO.dx, GEO.dy))
+    lf = m.train_cfg['losses']['loss_factor']
+    outs = []
+    for _ in range(2):
+        m.physics_net.zero_grad(set_to_none=True)
+        loss = m.place_one_batch(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'], torch.nn.MSELoss(), lf, 0, 0,
+                                 _dev())
+        loss.backward()
+        outs.append((loss.detach().clone(), [p.grad.detach().clone() for p in m.physics_net.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a_, b_ in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a_, b_)
