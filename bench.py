@@ -29,6 +29,8 @@ MFMA_PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.
 # HBM bytes per dpn_fwd_kernel launch at 37 265 points from the rocprofv3 PMC passes committed in profiles/
 # (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 FETCH_SIZE correction of the guide applied); bench.py cannot collect PMCs itself.
 PMC_TRAFFIC_FWD = {('bf16', 257 * 145): (2 * 57357.3 + 383646.4) * 1024}
+PMC_TRAFFIC_WGRAD = {('bf16', 257 * 145): (2 * 422364.5 + 54001.9) * 1024}
+HBM_PEAK = 8.0e12                      # HBM3E, MI355X_MICROARCH.md
 
 
 def synth_batch(n_points, device, seed, lon=257, lat=145, dx=27000.0, dy=27000.0):
@@ -237,8 +239,34 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             k_ms = e0.elapsed_time(e1) / reps
+            # ---- the HBM-bound kernel of the path: dpn_wgrad (points-reduction GEMMs; every saved / cotangent operand is read once)
+            f_ = PP._f32c(batch['f']).reshape(-1)
+            ph = cfg.physics()
+            g_out = torch.empty((args.points, 6), device=dev)
+            g_jxi = torch.empty((args.points, 6, 3), device=dev)
+            operands = torch.empty(ws.sizes.operands, dtype=torch.uint8, device=dev)
+            partials = torch.empty(ws.sizes.partials, dtype=torch.uint8, device=dev)
+            L.check(lib.dpn_residual(PP._ptr(out_n), PP._ptr(jac_n), PP._ptr(f_), args.points, ctypes.byref(geo), ctypes.byref(ph), None, None, None,
+                                     PP._ptr(g_out), PP._ptr(g_jxi), PP._stream()), 'dpn_residual')
+            L.check(lib.dpn_bwd_points(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), args.points, PP._ptr(PP._freqs(dev)),
+                                       ctypes.byref(geo), PP._ptr(ws.packed), cfg.prec, PP._ptr(g_out), PP._ptr(g_jxi), PP._ptr(ws.saved),
+                                       PP._ptr(operands), PP._stream()), 'dpn_bwd_points')
+
+            def launch_w():
+                L.check(lib.dpn_wgrad(args.points, cfg.prec, PP._ptr(g_out), PP._ptr(ws.saved), PP._ptr(operands), PP._ptr(partials), PP._stream()),
+                        'dpn_wgrad')
+            for _ in range(3):
+                launch_w()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                launch_w()
+            e1.record()
+            torch.cuda.synchronize()
+            w_ms = e0.elapsed_time(e1) / reps
         ach = args.points * ALG_FLOP_FWD_JAC / (k_ms * 1e-3)
         nsplit = 3 if args.prec == 'bf16x2' else 1
+        nsplit_bytes = 2 if args.prec == 'bf16x2' else 1
         out['roofline'] = {'bound': 'mfma', 'kernel': 'dpn_fwd_kernel<%d>' % (2 if args.prec == 'bf16x2' else 1),
                            'achieved': ach / 1e12, 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_BF16,
                            'traffic': PMC_TRAFFIC_FWD.get((args.prec, args.points)), 'traffic_source': 'profiles/round1_pmc_bf16_eager_step.txt',
@@ -246,6 +274,12 @@ def main():
                            'algorithmic_flop_per_point': ALG_FLOP_FWD_JAC,
                            'executed_mfma_tflops': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / 1e12,
                            'step_frac_of_peak': pts_per_s / world * ALG_FLOP_STEP / MFMA_PEAK_BF16}
+        # operands of the four products per point per net: M2+Z, V+Z1, V+G6, T1+Z0 = 3840 B of bf16 (x2 in the hi+lo mode), each read once
+        w_bytes = ws.sizes.n_pad * 6 * 3840 * nsplit_bytes
+        out['roofline_hbm_kernel'] = {'bound': 'hbm', 'kernel': 'dpn_wgrad_kernel<%d>' % (2 if args.prec == 'bf16x2' else 1),
+                                      'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                                      'frac': w_bytes / (w_ms * 1e-3) / HBM_PEAK, 'kernel_ms': w_ms, 'algorithmic_bytes': w_bytes,
+                                      'traffic': PMC_TRAFFIC_WGRAD.get((args.prec, args.points))}
         if not args.no_alt and world == 1:
             alt = 'bf16x2' if args.prec == 'bf16' else 'bf16'
             del m
