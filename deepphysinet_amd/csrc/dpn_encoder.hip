@@ -70,12 +70,28 @@ struct AttnArgs {
     int L;
     float scale;
 };
+// arguments of field b of a batch: rows [b*L, (b+1)*L) of every [batch*L][256] tensor, P block b of [batch][8][288][288]
+DEV AttnArgs attn_field(AttnArgs a, const int b) {
+    const int64_t ro = (int64_t)b * a.L * kD, po = (int64_t)b * kH * kLmax * kLmax;
+    if (a.q) a.q += ro;
+    if (a.k) a.k += ro;
+    if (a.v) a.v += ro;
+    if (a.o) a.o += ro;
+    if (a.go) a.go += ro;
+    if (a.out) a.out += ro;
+    if (a.dq) a.dq += ro;
+    if (a.dk) a.dk += ro;
+    if (a.dv) a.dv += ro;
+    if (a.P) a.P += po;
+    return a;
+}
 
 // ---------------------------------------------------------------------------------------------------- attention forward
 // grid (query tiles of 32, heads); one workgroup keeps K and V of its head in LDS, computes its 32 score rows, the row
 // softmax, the probabilities (saved for the backward pass) and the 32 x 32 output tile.
-__global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AttnArgs a = attn_field(a0, blockIdx.z);
     float (*Ks)[33] = reinterpret_cast<float (*)[33]>(smem);                                  // [288][33]
     float (*Vs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);                 // [288][33]
     float (*Qs)[33] = reinterpret_cast<float (*)[33]>(smem + 2 * kLmax * 33 * 4);             // [32][33]
@@ -226,9 +242,10 @@ DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
     });
 }
 
-__global__ __launch_bounds__(256) void dpn_attn_bwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void dpn_attn_bwd_kernel(AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (blockIdx.z == 0) attn_bwd_query_role(a, smem);
+    const AttnArgs a = attn_field(a0, blockIdx.z >> 1);        // grid.z = 2 * field + role
+    if ((blockIdx.z & 1) == 0) attn_bwd_query_role(a, smem);
     else attn_bwd_key_role(a, smem);
 }
 
@@ -312,38 +329,44 @@ __global__ __launch_bounds__(256) void dpn_ln_colsum_kernel(const float* partial
 
 
 // ---------------------------------------------------------------- data embedding pieces (model/embed.py:36-64)
-// SineCosPE of one scalar (include_input=False): out[2f] = sin(h * freq[f]), out[2f+1] = cos(h * freq[f])   (position_encoding.py:35-50)
-__global__ void dpn_lead_pe_kernel(const float* h, const float* fa, int na, float* oa, const float* fb, int nb, float* ob) {
+// SineCosPE of a scalar per field (include_input=False): out[b][2f] = sin(h[b] * freq[f]), out[b][2f+1] = cos(h[b] * freq[f])
+// (position_encoding.py:35-50), for one or two frequency tables.
+__global__ void dpn_lead_pe_kernel(const float* h, int batch, const float* fa, int na, float* oa, const float* fb, int nb, float* ob) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float hv = h[0];
-    if (i < na) { const float s = hv * fa[i]; oa[2 * i] = sinf(s); oa[2 * i + 1] = cosf(s); }
-    else if (i < na + nb) { const int j = i - na; const float s = hv * fb[j]; ob[2 * j] = sinf(s); ob[2 * j + 1] = cosf(s); }
+    if (i >= batch * (na + nb)) return;
+    const int b = i / (na + nb), j = i - b * (na + nb);
+    const float hv = h[b];
+    if (j < na) { const float s = hv * fa[j]; oa[(int64_t)b * 2 * na + 2 * j] = sinf(s); oa[(int64_t)b * 2 * na + 2 * j + 1] = cosf(s); }
+    else { const int jj = j - na; const float s = hv * fb[jj]; ob[(int64_t)b * 2 * nb + 2 * jj] = sinf(s); ob[(int64_t)b * 2 * nb + 2 * jj + 1] = cosf(s); }
 }
-// im2col of the circular k=3 convolution along the token axis: out[t][c*3 + tap] = x[(t + tap - 1) mod T][c], so that the conv is
-// out . W^T with the Conv1d weight [d_model][C][3] read in place as [d_model][3C] (no permuted copy, and the weight gradient of
-// that GEMM is already in the parameter's layout).
-__global__ __launch_bounds__(256) void dpn_im2col_circ3_kernel(const float* x, int T, int C, float* out) {
+// im2col of the circular k=3 convolution along the token axis of every field: out[b*T + t][c*3 + tap] = x[b*T + (t + tap - 1) mod T][c],
+// so that the conv is out . W^T with the Conv1d weight [d_model][C][3] read in place as [d_model][3C] (no permuted copy, and the weight
+// gradient of that GEMM is already in the parameter's layout).
+__global__ __launch_bounds__(256) void dpn_im2col_circ3_kernel(const float* x, int T, int C, int64_t total, float* out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)T * C * 3) return;
-    const int t = (int)(i / (3 * C)), r = (int)(i - (int64_t)t * 3 * C), c = r / 3, tap = r - 3 * c;
-    int ts = t + tap - 1;
+    if (i >= total) return;
+    const int64_t tg = i / (3 * C);
+    const int r = (int)(i - tg * 3 * C), c = r / 3, tap = r - 3 * c;
+    const int64_t b = tg / T;
+    int ts = (int)(tg - b * T) + tap - 1;
     ts = ts < 0 ? ts + T : (ts >= T ? ts - T : ts);
-    out[i] = x[(int64_t)ts * C + c];
+    out[i] = x[(b * T + ts) * C + c];
 }
-// x0 = cat(learnable_token, value_embedding) + positional table + lead-time embedding (embed.py:60-64, transformer_net.py:124-126).
-// The value embedding arrives as n_parts split-K partial products [n_parts][n_emb][256] (added here in a fixed order) plus the conv bias.
+// x0 = cat(learnable_token, value_embedding) + positional table + lead-time embedding (embed.py:60-64, transformer_net.py:124-126) for every
+// field of the batch.  The value embedding arrives as n_parts split-K partial products [n_parts][batch*n_emb][256] (added here in a fixed
+// order) plus the conv bias; te is [batch][256].
 __global__ __launch_bounds__(256) void dpn_embed_assemble_kernel(const float* token, int n_tok, const float* emb_parts, int n_parts, int n_emb,
-                                                                  const float* bias, const float* pos, const float* te, float* out) {
-    const int row = blockIdx.x, c = threadIdx.x;
+                                                                  int batch, const float* bias, const float* pos, const float* te, float* out) {
+    const int L = n_tok + n_emb, b = blockIdx.x / L, row = blockIdx.x - b * L, c = threadIdx.x;
     float v;
     if (row < n_tok) v = token[(int64_t)row * kD + c];
     else {
-        const int64_t o = (int64_t)(row - n_tok) * kD + c;
+        const int64_t o = ((int64_t)b * n_emb + row - n_tok) * kD + c;
         v = emb_parts[o];
-        for (int p = 1; p < n_parts; ++p) v += emb_parts[(int64_t)p * n_emb * kD + o];
+        for (int p = 1; p < n_parts; ++p) v += emb_parts[(int64_t)p * batch * n_emb * kD + o];
         v += bias ? bias[c] : 0.f;
     }
-    out[(int64_t)row * kD + c] = (v + pos[(int64_t)row * kD + c]) + te[c];
+    out[(int64_t)blockIdx.x * kD + c] = (v + pos[(int64_t)row * kD + c]) + te[(int64_t)b * kD + c];
 }
 
 __global__ __launch_bounds__(256) void dpn_sum_parts_kernel(const float* parts, int n_parts, int64_t count, int64_t zero_tail, float* out) {
@@ -362,27 +385,27 @@ static_assert(2 * kLmax * 33 * 4 + 32 * 33 * 4 + kLmax * 4 + 4 * 32 * 33 * 4 <= 
 
 extern "C" {
 
-int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, float* out, float* P, void* stream) {
-    if (!q || !k || !v || !out || !P || L <= 0 || L > kLmax) return -1;
+int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, int batch, float* out, float* P, void* stream) {
+    if (!q || !k || !v || !out || !P || L <= 0 || L > kLmax || batch <= 0 || batch > 32767) return -1;
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.out = out; a.P = P; a.L = L; a.scale = 1.0f / sqrtf((float)kE);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); once = true; }
-    hipLaunchKernelGGL(dpn_attn_fwd_kernel, dim3((L + 31) / 32, kH), dim3(256), kAttnLds, s, a);
+    hipLaunchKernelGGL(dpn_attn_fwd_kernel, dim3((L + 31) / 32, kH, batch), dim3(256), kAttnLds, s, a);
     return (int)hipGetLastError();
 }
 
-int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L,
+int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L, int batch,
                  float* dq, float* dk, float* dv, void* stream) {
-    if (!q || !k || !v || !o || !P || !go || !dq || !dk || !dv || L <= 0 || L > kLmax) return -1;
+    if (!q || !k || !v || !o || !P || !go || !dq || !dk || !dv || L <= 0 || L > kLmax || batch <= 0 || batch > 16383) return -1;
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.o = o; a.go = go; a.P = const_cast<float*>(P); a.dq = dq; a.dk = dk; a.dv = dv; a.L = L;
     a.scale = 1.0f / sqrtf((float)kE);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); once = true; }
-    hipLaunchKernelGGL(dpn_attn_bwd_kernel, dim3((L + 31) / 32, kH, 2), dim3(256), kAttnLds, s, a);
+    hipLaunchKernelGGL(dpn_attn_bwd_kernel, dim3((L + 31) / 32, kH, 2 * batch), dim3(256), kAttnLds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -414,25 +437,25 @@ int dpn_sum_parts(const float* parts, int n_parts, int64_t count, int64_t zero_t
     return (int)hipGetLastError();
 }
 
-int dpn_lead_pe(const float* h_dev, const float* freqs_a, int n_a, float* out_a, const float* freqs_b, int n_b, float* out_b, void* stream) {
-    if (!h_dev || !freqs_a || !out_a || n_a <= 0 || n_b < 0 || (n_b > 0 && (!freqs_b || !out_b))) return -1;
-    hipLaunchKernelGGL(dpn_lead_pe_kernel, dim3((n_a + n_b + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), h_dev, freqs_a, n_a,
-                       out_a, freqs_b, n_b, out_b);
+int dpn_lead_pe(const float* h_dev, int batch, const float* freqs_a, int n_a, float* out_a, const float* freqs_b, int n_b, float* out_b, void* stream) {
+    if (!h_dev || batch <= 0 || !freqs_a || !out_a || n_a <= 0 || n_b < 0 || (n_b > 0 && (!freqs_b || !out_b))) return -1;
+    hipLaunchKernelGGL(dpn_lead_pe_kernel, dim3((batch * (n_a + n_b) + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), h_dev, batch,
+                       freqs_a, n_a, out_a, freqs_b, n_b, out_b);
     return (int)hipGetLastError();
 }
 
-int dpn_im2col_circ3(const float* x, int T, int C, float* out, void* stream) {
-    if (!x || !out || T <= 0 || C <= 0) return -1;
-    const int64_t total = (int64_t)T * C * 3;
-    hipLaunchKernelGGL(dpn_im2col_circ3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, T, C, out);
+int dpn_im2col_circ3(const float* x, int T, int C, int batch, float* out, void* stream) {
+    if (!x || !out || T <= 0 || C <= 0 || batch <= 0) return -1;
+    const int64_t total = (int64_t)batch * T * C * 3;
+    hipLaunchKernelGGL(dpn_im2col_circ3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, T, C, total, out);
     return (int)hipGetLastError();
 }
 
-int dpn_embed_assemble(const float* token, int n_tok, const float* emb_parts, int n_parts, int n_emb, const float* bias, const float* pos,
+int dpn_embed_assemble(const float* token, int n_tok, const float* emb_parts, int n_parts, int n_emb, int batch, const float* bias, const float* pos,
                        const float* te, float* out, void* stream) {
-    if (!token || !emb_parts || !pos || !te || !out || n_tok < 0 || n_emb <= 0 || n_parts <= 0) return -1;
-    hipLaunchKernelGGL(dpn_embed_assemble_kernel, dim3(n_tok + n_emb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), token, n_tok, emb_parts,
-                       n_parts, n_emb, bias, pos, te, out);
+    if (!token || !emb_parts || !pos || !te || !out || n_tok < 0 || n_emb <= 0 || n_parts <= 0 || batch <= 0) return -1;
+    hipLaunchKernelGGL(dpn_embed_assemble_kernel, dim3((unsigned)(batch * (n_tok + n_emb))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), token,
+                       n_tok, emb_parts, n_parts, n_emb, batch, bias, pos, te, out);
     return (int)hipGetLastError();
 }
 

@@ -51,20 +51,24 @@ class PhysicsNet(nn.Module):
         self._meta_cache = None
 
     def field_weights(self, field_x, forecast_h, use_cache=False):
-        """Everything the point kernels need for one field sample: (heads [256, 2700], evec [6,256], statics[48]).
+        """Everything the point kernels need for one field sample: (heads [256, 2700], evec [6,256], statics[48]); for a batch of B > 1
+        field samples (field_x [B,159,2405], forecast_h [B,1,1]) heads and evec get a leading B.
 
         The twelve hyper-network heads (coord_input_fc / coord_hidden_fc of the six nets, variable_net.py:59-65) share their
         input, so they run as ONE GEMM whose output rows are [w1b1_0..5 | w2b2_0..5]; the six lead-time embeddings
         (variable_net.py:75-78) are one GEMV batch."""
         meta_out = self.encode_field(field_x, forecast_h, use_cache=use_cache)
         nets = self.nets_in_output_order()
-        if meta_out.is_cuda and meta_out.shape[0] == 1:
+        if meta_out.is_cuda:
             from ..encoder_ops import _HeadsFn, lead_time_pe
-            pe_h = lead_time_pe(forecast_h, nets[0].pe_fore_h.freq_bands)              # [192] (same encoder in every net)
-            heads, evec = _HeadsFn.apply(meta_out, pe_h,
+            B = meta_out.shape[0]
+            pe_h = lead_time_pe(forecast_h, nets[0].pe_fore_h.freq_bands)              # [B, 192] (same encoder in every net)
+            heads, evec = _HeadsFn.apply(meta_out, pe_h.reshape(B, 192),
                                          *[n.coord_input_fc.weight for n in nets], *[n.coord_hidden_fc.weight for n in nets],
                                          *[n.coord_input_fc.bias for n in nets], *[n.coord_hidden_fc.bias for n in nets],
                                          *[n.fore_h_fc.weight for n in nets], *[n.fore_h_fc.bias for n in nets])
+            if B == 1:
+                heads, evec = heads.view(256, -1), evec.view(6, 256)                   # one field: the shapes the point path takes
         else:
             m_t = torch.squeeze(meta_out, dim=0)[0:nets[0].token_num].T                # [256 channels, 256 tokens]
             w_cat = torch.cat([n.coord_input_fc.weight for n in nets] + [n.coord_hidden_fc.weight for n in nets], dim=0)

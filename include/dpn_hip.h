@@ -159,10 +159,11 @@ typedef struct DpnColsumJob { const float* partial; float* out_a; float* out_b; 
 int dpn_sgemm_batch_jobs(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs /* host array, <= 2 */, void* stream);
 
 /* FullAttention of the encoder (model/attn.py:50-68): o = softmax(q k^T / sqrt(32)) v for 8 heads x 32 over L <= 288 tokens.
- * q,k,v,o,go,dq,dk,dv: [L][256] fp32 row-major (head h = columns 32h..32h+31).  P (saved probabilities): [8][288][288] fp32.
+ * q,k,v,o,go,dq,dk,dv: [batch*L][256] fp32 row-major (field b = rows b*L.., head h = columns 32h..32h+31); attention never crosses
+ * fields.  P (saved probabilities): [batch][8][288][288] fp32.
  * The backward is one launch: query-tile blocks produce dq, key-tile blocks produce dk and dv (recomputing their columns of dS). */
-int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, float* out, float* P, void* stream);
-int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L,
+int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, int batch, float* out, float* P, void* stream);
+int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L, int batch,
                  float* dq, float* dk, float* dv, void* stream);
 
 /* out = LayerNorm_256(x + r) * gamma + beta (eps 1e-5), r may be NULL (transformer_net.py:37,44,68); saves xhat [rows][256] and rstd [rows].
@@ -182,10 +183,12 @@ int dpn_add_ln_bwd(const float* g, const float* xhat, const float* rstd, const f
  *                      value embedding is given as n_parts split-K partial products [n_parts][n_emb][256] (+ bias[256], may be NULL). */
 /* out[0 .. count) = sum_p parts[p][0 .. count) (fixed order), out[count .. count + zero_tail) = 0: joins split-K partial products. */
 int dpn_sum_parts(const float* parts, int n_parts, int64_t count, int64_t zero_tail, float* out, void* stream);
-int dpn_lead_pe(const float* h_dev, const float* freqs_a, int n_a, float* out_a, const float* freqs_b, int n_b, float* out_b, void* stream);
-int dpn_im2col_circ3(const float* x, int T, int C, float* out, void* stream);
-int dpn_embed_assemble(const float* token, int n_tok, const float* emb_parts, int n_parts, int n_emb, const float* bias, const float* pos,
-                       const float* te, float* out, void* stream);
+int dpn_lead_pe(const float* h_dev /* [batch] */, int batch, const float* freqs_a, int n_a, float* out_a /* [batch][2 n_a] */,
+                const float* freqs_b, int n_b, float* out_b, void* stream);
+int dpn_im2col_circ3(const float* x /* [batch*T][C] */, int T, int C, int batch, float* out /* [batch*T][3C] */, void* stream);
+int dpn_embed_assemble(const float* token, int n_tok, const float* emb_parts /* [n_parts][batch*n_emb][256] */, int n_parts, int n_emb, int batch,
+                       const float* bias, const float* pos, const float* te /* [batch][256] */, float* out /* [batch*(n_tok+n_emb)][256] */,
+                       void* stream);
 
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step (interface_physics.py:514-515; cfg:151-155: L2-in-gradient weight decay)
  * over a list of fp32 tensors.  The pointer arrays and `numel` are HOST arrays of length n_tensors (device pointers inside);

@@ -353,9 +353,11 @@ def test_encoder_kernels_gradients_vs_torch():
     assert torch.equal(ya, linear(xa, wa, ba))
 
 
-def test_fused_encoder_nodes_vs_torch_autograd():
+@pytest.mark.parametrize('B', [1, 3])
+def test_fused_encoder_nodes_vs_torch_autograd(B):
     """The hand-scheduled autograd nodes of encoder_ops (whole EncoderLayer, data embedding, hyper-network heads) against the reference's
-    own torch expressions (transformer_net.py:28-44, embed.py:36-64, variable_net.py:57-65,75-78) evaluated by torch autograd on the GPU."""
+    own torch expressions (transformer_net.py:28-44, embed.py:36-64, variable_net.py:57-65,75-78) evaluated by torch autograd on the GPU,
+    for one field sample and for a batch of B field samples (BASELINE configs[2]: distinct fields / lead times in one step)."""
     import torch.nn.functional as F
     from deepphysinet_amd.model import meta_net as MN
     from deepphysinet_amd.model.variable_net import VariableNet
@@ -368,58 +370,58 @@ def test_fused_encoder_nodes_vs_torch_autograd():
 
     # ---- EncoderLayer: fused node vs the per-op expression in plain torch
     layer = MN.EncoderLayer(MN.AttentionLayer(MN.FullAttention(False), 256, 8), 256, 256, activation='gelu').to(dev)
-    x = torch.randn(1, 287, 256, device=dev, requires_grad=True)
+    x = torch.randn(B, 287, 256, device=dev, requires_grad=True)
     y, _ = layer(x)
 
     def layer_ref(x):
         a = layer.attention
-        q, k, v = (F.linear(x, m.weight, m.bias).view(1, 287, 8, 32).transpose(1, 2) for m in (a.query_projection, a.key_projection, a.value_projection))
-        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, 287, 256)
+        q, k, v = (F.linear(x, m.weight, m.bias).view(B, 287, 8, 32).transpose(1, 2) for m in (a.query_projection, a.key_projection, a.value_projection))
+        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, 287, 256)
         x1 = layer.norm1(x + F.linear(o, a.out_projection.weight, a.out_projection.bias))
         h = F.gelu(F.linear(x1, layer.conv1.weight.squeeze(-1), layer.conv1.bias))
         return layer.norm2(x1 + F.linear(h, layer.conv2.weight.squeeze(-1), layer.conv2.bias))
     y_ref = layer_ref(x)
-    assert rel(y, y_ref) < 2e-5
+    assert y.shape == y_ref.shape and rel(y, y_ref) < 2e-5
     gy = torch.randn_like(y)
     names = ['x'] + [n_ for n_, _ in layer.named_parameters()]
     params = [x] + list(layer.parameters())
     for n_, a_, b_ in zip(names, torch.autograd.grad(y, params, gy), torch.autograd.grad(y_ref, params, gy)):
         if n_ == 'attention.key_projection.bias':
             continue                                            # mathematically zero (softmax shift invariance): pure rounding noise
-        assert rel(a_, b_) < 3e-4, (n_, rel(a_, b_))
+        assert a_.shape == b_.shape and rel(a_, b_) < 3e-4, (n_, rel(a_, b_))
 
     # ---- DataEmbedding + learnable tokens: fused node vs Conv1d(circular) + cat + pos + time embedding
     emb = MN.DataEmbedding(2405, 256).to(dev)
     token = torch.rand(1, 128, 256, device=dev, requires_grad=True)
-    field = torch.randn(1, 159, 2405, device=dev)
-    h = torch.full((1, 1, 1), 0.4, device=dev)
+    field = torch.randn(B, 159, 2405, device=dev)
+    h = torch.linspace(0.1, 0.9, B, device=dev).view(B, 1, 1)
     e = emb(field, h, token)
     conv = emb.value_embedding.tokenConv
-    e_ref = torch.cat([token, conv(field.permute(0, 2, 1)).transpose(1, 2)], dim=1)
+    e_ref = torch.cat([token.expand(B, -1, -1), conv(field.permute(0, 2, 1)).transpose(1, 2)], dim=1)
     e_ref = e_ref + emb.position_embedding(e_ref) + emb.time_embending(h)
     assert e.shape == e_ref.shape and rel(e, e_ref) < 1e-5
     ge = torch.randn_like(e)
     for a_, b_ in zip(torch.autograd.grad(e, [token, conv.weight, conv.bias], ge), torch.autograd.grad(e_ref, [token, conv.weight, conv.bias], ge)):
         assert a_.shape == b_.shape and rel(a_, b_) < 1e-4
-    assert torch.equal(lead_time_pe(h, emb.time_embending.freq_bands), emb.time_embending(h).reshape(-1))     # same sin/cos, same order
+    assert torch.equal(lead_time_pe(h, emb.time_embending.freq_bands).reshape(-1), emb.time_embending(h).reshape(-1))     # same sin/cos, same order
 
     # ---- hyper-network heads + lead-time embeddings of six VariableNets
     nets = [VariableNet(256, 192, 256).to(dev) for _ in range(6)]
-    meta = torch.randn(1, 287, 256, device=dev, requires_grad=True)
-    pe_h = lead_time_pe(h, nets[0].pe_fore_h.freq_bands)
+    meta = torch.randn(B, 287, 256, device=dev, requires_grad=True)
+    pe_h = lead_time_pe(h, nets[0].pe_fore_h.freq_bands).reshape(B, 192)
     args = ([n.coord_input_fc.weight for n in nets] + [n.coord_hidden_fc.weight for n in nets] + [n.coord_input_fc.bias for n in nets]
             + [n.coord_hidden_fc.bias for n in nets] + [n.fore_h_fc.weight for n in nets] + [n.fore_h_fc.bias for n in nets])
     heads, evec = _HeadsFn.apply(meta, pe_h, *args)
-    m_t = meta[0, :256].T
-    heads_ref = torch.cat([n.coord_input_fc(m_t) for n in nets] + [n.coord_hidden_fc(m_t) for n in nets], dim=1)
-    evec_ref = torch.stack([n.fore_h_fc(n.pe_fore_h(h.squeeze(-1)))[0] for n in nets])
-    assert heads.shape == (256, 2700) and rel(heads, heads_ref) < 1e-5 and rel(evec, evec_ref) < 1e-5
+    heads_ref = torch.stack([torch.cat([n.coord_input_fc(meta[f, :256].T) for n in nets] + [n.coord_hidden_fc(meta[f, :256].T) for n in nets], dim=1)
+                             for f in range(B)])
+    evec_ref = torch.stack([torch.stack([n.fore_h_fc(n.pe_fore_h(h[f].reshape(1, 1)))[0] for n in nets]) for f in range(B)])
+    assert heads.shape == (B, 256, 2700) and rel(heads, heads_ref) < 1e-5 and rel(evec, evec_ref) < 1e-5
     gh, gv = torch.randn_like(heads), torch.randn_like(evec)
     g1 = torch.autograd.grad([heads, evec], [meta] + args, [gh, gv])
     g2 = torch.autograd.grad([heads_ref, evec_ref], [meta] + args, [gh, gv])
     for a_, b_ in zip(g1, g2):
         assert a_.shape == b_.shape and rel(a_, b_) < 1e-4
-    assert float(g1[0][0, 256:].abs().max()) == 0.0            # tokens 256..286 feed no VariableNet (variable_net.py:58)
+    assert float(g1[0][:, 256:].abs().max()) == 0.0            # tokens 256..286 feed no VariableNet (variable_net.py:58)
 
 
 def test_full_grid_step_is_bitwise_deterministic():
