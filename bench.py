@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--points', type=int, default=257 * 145)
+    ap.add_argument('--leads', type=int, default=1, help='field samples per step (BASELINE configs[2]: 61); default 1 = configs[1]')
     ap.add_argument('--prec', default=os.environ.get('DPN_PREC', 'bf16'), choices=['bf16', 'bf16x2'])
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -108,6 +109,13 @@ def main():
         return m, opt
 
     batch = synth_batch(args.points, dev, seed=1 + rank)
+    if args.leads > 1:                             # configs[2]: distinct field samples / lead times, one step
+        many = [synth_batch(args.points, dev, seed=1000 * (1 + rank) + b) for b in range(args.leads)]
+        lead = {k: torch.stack([m_[k].reshape(-1) for m_ in many]) for k in ('x', 'y', 't', 'f')}
+        lead['coord_data'] = torch.stack([m_['coord_data'] for m_ in many])
+        lead['field_data'] = torch.cat([m_['field_data'] for m_ in many], dim=0)
+        lead['forecast_h'] = torch.arange(args.leads, device=dev, dtype=torch.float32).mul_(24.0 / 360.0).view(-1, 1, 1)
+        del many
     crit = torch.nn.MSELoss()
     sync = D.GradientAllReduce() if world > 1 else None
 
@@ -123,8 +131,12 @@ def main():
 
         def compute():
             opt.zero_grad(set_to_none=True)
-            loss = m.place_one_batch(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'],
-                                     batch['forecast_h'], crit, lf, 0, 0, dev)
+            if args.leads > 1:
+                loss, _ = m.place_lead_batch(lead['x'], lead['y'], lead['t'], lead['f'], lead['field_data'], lead['coord_data'],
+                                             lead['forecast_h'], crit, lf)
+            else:
+                loss = m.place_one_batch(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'],
+                                         batch['forecast_h'], crit, lf, 0, 0, dev)
             loss.backward(one)                         # persistent seed: no ones_like fill per step
             return loss
 
@@ -193,15 +205,18 @@ def main():
 
     m, dt, graphed = run(args.prec, args.steps, args.warmup, not args.no_graph)
     ms_per_step = dt / args.steps * 1e3
-    pts_per_s = args.points * world * args.steps / dt
+    pts_per_s = args.points * args.leads * world * args.steps / dt
 
     out = {
         'metric': 'collocation-points/sec (fwd+PDE-Jacobian+bwd)', 'value': pts_per_s, 'unit': 'points/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate' if args.prec == 'bf16' else 'bf16x2 (hi+lo split bf16 MFMA operands), fp32 accumulate',
         'data': 'synthetic',
-        'config': {'workload': 'configs[1]: 0.25deg grid 257x145 = %d collocation points/GPU/step, one field sample, six PDE residual losses, '
-                               'encoder+hyper-net+fwd+Jacobian+bwd+clip+Adam' % args.points,
+        'config': {'workload': ('configs[1]: 0.25deg grid 257x145 = %d collocation points/GPU/step, one field sample, six PDE residual losses, '
+                                'encoder+hyper-net+fwd+Jacobian+bwd+clip+Adam' % args.points) if args.leads == 1 else
+                               ('configs[2]: %d forecast-lead field samples x %d collocation points per GPU per step (one batched encoder pass, '
+                                'point kernels field after field), six PDE residual losses, fwd+Jacobian+bwd+clip+Adam' % (args.leads, args.points)),
+                   'leads': args.leads,
                    'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world},
         'algorithmic_tflops_step': pts_per_s * ALG_FLOP_STEP / 1e12,
     }
@@ -286,7 +301,7 @@ def main():
             torch.cuda.empty_cache()
             _, dt2, _ = run(alt, max(5, args.steps // 3), 3, not args.no_graph)
             st2 = max(5, args.steps // 3)
-            out['other_precision_mode'] = {'mode': alt, 'value': args.points * st2 / dt2, 'ms_per_step': dt2 / st2 * 1e3}
+            out['other_precision_mode'] = {'mode': alt, 'value': args.points * args.leads * st2 / dt2, 'ms_per_step': dt2 / st2 * 1e3}
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(args.cpu_threads or min(32, os.cpu_count() or 1))   # more threads only add OpenMP overhead on these small ops
             v, secs = cpu_baseline(args.cpu_sample, seed=1)

@@ -184,6 +184,21 @@ class InterfacePhysics(nn.Module):
             print('%s:' % prefix + ','.join('%s:%f' % (n_, v_) for n_, v_ in zip(names, vals)))
         return train_loss.float()
 
+    def place_lead_batch(self, x, y, t, f, field_data, input_data, forecast_h, criterion, loss_factor, reduction='mean'):
+        """BASELINE configs[2]: B field samples (e.g. the 61 forecast leads, physics_dataset.py:173-174) in ONE step.  x, y, t, f: [B, N];
+        field_data [B, 159, 2405]; input_data [B, N, 6]; forecast_h [B, 1, 1].  Equals place_one_batch applied to every sample
+        (:271-320), the B totals averaged ('mean') or added ('sum'); the encoder runs once over all B samples and the point kernels
+        field after field.  Returns (loss, terms [B, 6])."""
+        from ..point_path import pde_losses_batch
+        self._check_pde_criterion(criterion)
+        cfg = self.point_config(loss_factor)
+        heads, evec, statics = self.physics_net.field_weights(field_data, forecast_h)
+        B = field_data.shape[0]
+        heads, evec = heads.reshape(B, 256, -1), evec.reshape(B, 6, 256)
+        terms, totals = pde_losses_batch(cfg, x, y, t, f, input_data, heads, evec, statics)
+        loss = totals.sum() if reduction == 'sum' else totals.mean()
+        return loss.float(), terms
+
     def data_loss(self, x, y, t, field_data, input_data, labels, forecast_h, margin_factor=None, beta=0.1, use_cache=False):
         """Data ("margin") loss of the step body (:464-474): mean SmoothL1(beta) over [N,6] times margin_factor."""
         self.point_config()

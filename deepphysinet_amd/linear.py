@@ -93,15 +93,17 @@ class _MultiLinearFn(torch.autograd.Function):
                 N0 = ws[0].shape[0]
                 assert all(w.shape[0] == N0 for w in ws)
                 problems.append(_problem(M, K, N0, [(g, N0, w, K) for g, w in zip(gs, ws)], gx, K, 0, 0))      # gx = sum_i g_i W_i
+        from .encoder_ops import _wgrad
         gws, gbs = [], []
         for i, (g, w) in enumerate(zip(gs, ws)):
             N = w.shape[0]
             gw = torch.empty((N, K), dtype=torch.float32, device=dev)
             gb = torch.empty((N,), dtype=torch.float32, device=dev) if ctx.has_bias[i] else None
-            problems.append(_problem(N, K, M, [(g, N, x2, K)], gw, K, 1, 0, asum=gb))                        # gw = g^T x ; gb = sum_m g
+            _wgrad(problems, N, K, M, g, N, x2, K, gw, gb)             # gw = g^T x ; gb = sum_m g (split-K kernel when M is a batch of fields)
             gws.append(gw)
             gbs.append(gb)
-        _launch(problems)
+        if problems:
+            _launch(problems)
         return (gx.reshape(ctx.x_shape) if gx is not None else None, *gws, *gbs)
 
 

@@ -135,8 +135,9 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     return out_n, jac_n
 
 
-def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics):
-    """Weight gradients from per-point cotangents.  Returns (g_heads [256,2700], g_evec [6,256], [48 static grads])."""
+def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics, into=None):
+    """Weight gradients from per-point cotangents.  Returns (g_heads [256,2700], g_evec [6,256], [48 static grads]); `into` = the same
+    triple preallocated by the caller (a batch of fields writes each field's gradients side by side)."""
     lib = L.load()
     n = coord_data.shape[0]
     dev = coord_data.device
@@ -147,9 +148,12 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
                                _ptr(ws.packed), cfg.prec, _ptr(g_out), _ptr(g_jxi), _ptr(ws.saved), _ptr(operands), _stream()),
             'dpn_bwd_points')
     L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
-    g_heads = torch.empty((256, HEADS_COLS), dtype=torch.float32, device=dev)
-    g_evec = torch.empty((6, 256), dtype=torch.float32, device=dev)
-    g_stat = [torch.empty(STATIC_SHAPES[j], dtype=torch.float32, device=dev) for _ in range(6) for j in range(8)]
+    if into is None:
+        g_heads = torch.empty((256, HEADS_COLS), dtype=torch.float32, device=dev)
+        g_evec = torch.empty((6, 256), dtype=torch.float32, device=dev)
+        g_stat = [torch.empty(STATIC_SHAPES[j], dtype=torch.float32, device=dev) for _ in range(6) for j in range(8)]
+    else:
+        g_heads, g_evec, g_stat = into
     garr = _net_ptrs(g_heads, g_evec, g_stat, cls=L.DpnNetGradPtrs)
     L.check(lib.dpn_wgrad_finish(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, _stream()), 'dpn_wgrad_finish')
     return g_heads, g_evec, g_stat
@@ -229,6 +233,81 @@ class _PdeLossFn(torch.autograd.Function):
         nets = _net_ptrs(hd_, ev_, st)
         ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st)
         return (None, None, None, None, None, None, ghd, gev, *gst)
+
+
+class _PdeLossBatchFn(torch.autograd.Function):
+    """BASELINE configs[2]: B field samples (distinct field / lead time => distinct hyper-network weights) with N collocation points each
+    in ONE step.  losses [B, 6] and totals [B]; heads [B, 256, 2700], evec [B, 6, 256], point tensors [B, N(,6)].  The point kernels run
+    field after field (each launch already fills the chip); the static-parameter gradients of the fields are written side by side and
+    added in a fixed order by one dpn_sum_parts launch, so nothing is accumulated through autograd."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, y, t, f, coord_data, heads, evec, *statics):
+        for nm, v in (('x', x), ('coord_data', coord_data), ('heads', heads)):
+            _require_gpu(v, nm)
+        lib = L.load()
+        B, n = coord_data.shape[0], coord_data.shape[1]
+        x_, y_, t_, f_ = (_f32c(v).reshape(B, n) for v in (x, y, t, f))
+        cd_, hd_, ev_ = _f32c(coord_data), _f32c(heads), _f32c(evec)
+        st = [_f32c(s) for s in statics]
+        dev = cd_.device
+        need_grad = any(v.requires_grad for v in (heads, evec) + tuple(statics))
+        losses7 = torch.empty((B, 7), dtype=torch.float32, device=dev)
+        sums = torch.empty(((n + 255) // 256) * 6, dtype=torch.float64, device=dev)
+        geo, ph = cfg.geometry(), cfg.physics()
+        fields = []
+        for b in range(B):
+            ws = _Workspace(n, cfg.prec, dev)
+            nets = _net_ptrs(hd_[b], ev_[b], st)
+            out_n, jac_n = _forward_points(cfg, ws, nets, x_[b], y_[b], t_[b], None, cd_[b], want_jac=True, want_saved=need_grad)
+            L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_[b]), n, ctypes.byref(geo), ctypes.byref(ph), None, None, _ptr(sums),
+                                     None, None, _stream()), 'dpn_residual')
+            L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses7[b]), _stream()), 'dpn_residual_finish')
+            fields.append((ws, out_n, jac_n))
+        ctx.cfg, ctx.fields = cfg, fields
+        ctx.keep = (x_, y_, t_, f_, cd_, hd_, ev_, st)
+        ctx.set_materialize_grads(False)
+        return losses7[:, :6], losses7[:, 6]
+
+    @staticmethod
+    def backward(ctx, g_losses, g_total):
+        lib = L.load()
+        cfg = ctx.cfg
+        x_, y_, t_, f_, cd_, hd_, ev_, st = ctx.keep
+        B, n = cd_.shape[0], cd_.shape[1]
+        dev = cd_.device
+        if g_losses is None and g_total is None:
+            return (None,) * (8 + len(st))
+        gl = None if g_losses is None else _f32c(g_losses)
+        gt = None if g_total is None else _f32c(g_total)
+        g_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
+        g_jxi = torch.empty((n, 6, 3), dtype=torch.float32, device=dev)
+        g_heads = torch.empty((B, 256, HEADS_COLS), dtype=torch.float32, device=dev)
+        g_evec = torch.empty((B, 6, 256), dtype=torch.float32, device=dev)
+        numels = [int(torch.Size(STATIC_SHAPES[j]).numel()) for _ in range(6) for j in range(8)]
+        starts = [0]
+        for m_ in numels:
+            starts.append(starts[-1] + m_)
+        flat = torch.empty((B, starts[-1]), dtype=torch.float32, device=dev)
+        geo, ph = cfg.geometry(), cfg.physics()
+        for b in range(B):
+            ws, out_n, jac_n = ctx.fields[b]
+            L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_[b]), n, ctypes.byref(geo), ctypes.byref(ph),
+                                     None if gl is None else _ptr(gl[b]), None if gt is None else _ptr(gt[b:b + 1]), None,
+                                     _ptr(g_out), _ptr(g_jxi), _stream()), 'dpn_residual(grad)')
+            nets = _net_ptrs(hd_[b], ev_[b], st)
+            g_stat = [flat[b, starts[i]:starts[i + 1]].view(STATIC_SHAPES[i % 8]) for i in range(48)]
+            _backward_points(cfg, ws, nets, x_[b], y_[b], t_[b], None, cd_[b], g_out, g_jxi, st, into=(g_heads[b], g_evec[b], g_stat))
+            ctx.fields[b] = None                                  # this field's saved state is no longer needed
+        total = torch.empty(starts[-1], dtype=torch.float32, device=dev)
+        L.check(lib.dpn_sum_parts(_ptr(flat), B, starts[-1], 0, _ptr(total), _stream()), 'dpn_sum_parts')
+        gst = [total[starts[i]:starts[i + 1]].view(STATIC_SHAPES[i % 8]) for i in range(48)]
+        return (None, None, None, None, None, None, g_heads, g_evec, *gst)
+
+
+def pde_losses_batch(cfg: PointConfig, x, y, t, f, coord_data, heads, evec, statics):
+    """(losses [B,6], totals [B]) for B field samples with N points each; tensors carry a leading B (see _PdeLossBatchFn)."""
+    return _PdeLossBatchFn.apply(cfg, x, y, t, f, coord_data, heads, evec, *statics)
 
 
 def point_fields(cfg: PointConfig, coord_data, heads, evec, statics, x=None, y=None, t=None, pe_in=None):

@@ -440,3 +440,44 @@ def test_full_grid_step_is_bitwise_deterministic():
     assert torch.equal(outs[0][0], outs[1][0])
     for a_, b_ in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a_, b_)
+
+
+def test_config2_lead_batch_in_one_step_equals_the_loop():
+    """BASELINE configs[2] as ONE step: place_lead_batch over B field samples (batched encoder, per-field point kernels, fixed-order
+    sums of the per-field parameter gradients) against (i) the CPU oracle per field and (ii) the same samples pushed one by one through
+    place_one_batch -- losses and all parameter gradients."""
+    B, N = 5, 256                                            # 5 x 287 rows: the batched encoder takes the long-reduction (split-K) path
+    m = _model('bf16x2')
+    lf = m.train_cfg['losses']['loss_factor']
+    crit = torch.nn.MSELoss()
+    samples = [synthetic_inputs(N, GEO.lon, GEO.lat, GEO.dx, GEO.dy, tag='lead%d' % b, forecast_h=24.0 * b / 360.0) for b in range(B)]
+    g = [_gpu(s_) for s_ in samples]
+    stack = lambda k: torch.stack([g_[k].reshape(-1) if g_[k].dim() == 2 and g_[k].shape[1] == 1 else g_[k] for g_ in g])
+    x, y, t, f = (stack(k) for k in ('x', 'y', 't', 'f'))
+    field = torch.cat([g_['field_data'] for g_ in g], dim=0)
+    cd = torch.stack([g_['coord_data'] for g_ in g])
+    fh = torch.cat([g_['forecast_h'] for g_ in g], dim=0)
+    m.physics_net.zero_grad(set_to_none=True)
+    loss, terms = m.place_lead_batch(x, y, t, f, field, cd, fh, crit, lf, reduction='sum')
+    loss.backward()
+    got = {n_: p.grad.detach().clone() for n_, p in m.physics_net.named_parameters()}
+    assert terms.shape == (B, 6)
+    # (i) oracle, field by field
+    for b in range(B):
+        ref = _oracle(samples[b], want_grads=False)
+        rel = np.abs(terms[b].detach().cpu().numpy() - ref['parts']) / np.abs(ref['parts'])
+        assert np.all(rel <= 2e-3) and np.median(rel) <= 5e-5, (b, rel)
+    # (ii) the loop of single-field steps on the same kernels
+    m.physics_net.zero_grad(set_to_none=True)
+    total = 0.0
+    for b in range(B):
+        l_b = m.place_one_batch(g[b]['x'], g[b]['y'], g[b]['t'], g[b]['f'], g[b]['field_data'], g[b]['coord_data'], g[b]['forecast_h'], crit, lf, 0, 0,
+                                _dev())
+        l_b.backward()
+        total += float(l_b.detach())
+    assert abs(float(loss.detach()) - total) <= 1e-5 * abs(total)
+    for n_, p in m.physics_net.named_parameters():
+        if n_.endswith('key_projection.bias'):
+            continue
+        a_, b_ = got[n_], p.grad
+        assert float((a_ - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-30, n_
