@@ -139,8 +139,15 @@ DEV void pack_vectors(const PackArgs& a, const int net) {
     const int idx = threadIdx.x;
     const int h = idx >> 7, T = (idx >> 4) & 7, r = idx & 15;
     const int ch = 32 * T + drow32(r, h);
-    float u = 0.f;
-    for (int o = 0; o < kHidden; ++o) u = fmaf(P.wo[o], P.W2[o * kHidden + ch], u);
+    // u = W2^T wo: 256 independent row reads per thread -- sixteen of them in flight at a time (the loop is latency-bound otherwise),
+    // partial sums joined in a fixed order
+    float up[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int o = 0; o < kHidden; o += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) up[j] = fmaf(P.wo[o + j], P.W2[(o + j) * kHidden + ch], up[j]);
+    }
+    const float u = (up[0] + up[1]) + (up[2] + up[3]);
     vec[kVecB1 * 256 + idx] = P.w1b1[ch * P.ld_w1b1 + kPe];
     vec[kVecCvec * 256 + idx] = P.w2b2[ch * P.ld_w2b2 + kHidden] + P.bd[ch] + P.evec[ch];
     vec[kVecBf1 * 256 + idx] = P.bf1[ch];

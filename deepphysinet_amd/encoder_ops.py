@@ -95,13 +95,32 @@ def add_layer_norm(x, r, norm: torch.nn.LayerNorm):
 
 
 def _wgrad(batch, N, K, n, g, ldg, x, ldx, gw, gb):
-    """gw[N][K] = g^T x over the n rows (gb = column sums of g).  Short reductions (one field: n = 287) join the GEMM launch `batch`;
-    long ones (a batch of fields: n = B * 287) take the two-pass split-K kernel, which spreads the reduction over the whole chip."""
-    from .linear import _problem, _sgemm_splitk
+    """gw[N][K] = g^T x over the n rows (gb = column sums of g).  Short reductions (one field: n = 287) join the GEMM launch `batch`.
+    Long ones (a batch of fields: n = B * 287) are cut into row slices that run side by side as problems of their own MFMA launch;
+    the slice results are added in a fixed order by dpn_sum_parts."""
+    from .linear import _launch, _problem
     if n < 1024:
         batch.append(_problem(N, K, n, [(g, ldg, x, ldx)], gw, K, 1, 0, asum=gb))
-    else:
-        _sgemm_splitk(1, 0, N, K, n, g, ldg, x, ldx, gw, K, asum=gb)
+        return
+    S = min(16, (n + 1023) // 1024)
+    rows = (n + S - 1) // S
+    stride = N * K + N                                           # per slice: the weight block, then the bias sums
+    parts = torch.empty((S, stride), dtype=torch.float32, device=g.device)
+    out = torch.empty(stride, dtype=torch.float32, device=g.device)
+    problems = []
+    for s_ in range(S):
+        r0, r1 = s_ * rows, min(n, (s_ + 1) * rows)
+        q = _problem(N, K, r1 - r0, [(g, ldg, x, ldx)], parts, K, 1, 0, asum=parts if gb is not None else None)
+        base = parts.data_ptr() + s_ * stride * 4
+        q.A[0], q.B[0], q.C = g.data_ptr() + r0 * ldg * 4, x.data_ptr() + r0 * ldx * 4, base
+        if gb is not None:
+            q.asum = base + N * K * 4
+        problems.append(q)
+    _launch(problems)
+    L.check(L.load().dpn_sum_parts(_p(parts), S, stride if gb is not None else N * K, 0, _p(out), _s()), 'dpn_sum_parts')
+    gw.copy_(out[:N * K].view(N, K))                             # the callers own gw / gb (they are returned as gradients)
+    if gb is not None:
+        gb.copy_(out[N * K:])
 
 
 class _EncoderLayerFn(torch.autograd.Function):
