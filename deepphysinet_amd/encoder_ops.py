@@ -9,7 +9,11 @@ from . import _lib as L
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('deepphysinet_amd: a %s tensor on %s was passed to a HIP kernel; there is no CPU fallback' % (tuple(t.shape), t.device))
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _s():

@@ -13,7 +13,11 @@ from . import _lib as L
 
 
 def _p(t):
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('deepphysinet_amd: a %s tensor on %s was passed to a HIP kernel; there is no CPU fallback' % (tuple(t.shape), t.device))
+    return t.data_ptr()
 
 
 def _problem(M, N, K, terms, C, ldc, ta, tb, bias=None, asum=None, epi=0, aux=None, aux_out=None):
@@ -21,9 +25,9 @@ def _problem(M, N, K, terms, C, ldc, ta, tb, bias=None, asum=None, epi=0, aux=No
     q.epi, q.aux, q.aux_out = epi, _p(aux), _p(aux_out)
     for i, term in enumerate(terms):                 # (A, lda, B, ldb) or (A, lda, B, ldb, K_t) when the terms reduce over different lengths
         A, lda, B, ldb = term[:4]
-        q.A[i], q.lda[i], q.B[i], q.ldb[i] = A.data_ptr(), lda, B.data_ptr(), ldb
+        q.A[i], q.lda[i], q.B[i], q.ldb[i] = _p(A), lda, _p(B), ldb
         q.k_term[i] = term[4] if len(term) > 4 else 0
-    q.bias, q.C, q.asum = _p(bias), C.data_ptr(), _p(asum)
+    q.bias, q.C, q.asum = _p(bias), _p(C), _p(asum)
     q.M, q.N, q.K, q.ldc, q.ta, q.tb, q.nterms = M, N, K, ldc, ta, tb, len(terms)
     return q
 
@@ -45,7 +49,7 @@ def _sgemm_splitk(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, asum=None)
     lib = L.load()
     ws_bytes = 32 * (M * N + M) * 4
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=C.device)
-    L.check(lib.dpn_sgemm(ta, tb, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, _p(bias), _p(asum), 0, ws.data_ptr(),
+    L.check(lib.dpn_sgemm(ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias), _p(asum), 0, ws.data_ptr(),
                           ws_bytes, torch.cuda.current_stream().cuda_stream), 'dpn_sgemm')
 
 

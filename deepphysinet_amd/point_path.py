@@ -84,7 +84,12 @@ def _stream() -> int:
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device pointer for the C ABI.  Every tensor handed to the library goes through here: a host tensor raises instead of reaching a kernel."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('deepphysinet_amd: a %s tensor on %s was passed to a HIP kernel; there is no CPU fallback' % (tuple(t.shape), t.device))
+    return ctypes.c_void_p(t.data_ptr())
 
 
 HEADS_COLS = 6 * 193 + 6 * 257          # one GEMM output row: [w1b1 of net 0..5 | w2b2 of net 0..5]

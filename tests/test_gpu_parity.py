@@ -481,3 +481,22 @@ def test_config2_lead_batch_in_one_step_equals_the_loop():
             continue
         a_, b_ = got[n_], p.grad
         assert float((a_ - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-30, n_
+
+
+def test_error_behaviour_matches_the_reference_convention():
+    """Plain Python exceptions (the reference's convention, interface/build.py:20): RuntimeError for what the kernels cannot take,
+    NotImplementedError for unsupported configuration -- never a silent fallback."""
+    import deepphysinet_amd as dpn
+    m = _model('bf16x2')
+    g = _gpu(synthetic_inputs(64, GEO.lon, GEO.lat, GEO.dx, GEO.dy))
+    lf = m.train_cfg['losses']['loss_factor']
+    with pytest.raises(NotImplementedError):
+        m.place_one_batch(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'], torch.nn.L1Loss(), lf, 0, 0, _dev())
+    with pytest.raises(RuntimeError):                       # zero collocation points: the C ABI refuses n <= 0
+        e = torch.empty(0, device=_dev())
+        m.place_one_batch(e, e, e, e, g['field_data'], torch.empty(0, 6, device=_dev()), g['forecast_h'], torch.nn.MSELoss(), lf, 0, 0, _dev())
+    with pytest.raises(RuntimeError):                       # host tensors: no CPU fallback
+        heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
+        dpn.pde_fields_and_jacobian(m.point_config(), g['x'].cpu(), g['y'].cpu(), g['t'].cpu(), g['coord_data'].cpu(), heads, evec, statics)
+    with pytest.raises(ValueError):
+        m.predict_grid(g['field_data'], g['x'], g['y'], g['t'], g['coord_data'], g['forecast_h'])      # needs all lon x lat nodes
