@@ -1,4 +1,7 @@
-"""Autograd wrappers of the encoder kernels in libdpn_hip.so (csrc/dpn_encoder.hip): attention and add + LayerNorm.
+"""Autograd nodes of the grid encoder on libdpn_hip.so (csrc/dpn_encoder.hip, dpn_sgemm_batch): the data embedding, a whole
+EncoderLayer and the hyper-network heads as single nodes with hand-scheduled backward passes (a dependent kernel costs >= 4.5 us on
+this machine whatever it does, so the schedule minimises the number of launches on the dependency chain), for one field sample or
+a batch of them; plus per-op wrappers (attention, add + LayerNorm) for modules that do not fit the fused nodes.
 CPU tensors take the equivalent torch expressions (encoder-math tests only)."""
 import ctypes
 

@@ -1,8 +1,10 @@
-"""y = x W^T + b for the per-field tensors (encoder, hyper-network heads) on the library's own small fp32 GEMMs.
+"""y = x W^T + b for the per-field tensors (encoder, hyper-network heads) on the library's own exact-fp32 MFMA GEMM, and the
+problem / launch helpers the encoder nodes (encoder_ops.py) build their launches from.
 
-At these shapes (M <= 288 tokens, K = N = 256) library GEMMs are latency-bound (19-75 us each on MI355X, see
-profiles/); dpn_sgemm_batch runs the independent GEMMs of one layer step in a single launch (the three q/k/v projections;
-the input- and weight-gradient GEMMs of a linear).  CPU tensors take torch's F.linear (tests of the encoder math only).
+At these shapes (M = 287 tokens, K = N = 256) a GEMM is latency-bound whatever computes it (rocBLAS / hipBLASLt through torch:
+19-75 us each on MI355X); dpn_sgemm_batch runs the independent GEMMs of one step of the layer schedule in a single launch (the
+three q/k/v projections; the input- and weight-gradient GEMMs of a linear; ride-along LayerNorm parameter sums) in 8-25 us.
+CPU tensors take torch's F.linear (tests of the encoder math only).
 """
 import ctypes
 
