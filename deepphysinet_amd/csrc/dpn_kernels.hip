@@ -642,13 +642,19 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
                 const int r = 4 * q + i;
                 const float p0 = acc[T][r], p1 = acc[T][r + 1];
                 const bool on0 = p0 > 0.f, on1 = p1 > 0.f;
-                adot = fmaf(relu1(p0), uu[i], adot);
-                adot = fmaf(relu1(p1), uu[i + 1], adot);
-                frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, on0 ? uu[i] : 0.f, on1 ? uu[i + 1] : 0.f);
+                const float t0 = on0 ? uu[i] : 0.f, t1 = on1 ? uu[i + 1] : 0.f;      // t2 = m2 (.) u
+                adot = fmaf(p0, t0, adot);                                           // relu(p) * u == p * (m2 * u): no separate max
+                adot = fmaf(p1, t1, adot);
+                frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, t0, t1);
                 const u32 mw = (on0 ? 0x3F80u : 0u) | (on1 ? 0x3F800000u : 0u);
                 if (r < 8) mk0.w[0][(r & 7) >> 1] = mw; else mk1.w[0][(r & 7) >> 1] = mw;
             }
         }
+        // pin t2 and the mask words in VGPRs HERE: left alone, the scheduler keeps the 128 compare results as lane masks in SGPRs
+        // (spilling them through v_writelane / v_readlane) and materialises every select in one 1000-instruction block after the GEMM
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) asm volatile("" : "+v"(actA[2 * T].w[s2]), "+v"(actA[2 * T + 1].w[s2]));
+        asm volatile("" : "+v"(mk0.w[0]), "+v"(mk1.w[0]));
         if (save) store_tile_k<1, 1>(sv.M2, net, tile32, T, L, mk0, mk1, partial);
     };
 #pragma unroll
