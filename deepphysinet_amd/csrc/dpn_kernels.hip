@@ -409,17 +409,19 @@ DEV void load_pe3(const float* row, int h, Frag<NS>* act, float g) {
 
 // data PE fragments (SineCosPE(6,16) of coord_data, variable_net.py:73), scaled by g
 template <int NS>
+DEV void build_pe6_ks(const Lane& L, const float* cd6, Frag<NS>* act, float g, const int ks) {
+    const float v = cd6[ks >> 1];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float s, co;
+        sincos_t<NS>(v * L.fr16[4 * (ks & 1) + p], s, co);
+        frag_set2<NS>(act[ks], p, g * s, g * co);
+    }
+}
+template <int NS>
 DEV void build_pe6(const Lane& L, const float* cd6, Frag<NS>* act, float g) {
 #pragma unroll
-    for (int ks = 0; ks < 12; ++ks) {
-        const float v = cd6[ks >> 1];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float s, co;
-            sincos_t<NS>(v * L.fr16[4 * (ks & 1) + p], s, co);
-            frag_set2<NS>(act[ks], p, g * s, g * co);
-        }
-    }
+    for (int ks = 0; ks < 12; ++ks) build_pe6_ks<NS>(L, cd6, act, g, ks);
 }
 
 // The permuted bias vectors live in LDS (filled once, before any DMA is in flight) and are read with inline-asm ds_read_b128
@@ -613,13 +615,25 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     };
     {
         // pass A: all eight tiles of w2 . h1 (h1 = actA dies here); pass B: + Wd . pe6, epilogue one tile late
+        // the data PE (96 sin/cos + packing per lane) is built two k-steps per tile UNDER the MFMAs of pass A, whose tiles have no
+        // epilogue of their own, and pinned there (left to the scheduler it lands in one block in front of pass B)
+        Frag<NS> pe6[12];
+        auto pe6_part = [&](const int T) __attribute__((always_inline)) {
+            if (NS == 1 && T < 6) {                              // hi+lo fragments: twice the registers, the early build spills
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    build_pe6_ks<NS>(L, cd6, pe6, 1.0f, 2 * T + j);
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) asm volatile("" : "+v"(pe6[2 * T + j].w[s2]));
+                }
+            }
+        };
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             acc_init_vec(acc[T], lds_vec, kVecCvec, h, T, 1.0f);
-            DPN_STEP(8 + T, 16, false, actA, acc[T], (void)0);
+            DPN_STEP(8 + T, 16, false, actA, acc[T], pe6_part(T));
         }
-        Frag<NS> pe6[12];
-        build_pe6<NS>(L, cd6, pe6, 1.0f);
+        if constexpr (NS == 2) build_pe6<NS>(L, cd6, pe6, 1.0f);
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             if (T == 0) DPN_STEP(16 + T, 12, false, pe6, acc[T], (void)0);
