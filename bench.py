@@ -50,8 +50,9 @@ def synth_batch(n_points, device, seed, lon=257, lat=145, dx=27000.0, dy=27000.0
     return {k: v.to(device) for k, v in b.items()}
 
 
-def cpu_baseline(sample_points, seed):
-    """The CPU oracle (reference-faithful: 28 autograd.grad calls + double backward) on a bounded sample of the same workload."""
+def cpu_baseline(sample_points, seed, share_derivatives=False):
+    """The CPU oracle (reference-faithful: 28 autograd.grad calls + double backward; or, share_derivatives, the 18 distinct derivatives
+    taken once) on a bounded sample of the same workload."""
     from oracle import dpn_oracle as O
     torch.manual_seed(seed)
     from deepphysinet_amd.configs import ncep_config
@@ -65,7 +66,7 @@ def cpu_baseline(sample_points, seed):
     for it in range(3):
         x, y, t = (b[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
         t0 = time.perf_counter()
-        tot = O.place_one_batch(st, x, y, t, b['f'], b['field_data'], b['coord_data'], b['forecast_h'], geo)
+        tot = O.place_one_batch(st, x, y, t, b['f'], b['field_data'], b['coord_data'], b['forecast_h'], geo, share_derivatives=share_derivatives)
         torch.autograd.grad(tot, [st[n] for n in names])
         dt = time.perf_counter() - t0
         if it > 0:
@@ -221,6 +222,10 @@ def main():
         'algorithmic_tflops_step': pts_per_s * ALG_FLOP_STEP / 1e12,
     }
 
+    if rank == 0 and args.leads == 1:
+        with torch.no_grad():                      # the six scaled PDE-loss scalars of the timed workload (SURVEY 8d asks for them next to the rate)
+            terms = m.pde_loss_terms(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'], batch['forecast_h'])
+        out['pde_losses'] = dict(zip(('motion_u', 'motion_v', 'continuous', 'energy', 'vapor', 'gas'), [float(v) for v in terms.cpu()]))
     if rank == 0:
         # ---- roofline of the dominant kernel (dpn_fwd_kernel: fused forward + Jacobian), HIP events on the launch stream
         import ctypes
@@ -321,9 +326,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(args.cpu_threads or min(32, os.cpu_count() or 1))   # more threads only add OpenMP overhead on these small ops
             v, secs = cpu_baseline(args.cpu_sample, seed=1)
+            v2, secs2 = cpu_baseline(args.cpu_sample, seed=1, share_derivatives=True)
             out['cpu_baseline'] = {'value': v, 'unit': 'points/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                                    'sample': 'oracle place_one_batch + backward (fp32, 28 autograd.grad calls) on %d points of the same '
-                                             'synthetic field; best of 2 after 1 warm-up, %.1f s per pass' % (args.cpu_sample, secs)}
+                                             'synthetic field; best of 2 after 1 warm-up, %.1f s per pass' % (args.cpu_sample, secs),
+                                   'shared_jacobian_variant': {'value': v2, 'seconds_per_pass': secs2,
+                                                               'note': 'same oracle, the 18 distinct derivatives taken once (SURVEY 8d variant ii)'}}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
