@@ -500,3 +500,48 @@ def test_error_behaviour_matches_the_reference_convention():
         dpn.pde_fields_and_jacobian(m.point_config(), g['x'].cpu(), g['y'].cpu(), g['t'].cpu(), g['coord_data'].cpu(), heads, evec, statics)
     with pytest.raises(ValueError):
         m.predict_grid(g['field_data'], g['x'], g['y'], g['t'], g['coord_data'], g['forecast_h'])      # needs all lon x lat nodes
+
+
+def test_hipgraph_replays_equal_eager_steps():
+    """bench.py times replays of ONE captured step.  Three replays must leave the model exactly where three eager steps from the same
+    state leave it (the Adam step counter lives on the device; nothing is cached between replays): bitwise equal parameters."""
+    from deepphysinet_amd.optim import FusedClipAdam
+    dev = _dev()
+    g = _gpu(synthetic_inputs(1024, GEO.lon, GEO.lat, GEO.dx, GEO.dy))
+    crit = torch.nn.MSELoss()
+
+    def make():
+        m = _model('bf16')
+        opt = FusedClipAdam(m.physics_net.parameters(), lr=1e-3, weight_decay=1e-4, max_norm=2.5e7)
+        lf = m.train_cfg['losses']['loss_factor']
+        one = torch.ones((), device=dev)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = m.place_one_batch(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'], crit, lf, 0, 0, dev)
+            loss.backward(one)
+            opt.step()
+            return loss
+        return m, opt, step
+    # eager: 2 (warm-up) + 1 (the step a capture executes... it does not: capture only records) + 3 steps
+    m1, opt1, step1 = make()
+    for _ in range(2 + 3):
+        step1()
+    # graph: 2 eager warm-up steps on a side stream (as bench.py does), capture, 3 replays
+    m2, opt2, step2 = make()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step2()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step2()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert int(opt1.step_count) == int(opt2.step_count) == 5
+    for (n_, a_), (_, b_) in zip(m1.physics_net.named_parameters(), m2.physics_net.named_parameters()):
+        assert torch.equal(a_, b_), n_
