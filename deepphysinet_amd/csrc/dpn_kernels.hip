@@ -1577,12 +1577,31 @@ struct AdamTable {
     int numel[kAdamMaxTensors];
     int n;
 };
-DEV int adam_find(const AdamTable& t, int blk) {
+// Optimiser state kept by the caller as ONE flat buffer per moment, tensor i at offset chunk_start[i] * kAdamChunk (each tensor padded to
+// whole chunks): no per-tensor state pointers, so 160 tensors fit in the kernel arguments and a PhysicsNet is one launch per pass.
+constexpr int kAdamFlatMaxTensors = 160;
+struct AdamTableFlat {
+    float* p[kAdamFlatMaxTensors];
+    const float* g[kAdamFlatMaxTensors];
+    int chunk_start[kAdamFlatMaxTensors + 1];
+    int numel[kAdamFlatMaxTensors];
+    float* m_flat;
+    float* v_flat;
+    int n;
+};
+static_assert(sizeof(AdamTableFlat) + 64 <= 4096, "kernel arguments are limited to 4 KB");
+DEV float* table_m(const AdamTable& t, int ti) { return t.m[ti]; }
+DEV float* table_v(const AdamTable& t, int ti) { return t.v[ti]; }
+DEV float* table_m(const AdamTableFlat& t, int ti) { return t.m_flat + (int64_t)t.chunk_start[ti] * kAdamChunk; }
+DEV float* table_v(const AdamTableFlat& t, int ti) { return t.v_flat + (int64_t)t.chunk_start[ti] * kAdamChunk; }
+template <class Table>
+DEV int adam_find(const Table& t, int blk) {
     int lo = 0, hi = t.n - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.chunk_start[mid] <= blk) lo = mid; else hi = mid - 1; }
     return lo;
 }
-__global__ __launch_bounds__(256) void dpn_gradnorm_kernel(AdamTable t, double* partial, int* step, int bump_step) {
+template <class Table>
+__global__ __launch_bounds__(256) void dpn_gradnorm_kernel(Table t, double* partial, int* step, int bump_step) {
     // one fp64 partial per block (no atomics: 2.7k serialised fp64 atomics on one address cost more than reading the gradients);
     // dpn_gradnorm_reduce_kernel adds them in a fixed order -> the clip coefficient is run-to-run deterministic
     if (bump_step && blockIdx.x == 0 && threadIdx.x == 0) *step += 1;       // device-side step counter: graph replays advance it
@@ -1619,7 +1638,8 @@ __global__ __launch_bounds__(256) void dpn_gradnorm_reduce_kernel(const double* 
     __syncthreads();
     if (threadIdx.x == 0) *sumsq = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ __launch_bounds__(256) void dpn_adam_kernel(AdamTable t, const double* sumsq, const int* step, float lr, float b1, float b2, float eps,
+template <class Table>
+__global__ __launch_bounds__(256) void dpn_adam_kernel(Table t, const double* sumsq, const int* step, float lr, float b1, float b2, float eps,
                                                        float wd, float max_norm, float* out_norm) {
     const float total = (float)sqrt(*sumsq);
     if (out_norm && blockIdx.x == 0 && threadIdx.x == 0) *out_norm = total;
@@ -1629,7 +1649,7 @@ __global__ __launch_bounds__(256) void dpn_adam_kernel(AdamTable t, const double
     const float step_size = lr / bc1;
     const int ti = adam_find(t, blockIdx.x);
     const int base = (blockIdx.x - t.chunk_start[ti]) * kAdamChunk;
-    float* p = t.p[ti]; const float* g = t.g[ti]; float* m = t.m[ti]; float* v = t.v[ti];
+    float* p = t.p[ti]; const float* g = t.g[ti]; float* m = table_m(t, ti); float* v = table_v(t, ti);
     const int end = min(base + kAdamChunk, t.numel[ti]);
     auto upd = [&](float& pi, const float graw, float& mi, float& vi) __attribute__((always_inline)) {
         const float gi = fmaf(wd, pi, graw * coef);
@@ -1899,9 +1919,49 @@ int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads
                 chunks += (t.numel[i] + kAdamChunk - 1) / kAdamChunk;
             }
             t.chunk_start[t.n] = chunks;
-            if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
-            else hipLaunchKernelGGL(dpn_adam_kernel, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr, beta1,
+            if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel<AdamTable>, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
+            else hipLaunchKernelGGL(dpn_adam_kernel<AdamTable>, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr, beta1,
                                     beta2, eps, weight_decay, max_norm, out_norm_dev);
+            base_chunk += chunks;
+        }
+        if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, base_chunk, sumsq);
+    }
+    return ck(hipGetLastError());
+}
+
+int64_t dpn_clip_adam_flat_floats(int n_tensors, const int64_t* numel) {
+    if (n_tensors <= 0 || !numel) return -1;
+    int64_t chunks = 0;
+    for (int i = 0; i < n_tensors; ++i) chunks += (numel[i] + kAdamChunk - 1) / kAdamChunk;
+    return chunks * kAdamChunk;
+}
+
+int dpn_clip_adam_flat(int n_tensors, float* const* params, const float* const* grads, const int64_t* numel, float* exp_avg_flat,
+                       float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float max_norm, float* out_norm_dev, void* stream) {
+    if (n_tensors <= 0 || !params || !grads || !numel || !exp_avg_flat || !exp_avg_sq_flat || !scratch_dev || !step_dev) return -1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    double* sumsq = scratch_dev;
+    double* partial = scratch_dev + 1;
+    for (int pass = 0; pass < 2; ++pass) {
+        int base_chunk = 0;
+        for (int t0 = 0; t0 < n_tensors; t0 += kAdamFlatMaxTensors) {
+            AdamTableFlat t;
+            t.n = (n_tensors - t0 < kAdamFlatMaxTensors) ? n_tensors - t0 : kAdamFlatMaxTensors;
+            t.m_flat = exp_avg_flat + (int64_t)base_chunk * kAdamChunk;
+            t.v_flat = exp_avg_sq_flat + (int64_t)base_chunk * kAdamChunk;
+            int chunks = 0;
+            for (int i = 0; i < t.n; ++i) {
+                if (numel[t0 + i] <= 0 || numel[t0 + i] > 0x7fffffff) return -1;
+                t.p[i] = params[t0 + i]; t.g[i] = grads[t0 + i];
+                t.numel[i] = (int)numel[t0 + i];
+                t.chunk_start[i] = chunks;
+                chunks += (t.numel[i] + kAdamChunk - 1) / kAdamChunk;
+            }
+            t.chunk_start[t.n] = chunks;
+            if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
+            else hipLaunchKernelGGL(dpn_adam_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr,
+                                    beta1, beta2, eps, weight_decay, max_norm, out_norm_dev);
             base_chunk += chunks;
         }
         if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, base_chunk, sumsq);

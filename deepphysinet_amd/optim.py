@@ -1,7 +1,7 @@
 """Fused clip_grad_norm_ + Adam on the HIP library (reference: interface_physics.py:514-515, cfg:151-155).
 
 Same arithmetic as `torch.nn.utils.clip_grad_norm_(params, max_norm)` followed by `torch.optim.Adam(lr, betas, eps,
-weight_decay)` (weight decay added to the gradient), but seven kernel launches for the whole model instead of ~60, and
+weight_decay)` (weight decay added to the gradient), but three kernel launches for the whole model instead of ~60, and
 hipGraph-capturable (the step counter lives on the device).
 """
 import ctypes
@@ -19,17 +19,25 @@ class FusedClipAdam:
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, initial_lr=lr)]
         self.max_norm = float(max_norm)
         dev = self.params[0].device
-        self.exp_avg = [torch.zeros_like(p) for p in self.params]
-        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         n = len(self.params)
+        lib = L.load()
         self._numel = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
         # [0] = sum of squares of all gradients, then one fp64 partial per 2048-element chunk (fixed-order reduction, no atomics)
-        self._sumsq = torch.zeros(int(L.load().dpn_clip_adam_scratch_doubles(n, self._numel)), dtype=torch.float64, device=dev)
+        self._sumsq = torch.zeros(int(lib.dpn_clip_adam_scratch_doubles(n, self._numel)), dtype=torch.float64, device=dev)
+        # both moments as ONE flat buffer each (every tensor padded to whole 2048-element chunks): the kernels need no per-tensor state
+        # pointers, and the whole model is one launch per pass.  exp_avg / exp_avg_sq are views into them.
+        total = int(lib.dpn_clip_adam_flat_floats(n, self._numel))
+        self._m_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._v_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg, self.exp_avg_sq, off = [], [], 0
+        for p in self.params:
+            k = p.numel()
+            self.exp_avg.append(self._m_flat[off:off + k].view_as(p))
+            self.exp_avg_sq.append(self._v_flat[off:off + k].view_as(p))
+            off += ((k + 2047) // 2048) * 2048
         self._p = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
-        self._m = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self.exp_avg])
-        self._v = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self.exp_avg_sq])
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -48,8 +56,8 @@ class FusedClipAdam:
             grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
         g = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
         grp = self.param_groups[0]
-        L.check(lib.dpn_clip_adam(n, self._p, g, self._m, self._v, self._numel, ctypes.c_void_p(self._sumsq.data_ptr()),
-                                  ctypes.c_void_p(self.step_count.data_ptr()), float(grp['lr']), float(grp['betas'][0]),
-                                  float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), self.max_norm,
-                                  ctypes.c_void_p(self.grad_norm.data_ptr()), torch.cuda.current_stream().cuda_stream), 'dpn_clip_adam')
+        L.check(lib.dpn_clip_adam_flat(n, self._p, g, self._numel, ctypes.c_void_p(self._m_flat.data_ptr()), ctypes.c_void_p(self._v_flat.data_ptr()),
+                                       ctypes.c_void_p(self._sumsq.data_ptr()), ctypes.c_void_p(self.step_count.data_ptr()), float(grp['lr']),
+                                       float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']), self.max_norm,
+                                       ctypes.c_void_p(self.grad_norm.data_ptr()), torch.cuda.current_stream().cuda_stream), 'dpn_clip_adam_flat')
         return self.grad_norm

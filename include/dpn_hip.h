@@ -230,6 +230,15 @@ int dpn_sample_points(const DpnSampler* s, const float* cube, const float* label
  * out_n[lon*lat][6] -> de-normalised maps[6][lat][lon] (inverse_norm :232-262 + the scatter loop :583-591). */
 int dpn_grid_maps(const float* out_n, int lon, int lat, const DpnPhysics* phys, int with_clip, float* maps, void* stream);
 
+/* The same step with the optimiser state held as ONE flat fp32 buffer per moment: tensor i lives at offset (sum of ceil(numel_j / 2048)
+ * over j < i) * 2048, i.e. every tensor is padded to whole 2048-element chunks; dpn_clip_adam_flat_floats gives the buffer length.
+ * No per-tensor state pointers travel in the kernel arguments, so up to 160 tensors are ONE launch per pass: three launches for a
+ * PhysicsNet (gradient norm, its fixed-order reduction, update). */
+int64_t dpn_clip_adam_flat_floats(int n_tensors, const int64_t* numel);
+int dpn_clip_adam_flat(int n_tensors, float* const* params, const float* const* grads, const int64_t* numel, float* exp_avg_flat,
+                       float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float max_norm, float* out_norm_dev, void* stream);
+
 /* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
 int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);
 
