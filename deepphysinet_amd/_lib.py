@@ -42,6 +42,11 @@ class DpnGemmProblem(Structure):
 EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_ADD = 0, 1, 2, 3
 
 
+class DpnLnGemm(Structure):
+    _fields_ = [(n, c_int32) for n in ('mode', 'M', 'N', 'tb', 'ldb', 'ldc', 'epi')] + \
+               [(n, c_void_p) for n in ('x', 'r', 'gamma', 'beta', 'rstd_in', 'y_out', 'xhat_out', 'rstd_out', 'partial', 'B', 'bias', 'C', 'aux', 'aux_out')]
+
+
 class DpnColsumJob(Structure):
     _fields_ = [('partial', c_void_p), ('out_a', c_void_p), ('out_b', c_void_p), ('n_blocks', c_int32)]
 
@@ -76,6 +81,7 @@ EXPORTS = {
     'dpn_smooth_l1': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'dpn_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                           c_void_p, c_int64, c_void_p]),
+    'dpn_sgemm_ln': (c_int, [POINTER(DpnLnGemm), c_void_p]),
     'dpn_sgemm_batch_jobs': (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'dpn_sgemm_batch': (c_int, [c_int, POINTER(DpnGemmProblem), c_void_p]),
     'dpn_attn_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -1563,6 +1563,152 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     if (do_asum && threadIdx.x < BM && m0 + threadIdx.x < a.M) a.asum[m0 + threadIdx.x] = rs;
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm folded into a GEMM's A operand
+// A dependent kernel costs >= 4.5 us on this machine whatever it does, and LayerNorm (forward or backward) on 287 x 256 does almost
+// nothing.  Its consumer is always a GEMM over the FULL 256-wide rows (K = d_model = 256 = one LDS tile), so the consumer can apply it
+// to its own A tile: every workgroup of a row block recomputes the 32 row statistics (cheap), the n0 == 0 workgroups write the
+// normalised rows / statistics (forward) or the row gradients and the per-block parameter partial sums (backward) for later use.
+//   mode 1:  A = LN(x + r) * gamma + beta      (writes y, xhat, rstd)                       -- transformer_net.py:37,44
+//   mode 2:  A = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))               (writes gs and partial[block][2][256])
+struct LnGemmArgs {
+    int mode, M, N, tb, ldb, ldc, epi;
+    const float *x, *r, *gamma, *beta, *rstd_in;
+    float *y_out, *xhat_out, *rstd_out, *partial;
+    const float *B, *bias;
+    float* C;
+    const float* aux;
+    float* aux_out;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
+    constexpr int BK = 256;
+    __shared__ float As[BK][33];
+    __shared__ float Bs[BK][33];
+    __shared__ float Xs[MODE == 2 ? BK : 1][33];
+    __shared__ float red[2][8][32];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    // ---- stage A (thread t owns column k = t of the 32 rows) and B
+    {
+        float ra[32], rx[MODE == 2 ? 32 : 1], rb[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int gm = m0 + q;
+            const bool ok = gm < a.M;
+            ra[q] = ok ? a.x[(int64_t)gm * 256 + t] : 0.f;
+            if (MODE == 1) { if (ok && a.r) ra[q] += a.r[(int64_t)gm * 256 + t]; }
+            else rx[q] = ok ? a.r[(int64_t)gm * 256 + t] : 0.f;
+            const int e = t + 256 * q;
+            const int kk = a.tb ? (e & 255) : (e >> 5), nn = a.tb ? (e >> 8) : (e & 31);
+            const int gn = n0 + nn;
+            rb[q] = (gn < a.N) ? (a.tb ? a.B[(int64_t)gn * a.ldb + kk] : a.B[(int64_t)kk * a.ldb + gn]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            As[t][q] = ra[q];
+            if (MODE == 2) Xs[t][q] = rx[q];
+            const int e = t + 256 * q;
+            Bs[a.tb ? (e & 255) : (e >> 5)][a.tb ? (e >> 8) : (e & 31)] = rb[q];
+        }
+    }
+    __syncthreads();
+    const float gam = a.gamma[t];
+    // ---- row statistics: thread (row m = t & 31, part = t >> 5) sums its 32 columns; the 8 parts are joined in a fixed order
+    const int m = t & 31, part = t >> 5;
+    float st0, st1;                                        // mode 1: mean, rstd ; mode 2: mean(g gamma), mean(g gamma xhat)
+    if (MODE == 1) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = part * 32; k < part * 32 + 32; ++k) s += As[k][m];
+        red[0][part][m] = s;
+        __syncthreads();
+        float mean = 0.f;
+#pragma unroll
+        for (int p_ = 0; p_ < 8; ++p_) mean += red[0][p_][m];
+        mean *= (1.f / 256.f);
+        float v = 0.f;
+#pragma unroll 8
+        for (int k = part * 32; k < part * 32 + 32; ++k) { const float d = As[k][m] - mean; v = fmaf(d, d, v); }
+        red[1][part][m] = v;
+        __syncthreads();
+        float var = 0.f;
+#pragma unroll
+        for (int p_ = 0; p_ < 8; ++p_) var += red[1][p_][m];
+        st0 = mean;
+        st1 = 1.0f / sqrtf(var * (1.f / 256.f) + 1e-5f);
+        if (blockIdx.x == 0 && part == 0 && m0 + m < a.M) a.rstd_out[m0 + m] = st1;
+    } else {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+        for (int k = part * 32; k < part * 32 + 32; ++k) { const float tk = As[k][m] * a.gamma[k]; s1 += tk; s2 = fmaf(tk, Xs[k][m], s2); }
+        red[0][part][m] = s1;
+        red[1][part][m] = s2;
+        __syncthreads();
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int p_ = 0; p_ < 8; ++p_) { m1 += red[0][p_][m]; m2 += red[1][p_][m]; }
+        st0 = m1 * (1.f / 256.f);
+        st1 = m2 * (1.f / 256.f);
+        if (blockIdx.x == 0) {                              // parameter partial sums of this row block: column k = t over the 32 rows
+            float dg = 0.f, db = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < 32; ++q) { dg = fmaf(As[t][q], Xs[t][q], dg); db += As[t][q]; }
+            a.partial[(int64_t)blockIdx.y * 512 + t] = dg;
+            a.partial[(int64_t)blockIdx.y * 512 + 256 + t] = db;
+        }
+    }
+    // publish the row statistics (each row's value is identical in its 8 part-threads; part 0 writes)
+    __syncthreads();
+    if (part == 0) { red[0][0][m] = st0; red[1][0][m] = st1; }
+    __syncthreads();
+    // ---- transform the A tile in place (column k = t, rows q); the n0 == 0 workgroups keep the results
+    {
+        const float bet = (MODE == 1) ? a.beta[t] : 0.f;
+        const bool keep = blockIdx.x == 0;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+            const int gm = m0 + q;
+            float outv;
+            if (MODE == 1) {
+                const float xh = (As[t][q] - red[0][0][q]) * red[1][0][q];
+                outv = fmaf(xh, gam, bet);
+                if (keep && gm < a.M) { a.xhat_out[(int64_t)gm * 256 + t] = xh; a.y_out[(int64_t)gm * 256 + t] = outv; }
+            } else {
+                const float rs_ = gm < a.M ? a.rstd_in[gm] : 0.f;
+                outv = rs_ * (As[t][q] * gam - red[0][0][q] - Xs[t][q] * red[1][0][q]);
+                if (keep && gm < a.M) a.y_out[(int64_t)gm * 256 + t] = outv;
+            }
+            As[t][q] = outv;
+        }
+    }
+    __syncthreads();
+    // ---- the GEMM proper: four waves x 64 k each (exact fp32 MFMA), partial tiles joined in a fixed order
+    f32x16 acc = (f32x16)0.f;
+#pragma unroll 8
+    for (int u = 0; u < BK / 8; ++u) {
+        const int kk = wave * (BK / 4) + 2 * u + h;
+        acc = mfma_f32(As[kk][i], Bs[kk][i], acc);
+    }
+    __syncthreads();
+    float (*partt)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(&As[0][0]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) partt[wave][drow32(r, h) * 33 + i] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int e = t; e < 1024; e += 256) {
+        const int r = e >> 5, c = e & 31, o = r * 33 + c;
+        if (m0 + r < a.M && n0 + c < a.N) {
+            float v = ((partt[0][o] + partt[1][o]) + partt[2][o]) + partt[3][o];
+            v += a.bias ? a.bias[n0 + c] : 0.f;
+            const int64_t idx = (int64_t)(m0 + r) * a.ldc + n0 + c;
+            if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = v; v = gelu_exact(v); }
+            else if (a.epi == DPN_EPI_MUL_GELU_GRAD) v *= gelu_exact_grad(a.aux[idx]);
+            else if (a.epi == DPN_EPI_ADD) v += a.aux[idx];
+            a.C[idx] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ fused clip + Adam
 // clip_grad_norm_(max_norm) followed by torch.optim.Adam(lr, betas, eps, weight_decay) (L2-in-gradient, not AdamW), as in
 // interface_physics.py:514-515 / cfg:151-155, for a LIST of tensors per launch (pointer table in the kernel arguments).
@@ -1889,6 +2035,19 @@ int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems, void* stream
 
 int dpn_sgemm_batch_jobs(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream) {
     return sgemm_batch_launch(n_problems, problems, n_jobs, jobs, stream);
+}
+
+int dpn_sgemm_ln(const DpnLnGemm* q, void* stream) {
+    if (!q || (q->mode != 1 && q->mode != 2) || q->M <= 0 || q->N <= 0 || !q->x || !q->gamma || !q->B || !q->C || !q->y_out) return -1;
+    if (q->mode == 1 && (!q->beta || !q->xhat_out || !q->rstd_out)) return -1;
+    if (q->mode == 2 && (!q->r || !q->rstd_in || !q->partial)) return -1;
+    if (q->epi < 0 || q->epi > DPN_EPI_ADD || ((q->epi == DPN_EPI_MUL_GELU_GRAD || q->epi == DPN_EPI_ADD) && !q->aux)) return -1;
+    LnGemmArgs a{q->mode, q->M, q->N, q->tb, q->ldb, q->ldc, q->epi, q->x, q->r, q->gamma, q->beta, q->rstd_in, q->y_out, q->xhat_out,
+                 q->rstd_out, q->partial, q->B, q->bias, q->C, q->aux, q->aux_out};
+    const dim3 grid((q->N + 31) / 32, (q->M + 31) / 32);
+    if (q->mode == 1) hipLaunchKernelGGL(dpn_sgemm_ln_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(dpn_sgemm_ln_kernel<2>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return ck(hipGetLastError());
 }
 
 int64_t dpn_clip_adam_scratch_doubles(int n_tensors, const int64_t* numel) {

@@ -133,15 +133,16 @@ def _wgrad(batch, N, K, n, g, ldg, x, ldx, gw, gb):
 class _EncoderLayerFn(torch.autograd.Function):
     """One EncoderLayer (model/transformer_net.py:28-44 + attn.py:177-196) as a single autograd node with a hand-scheduled backward:
         x1 = LN1(x + out_proj(attention(q(x), k(x), v(x))));  out = LN2(x1 + conv2(gelu(conv1(x1))))
-    7 launches forward, 8 backward.  GELU and its derivative ride in the GEMM epilogues, each residual-branch gradient joins the
-    input gradient inside the GEMM that produces it (DPN_EPI_ADD), and the LayerNorm parameter sums ride along in the next GEMM
-    launch, so no elementwise kernel sits on the dependency chain of the step.
+    7 launches forward, 5 backward.  GELU and its derivative ride in the GEMM epilogues, each residual-branch gradient joins the
+    input gradient inside the GEMM that produces it (DPN_EPI_ADD), both LayerNorm backwards are applied by the consuming GEMM to its
+    own A tile (dpn_sgemm_ln), and the LayerNorm parameter sums ride along in the next GEMM launch: no elementwise kernel sits on
+    the dependency chain of the backward pass.
     x: [B * L, 256] -- B field samples of L tokens each; attention stays inside a field, everything else is row-wise.
     conv weights as [d_ff, 256] / [256, d_ff] matrices."""
 
     @staticmethod
     def forward(ctx, x, B, Lt, wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, wc1, bc1, wc2, bc2, g2, be2):
-        from .linear import _launch, _problem
+        from .linear import _launch, _launch_ln, _problem
         lib = L.load()
         x = _c(x)
         wq, wk, wv, wo, wc1, wc2 = (_c(w) for w in (wq, wk, wv, wo, wc1, wc2))
@@ -155,6 +156,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         L.check(lib.dpn_attn_fwd(_p(q), _p(k), _p(v), Lt, B, _p(o), _p(P), _s()), 'dpn_attn_fwd')
         a = new(n, D)
         _launch([_problem(n, D, D, [(o, D, wo, D)], a, D, 0, 1, bias=bo)])
+        # (LayerNorm forward folded into the conv1 GEMM -- dpn_sgemm_ln mode 1 -- measured slower than the two launches: 21 vs 13.6 us)
         x1, xhat1, rstd1 = new(n, D), new(n, D), new(n)
         L.check(lib.dpn_add_ln_fwd(_p(x), _p(a), _p(g1), _p(be1), n, _p(x1), _p(xhat1), _p(rstd1), _s()), 'dpn_add_ln_fwd')
         pre, act = new(n, Fh), new(n, Fh)
@@ -169,36 +171,30 @@ class _EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        from .linear import _launch, _problem
+        from .linear import _launch, _launch_ln, _problem
         lib = L.load()
         x, q, k, v, o, P, x1, pre, act, xhat1, rstd1, xhat2, rstd2, wq, wk, wv, wo, wc1, wc2, g1, g2 = ctx.saved_tensors
         n, D = x.shape
         Fh = wc1.shape[0]
         dev = x.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        scratch = new(((n + 3) // 4) * 512)
-        # LN2 (its parameter sums ride along in the next GEMM launch)
+        nb = (n + 31) // 32                                       # row blocks of the LayerNorm-in-GEMM launches (their partial sums)
+        scratch2, scratch1 = new(nb * 512), new(nb * 512)
+        # LN2 backward is applied by the conv2 input-gradient GEMM to its own A tile: d(pre) = (gs2 W_c2) * gelu'(pre); gs2 kept
         gs2, dg2, dbe2 = new(n, D), new(D), new(D)
-        L.check(lib.dpn_add_ln_bwd(_p(_c(g)), _p(xhat2), _p(rstd2), _p(g2), n, _p(gs2), None, None, _p(scratch), _s()), 'dpn_add_ln_bwd')
-        # conv2: d(pre) = (gs2 W_c2) * gelu'(pre) ; dW_c2 = gs2^T act ; db_c2 = sum_rows gs2
-        dpre, dwc2, dbc2 = new(n, Fh), new(D, Fh), new(D)
-        batch = [_problem(n, Fh, D, [(gs2, D, wc2, Fh)], dpre, Fh, 0, 0, epi=L.EPI_MUL_GELU_GRAD, aux=pre)]
-        _wgrad(batch, D, Fh, n, gs2, D, act, Fh, dwc2, dbc2)
-        _launch(batch, colsum_jobs=[(scratch, n, dg2, dbe2)])
-        # conv1: d(x1) = dpre W_c1 + gs2 (the residual branch) ; dW_c1 = dpre^T x1
+        dpre = new(n, Fh)
+        _launch_ln(2, n, Fh, _c(g), xhat2, g2, None, rstd2, gs2, None, None, scratch2, wc2, 0, Fh, dpre, Fh, epi=L.EPI_MUL_GELU_GRAD, aux=pre)
+        # conv1: d(x1) = dpre W_c1 + gs2 (the residual branch); with it dW_c2 = gs2^T act, dW_c1 = dpre^T x1 and LN2's parameter sums
+        dwc2, dbc2 = new(D, Fh), new(D)
         dx1, dwc1, dbc1 = new(n, D), new(Fh, D), new(Fh)
         batch = [_problem(n, D, Fh, [(dpre, Fh, wc1, D)], dx1, D, 0, 0, epi=L.EPI_ADD, aux=gs2)]
+        _wgrad(batch, D, Fh, n, gs2, D, act, Fh, dwc2, dbc2)
         _wgrad(batch, Fh, D, n, dpre, Fh, x1, D, dwc1, dbc1)
-        _launch(batch)
-        # LN1
+        _launch(batch, colsum_jobs=[(scratch2, n, dg2, dbe2, nb)])
+        # LN1 backward is applied by the out-projection input-gradient GEMM: d(o) = gs1 W_o; gs1 kept
         gs1, dg1, dbe1 = new(n, D), new(D), new(D)
-        scratch1 = new(((n + 3) // 4) * 512)
-        L.check(lib.dpn_add_ln_bwd(_p(dx1), _p(xhat1), _p(rstd1), _p(g1), n, _p(gs1), None, None, _p(scratch1), _s()), 'dpn_add_ln_bwd')
-        # out projection
         do, dwo, dbo = new(n, D), new(D, D), new(D)
-        batch = [_problem(n, D, D, [(gs1, D, wo, D)], do, D, 0, 0)]
-        _wgrad(batch, D, D, n, gs1, D, o, D, dwo, dbo)
-        _launch(batch, colsum_jobs=[(scratch1, n, dg1, dbe1)])
+        _launch_ln(2, n, D, dx1, xhat1, g1, None, rstd1, gs1, None, None, scratch1, wo, 0, D, do, D)
         # attention
         dq, dk, dv = new(n, D), new(n, D), new(n, D)
         L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(do), ctx.Lt, ctx.B, _p(dq), _p(dk), _p(dv), _s()), 'dpn_attn_bwd')
@@ -207,7 +203,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         batch = [_problem(n, D, D, [(dq, D, wq, D), (dk, D, wk, D), (dv, D, wv, D)], dx, D, 0, 0, epi=L.EPI_ADD, aux=gs1)]
         for gq, gw, gb in ((dq, dwq, dbq), (dk, dwk, dbk), (dv, dwv, dbv)):
             _wgrad(batch, D, D, n, gq, D, x, D, gw, gb)
-        _launch(batch)
+        _wgrad(batch, D, D, n, gs1, D, o, D, dwo, dbo)              # dW_o = gs1^T o
+        _launch(batch, colsum_jobs=[(scratch1, n, dg1, dbe1, nb)])
         return dx, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg1, dbe1, dwc1, dbc1, dwc2, dbc2, dg2, dbe2
 
 

@@ -41,9 +41,22 @@ def _launch(problems, colsum_jobs=()):
     if not colsum_jobs:
         L.check(lib.dpn_sgemm_batch(len(problems), arr, torch.cuda.current_stream().cuda_stream), 'dpn_sgemm_batch')
         return
-    jobs = (L.DpnColsumJob * len(colsum_jobs))(*[L.DpnColsumJob(s.data_ptr(), a.data_ptr(), b.data_ptr(), (rows + 3) // 4)
-                                                for s, rows, a, b in colsum_jobs])
+    # (scratch, rows, dgamma, dbeta): partials of dpn_add_ln_bwd (one block per 4 rows); a fifth element gives the block count itself
+    jobs = (L.DpnColsumJob * len(colsum_jobs))(*[L.DpnColsumJob(j[0].data_ptr(), j[2].data_ptr(), j[3].data_ptr(), j[4] if len(j) > 4 else (j[1] + 3) // 4)
+                                                for j in colsum_jobs])
     L.check(lib.dpn_sgemm_batch_jobs(len(problems), arr, len(colsum_jobs), jobs, torch.cuda.current_stream().cuda_stream), 'dpn_sgemm_batch_jobs')
+
+
+def _launch_ln(mode, M, N, x, r, gamma, beta, rstd_in, y_out, xhat_out, rstd_out, partial, B, tb, ldb, C, ldc, bias=None, epi=0, aux=None,
+               aux_out=None):
+    """dpn_sgemm_ln: LayerNorm (mode 1 forward of x + r, mode 2 backward of g = x with xhat = r) applied to the A tile of the GEMM that
+    consumes it -- one launch instead of two (include/dpn_hip.h)."""
+    q = L.DpnLnGemm()
+    q.mode, q.M, q.N, q.tb, q.ldb, q.ldc, q.epi = mode, M, N, tb, ldb, ldc, epi
+    q.x, q.r, q.gamma, q.beta, q.rstd_in = _p(x), _p(r), _p(gamma), _p(beta), _p(rstd_in)
+    q.y_out, q.xhat_out, q.rstd_out, q.partial = _p(y_out), _p(xhat_out), _p(rstd_out), _p(partial)
+    q.B, q.bias, q.C, q.aux, q.aux_out = _p(B), _p(bias), _p(C), _p(aux), _p(aux_out)
+    L.check(L.load().dpn_sgemm_ln(ctypes.byref(q), torch.cuda.current_stream().cuda_stream), 'dpn_sgemm_ln')
 
 
 def _sgemm_splitk(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, asum=None):

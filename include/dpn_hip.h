@@ -158,6 +158,24 @@ int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems /* host array
 typedef struct DpnColsumJob { const float* partial; float* out_a; float* out_b; int32_t n_blocks; } DpnColsumJob;
 int dpn_sgemm_batch_jobs(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs /* host array, <= 2 */, void* stream);
 
+/* LayerNorm folded into the A operand of the GEMM that consumes it (d_model = 256: the GEMM's K is the LayerNorm's row):
+ *   mode 1:  C = epilogue((LN(x + r) * gamma + beta) . op(B) + bias); also writes y = LN(..)*gamma+beta [M][256], xhat [M][256], rstd [M]
+ *            (EncoderLayer: x1 = norm1(x + attn) feeding conv1, transformer_net.py:37-41);
+ *   mode 2:  C = epilogue(gs . op(B) + bias) with gs = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)) the LayerNorm input
+ *            gradient (x = g, r = xhat); also writes gs [M][256] (y_out) and partial[ceil(M/32)][2][256] = per-row-block sums of g*xhat
+ *            and g, to be reduced by a DpnColsumJob (n_blocks = ceil(M/32)) of a later dpn_sgemm_batch_jobs launch.
+ * op(B) = B^T with B stored [N][256] (tb = 1) or B stored [256][N] (tb = 0).  One launch instead of LayerNorm + GEMM. */
+typedef struct DpnLnGemm {
+    int32_t mode, M, N, tb, ldb, ldc, epi;
+    const float *x, *r, *gamma, *beta, *rstd_in;
+    float *y_out, *xhat_out, *rstd_out, *partial;
+    const float *B, *bias;
+    float* C;
+    const float* aux;
+    float* aux_out;
+} DpnLnGemm;
+int dpn_sgemm_ln(const DpnLnGemm* problem, void* stream);
+
 /* FullAttention of the encoder (model/attn.py:50-68): o = softmax(q k^T / sqrt(32)) v for 8 heads x 32 over L <= 288 tokens.
  * q,k,v,o,go,dq,dk,dv: [batch*L][256] fp32 row-major (field b = rows b*L.., head h = columns 32h..32h+31); attention never crosses
  * fields.  P (saved probabilities): [batch][8][288][288] fp32.

@@ -545,3 +545,38 @@ def test_hipgraph_replays_equal_eager_steps():
     assert int(opt1.step_count) == int(opt2.step_count) == 5
     for (n_, a_), (_, b_) in zip(m1.physics_net.named_parameters(), m2.physics_net.named_parameters()):
         assert torch.equal(a_, b_), n_
+
+
+def test_layernorm_folded_into_gemm_both_modes():
+    """dpn_sgemm_ln through the C ABI against torch: mode 1 (LayerNorm forward of x + r feeds the GEMM; the backward of the encoder layer
+    uses mode 2, the forward keeps the two-launch form because it measured faster) and mode 2 (LayerNorm backward feeds the GEMM)."""
+    import torch.nn.functional as F
+    from deepphysinet_amd import _lib as L
+    from deepphysinet_amd.linear import _launch_ln
+    dev = _dev()
+    torch.manual_seed(11)
+    M, N = 287, 192
+    x, r = torch.randn(M, 256, device=dev), torch.randn(M, 256, device=dev)
+    gamma, beta = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev)
+    W, b = torch.randn(N, 256, device=dev) / 16, torch.randn(N, device=dev)
+    y, xhat, rstd, C, pre = (torch.empty(s_, device=dev) for s_ in ((M, 256), (M, 256), (M,), (M, N), (M, N)))
+    _launch_ln(1, M, N, x, r, gamma, beta, None, y, xhat, rstd, None, W, 1, 256, C, N, bias=b, epi=L.EPI_GELU, aux_out=pre)
+    s = x + r
+    y_ref = F.layer_norm(s, (256,), gamma, beta, 1e-5)
+    rstd_ref = 1.0 / torch.sqrt(s.var(dim=1, unbiased=False) + 1e-5)
+    pre_ref = y_ref @ W.T + b
+    assert torch.allclose(y, y_ref, rtol=1e-5, atol=1e-5) and torch.allclose(rstd, rstd_ref, rtol=1e-5)
+    assert torch.allclose(xhat, (s - s.mean(1, keepdim=True)) * rstd_ref[:, None], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(pre, pre_ref, rtol=1e-4, atol=1e-4) and torch.allclose(C, F.gelu(pre_ref), rtol=1e-4, atol=1e-4)
+    # mode 2: gs = LayerNorm input gradient of g; C = gs . B (B stored [256][N]); partial sums of g * xhat and g per 32-row block
+    g = torch.randn(M, 256, device=dev)
+    Bm = torch.randn(256, N, device=dev) / 16
+    gs, C2 = torch.empty(M, 256, device=dev), torch.empty(M, N, device=dev)
+    nb = (M + 31) // 32
+    partial = torch.empty(nb, 2, 256, device=dev)
+    xh = (s - s.mean(1, keepdim=True)) * rstd_ref[:, None]
+    _launch_ln(2, M, N, g, xh.contiguous(), gamma, None, rstd_ref.contiguous(), gs, None, None, partial, Bm, 0, N, C2, N)
+    tg = g * gamma
+    gs_ref = rstd_ref[:, None] * (tg - tg.mean(1, keepdim=True) - xh * (tg * xh).mean(1, keepdim=True))
+    assert torch.allclose(gs, gs_ref, rtol=1e-4, atol=1e-5) and torch.allclose(C2, gs_ref @ Bm, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(partial[:, 0].sum(0), (g * xh).sum(0), rtol=1e-4, atol=1e-4) and torch.allclose(partial[:, 1].sum(0), g.sum(0), rtol=1e-4, atol=1e-4)
