@@ -1584,102 +1584,97 @@ __global__ __launch_bounds__(256) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
     constexpr int BK = 256;
     __shared__ float As[BK][33];
     __shared__ float Bs[BK][33];
-    __shared__ float Xs[MODE == 2 ? BK : 1][33];
-    __shared__ float red[2][8][32];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    // ---- stage A (thread t owns column k = t of the 32 rows) and B
-    {
-        float ra[32], rx[MODE == 2 ? 32 : 1], rb[32];
+    const bool keep = blockIdx.x == 0;
+    // ---- B tile -> registers (stored to LDS after the LayerNorm phase, which may borrow Bs)
+    float rb[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int gm = m0 + q;
-            const bool ok = gm < a.M;
-            ra[q] = ok ? a.x[(int64_t)gm * 256 + t] : 0.f;
-            if (MODE == 1) { if (ok && a.r) ra[q] += a.r[(int64_t)gm * 256 + t]; }
-            else rx[q] = ok ? a.r[(int64_t)gm * 256 + t] : 0.f;
-            const int e = t + 256 * q;
-            const int kk = a.tb ? (e & 255) : (e >> 5), nn = a.tb ? (e >> 8) : (e & 31);
-            const int gn = n0 + nn;
-            rb[q] = (gn < a.N) ? (a.tb ? a.B[(int64_t)gn * a.ldb + kk] : a.B[(int64_t)kk * a.ldb + gn]) : 0.f;
-        }
+    for (int q = 0; q < 32; ++q) {
+        const int e = t + 256 * q;
+        const int kk = a.tb ? (e & 255) : (e >> 5), nn = a.tb ? (e >> 8) : (e & 31);
+        const int gn = n0 + nn;
+        rb[q] = (gn < a.N) ? (a.tb ? a.B[(int64_t)gn * a.ldb + kk] : a.B[(int64_t)kk * a.ldb + gn]) : 0.f;
+    }
+    // ---- A rows in registers: thread t holds columns [32 c, 32 c + 32) of row m (c = t & 7, m = t >> 3): a row is 8 adjacent lanes,
+    // so the row statistics are three xor-shuffles -- no LDS pass, no barrier
+    const int m = t >> 3, c0 = (t & 7) * 32, gm = m0 + m;
+    const bool ok = gm < a.M;
+    float v[32], w[MODE == 2 ? 32 : 1], gam[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            As[t][q] = ra[q];
-            if (MODE == 2) Xs[t][q] = rx[q];
-            const int e = t + 256 * q;
-            Bs[a.tb ? (e & 255) : (e >> 5)][a.tb ? (e >> 8) : (e & 31)] = rb[q];
+    for (int j = 0; j < 8; ++j) {
+        const float4 x4 = ok ? *reinterpret_cast<const float4*>(a.x + (int64_t)gm * 256 + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g4 = *reinterpret_cast<const float4*>(a.gamma + c0 + 4 * j);
+        v[4 * j] = x4.x; v[4 * j + 1] = x4.y; v[4 * j + 2] = x4.z; v[4 * j + 3] = x4.w;
+        gam[4 * j] = g4.x; gam[4 * j + 1] = g4.y; gam[4 * j + 2] = g4.z; gam[4 * j + 3] = g4.w;
+        if (MODE == 1) {
+            if (ok && a.r) {
+                const float4 r4 = *reinterpret_cast<const float4*>(a.r + (int64_t)gm * 256 + c0 + 4 * j);
+                v[4 * j] += r4.x; v[4 * j + 1] += r4.y; v[4 * j + 2] += r4.z; v[4 * j + 3] += r4.w;
+            }
+        } else {
+            const float4 r4 = ok ? *reinterpret_cast<const float4*>(a.r + (int64_t)gm * 256 + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w[4 * j] = r4.x; w[4 * j + 1] = r4.y; w[4 * j + 2] = r4.z; w[4 * j + 3] = r4.w;
         }
     }
-    __syncthreads();
-    const float gam = a.gamma[t];
-    // ---- row statistics: thread (row m = t & 31, part = t >> 5) sums its 32 columns; the 8 parts are joined in a fixed order
-    const int m = t & 31, part = t >> 5;
-    float st0, st1;                                        // mode 1: mean, rstd ; mode 2: mean(g gamma), mean(g gamma xhat)
+    auto row_sum = [&](float s_) __attribute__((always_inline)) {            // over the 8 lanes of the row, fixed order
+        s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 4);
+        return s_;
+    };
+    if (MODE == 2 && keep) {
+        // parameter partial sums of this row block need g and xhat column-wise: park them in As / Bs (both still unused), one pass
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { As[c0 + j][m] = v[j]; Bs[c0 + j][m] = w[j]; }
+        __syncthreads();
+        float dg = 0.f, db = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) { dg = fmaf(As[t][q], Bs[t][q], dg); db += As[t][q]; }
+        a.partial[(int64_t)blockIdx.y * 512 + t] = dg;
+        a.partial[(int64_t)blockIdx.y * 512 + 256 + t] = db;
+        __syncthreads();
+    }
     if (MODE == 1) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int k = part * 32; k < part * 32 + 32; ++k) s += As[k][m];
-        red[0][part][m] = s;
-        __syncthreads();
-        float mean = 0.f;
+        float s_ = 0.f;
 #pragma unroll
-        for (int p_ = 0; p_ < 8; ++p_) mean += red[0][p_][m];
-        mean *= (1.f / 256.f);
-        float v = 0.f;
-#pragma unroll 8
-        for (int k = part * 32; k < part * 32 + 32; ++k) { const float d = As[k][m] - mean; v = fmaf(d, d, v); }
-        red[1][part][m] = v;
-        __syncthreads();
-        float var = 0.f;
+        for (int j = 0; j < 32; ++j) s_ += v[j];
+        const float mean = row_sum(s_) * (1.f / 256.f);
+        float q_ = 0.f;
 #pragma unroll
-        for (int p_ = 0; p_ < 8; ++p_) var += red[1][p_][m];
-        st0 = mean;
-        st1 = 1.0f / sqrtf(var * (1.f / 256.f) + 1e-5f);
-        if (blockIdx.x == 0 && part == 0 && m0 + m < a.M) a.rstd_out[m0 + m] = st1;
+        for (int j = 0; j < 32; ++j) { const float d = v[j] - mean; q_ = fmaf(d, d, q_); }
+        const float rstd = 1.0f / sqrtf(row_sum(q_) * (1.f / 256.f) + 1e-5f);
+        if (keep && ok && (t & 7) == 0) a.rstd_out[gm] = rstd;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.beta + c0 + 4 * j);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            float xh[4], yy[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xh[e] = (v[4 * j + e] - mean) * rstd; yy[e] = fmaf(xh[e], gam[4 * j + e], bb[e]); v[4 * j + e] = yy[e]; }
+            if (keep && ok) {
+                *reinterpret_cast<float4*>(a.xhat_out + (int64_t)gm * 256 + c0 + 4 * j) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+                *reinterpret_cast<float4*>(a.y_out + (int64_t)gm * 256 + c0 + 4 * j) = make_float4(yy[0], yy[1], yy[2], yy[3]);
+            }
+        }
     } else {
         float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-        for (int k = part * 32; k < part * 32 + 32; ++k) { const float tk = As[k][m] * a.gamma[k]; s1 += tk; s2 = fmaf(tk, Xs[k][m], s2); }
-        red[0][part][m] = s1;
-        red[1][part][m] = s2;
-        __syncthreads();
-        float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int p_ = 0; p_ < 8; ++p_) { m1 += red[0][p_][m]; m2 += red[1][p_][m]; }
-        st0 = m1 * (1.f / 256.f);
-        st1 = m2 * (1.f / 256.f);
-        if (blockIdx.x == 0) {                              // parameter partial sums of this row block: column k = t over the 32 rows
-            float dg = 0.f, db = 0.f;
-#pragma unroll 8
-            for (int q = 0; q < 32; ++q) { dg = fmaf(As[t][q], Xs[t][q], dg); db += As[t][q]; }
-            a.partial[(int64_t)blockIdx.y * 512 + t] = dg;
-            a.partial[(int64_t)blockIdx.y * 512 + 256 + t] = db;
+        for (int j = 0; j < 32; ++j) { const float tk = v[j] * gam[j]; s1 += tk; s2 = fmaf(tk, w[j], s2); }
+        const float m1 = row_sum(s1) * (1.f / 256.f), m2 = row_sum(s2) * (1.f / 256.f);
+        const float rs_ = ok ? a.rstd_in[gm] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * j + e] = rs_ * (v[4 * j + e] * gam[4 * j + e] - m1 - w[4 * j + e] * m2);
+            if (keep && ok) *reinterpret_cast<float4*>(a.y_out + (int64_t)gm * 256 + c0 + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
         }
     }
-    // publish the row statistics (each row's value is identical in its 8 part-threads; part 0 writes)
-    __syncthreads();
-    if (part == 0) { red[0][0][m] = st0; red[1][0][m] = st1; }
-    __syncthreads();
-    // ---- transform the A tile in place (column k = t, rows q); the n0 == 0 workgroups keep the results
-    {
-        const float bet = (MODE == 1) ? a.beta[t] : 0.f;
-        const bool keep = blockIdx.x == 0;
-#pragma unroll 8
-        for (int q = 0; q < 32; ++q) {
-            const int gm = m0 + q;
-            float outv;
-            if (MODE == 1) {
-                const float xh = (As[t][q] - red[0][0][q]) * red[1][0][q];
-                outv = fmaf(xh, gam, bet);
-                if (keep && gm < a.M) { a.xhat_out[(int64_t)gm * 256 + t] = xh; a.y_out[(int64_t)gm * 256 + t] = outv; }
-            } else {
-                const float rs_ = gm < a.M ? a.rstd_in[gm] : 0.f;
-                outv = rs_ * (As[t][q] * gam - red[0][0][q] - Xs[t][q] * red[1][0][q]);
-                if (keep && gm < a.M) a.y_out[(int64_t)gm * 256 + t] = outv;
-            }
-            As[t][q] = outv;
-        }
+    // ---- transformed A tile and B tile -> LDS
+#pragma unroll
+    for (int j = 0; j < 32; ++j) As[c0 + j][m] = v[j];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int e = t + 256 * q;
+        Bs[a.tb ? (e & 255) : (e >> 5)][a.tb ? (e >> 8) : (e & 31)] = rb[q];
     }
     __syncthreads();
     // ---- the GEMM proper: four waves x 64 k each (exact fp32 MFMA), partial tiles joined in a fixed order
@@ -1698,13 +1693,13 @@ __global__ __launch_bounds__(256) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
     for (int e = t; e < 1024; e += 256) {
         const int r = e >> 5, c = e & 31, o = r * 33 + c;
         if (m0 + r < a.M && n0 + c < a.N) {
-            float v = ((partt[0][o] + partt[1][o]) + partt[2][o]) + partt[3][o];
-            v += a.bias ? a.bias[n0 + c] : 0.f;
+            float vv = ((partt[0][o] + partt[1][o]) + partt[2][o]) + partt[3][o];
+            vv += a.bias ? a.bias[n0 + c] : 0.f;
             const int64_t idx = (int64_t)(m0 + r) * a.ldc + n0 + c;
-            if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = v; v = gelu_exact(v); }
-            else if (a.epi == DPN_EPI_MUL_GELU_GRAD) v *= gelu_exact_grad(a.aux[idx]);
-            else if (a.epi == DPN_EPI_ADD) v += a.aux[idx];
-            a.C[idx] = v;
+            if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = vv; vv = gelu_exact(vv); }
+            else if (a.epi == DPN_EPI_MUL_GELU_GRAD) vv *= gelu_exact_grad(a.aux[idx]);
+            else if (a.epi == DPN_EPI_ADD) vv += a.aux[idx];
+            a.C[idx] = vv;
         }
     }
 }
