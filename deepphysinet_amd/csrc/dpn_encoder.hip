@@ -3,6 +3,9 @@
 // Reference behaviour (paths relative to /root/reference/DeepPhysiNet):
 //   model/attn.py:50-68     FullAttention: softmax(q k^T / sqrt(E)) v, no mask, no dropout   -> dpn_attn_fwd / dpn_attn_bwd
 //   model/transformer_net.py:28-44  x = LN1(x + attn), out = LN2(x + ffn)                    -> dpn_add_ln_fwd / dpn_add_ln_bwd
+//   model/embed.py:36-64    circular token conv (as im2col), lead-time SineCosPE, token/pos/time assembly -> dpn_im2col_circ3, dpn_lead_pe,
+//                           dpn_embed_assemble; dpn_sum_parts joins split-K slices / per-field gradients in a fixed order
+// All kernels take a batch of field samples (attention never crosses fields).
 // Sizes of the shipped config (cfg:13-24): L = 287 tokens, d_model = 256, 8 heads x 32.  Everything is exact fp32:
 // the GEMM-shaped parts use v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain), reductions are fixed-order.
 #include <hip/hip_runtime.h>

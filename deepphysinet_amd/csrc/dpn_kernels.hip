@@ -18,6 +18,10 @@
 //   dpn_bwd_kernel      per-point cotangent streams -> operands of the weight-gradient reductions
 //   dpn_wgrad_kernel    points-reduction GEMMs (split over point ranges)
 //   dpn_finish_*        split reduction, un-permutation, rank-1 fc.2 gradients
+//   dpn_sgemm_batch / dpn_sgemm_ln / dpn_sgemm     exact-fp32 MFMA GEMMs of the per-field tensors (encoder, heads), with the fused
+//                       epilogues / LayerNorm prologue / ride-along reductions the encoder nodes need
+//   dpn_gradnorm / dpn_adam                        global-norm clip + Adam over flat moment buffers
+// No kernel in this file uses atomics: every reduction is fixed-order, the whole step is bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
