@@ -722,6 +722,16 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     // ---------------- gpe = w1^T t1 (6 tiles), contracted with d(pe)/d(xi) in registers
     float jc[3] = {0.f, 0.f, 0.f};
     auto epij = [&](const int T) __attribute__((always_inline)) {
+        if (a.pe_in) {
+            // caller-encoded coordinates (PhysicsNet.forward surface): hand back d out / d pe_in itself, [N][6][192] in the
+            // reference's channel order, and let the caller's autograd chain it through its own encoding (generic path, scattered stores)
+            if (L.valid) {
+                float* o = a.jac_n + (L.pt * 6 + net) * kPe;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[pe3_ch(2 * T + (r >> 3), h, r & 7)] = acc[T][r];
+            }
+            return;
+        }
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {                // register pair (sin, cos) of one angle
             const int r = 2 * rp;
@@ -743,12 +753,22 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     pipe.drain();
 #pragma unroll
     for (int c = 0; c < 3; ++c) jc[c] += __shfl_xor(jc[c], 32);
-    if (L.valid && h == 0) {
+    if (L.valid && h == 0 && !a.pe_in) {
         float* o = a.jac_n + (L.pt * 6 + net) * 3;
         o[0] = jc[0] / a.geo.lon_m1 / a.geo.dx;          // chain rule through x/dx/(lon-1), in the reference's backward order
         o[1] = jc[1] / a.geo.lat_m1 / a.geo.dy;
         o[2] = jc[2] / a.geo.pred_t_span;
     }
+}
+
+// g_pe[n][c] = sum_k g_out[n][k] * gpe[n][k][c]: the cotangent of caller-encoded coordinates (PhysicsNet.forward backward w.r.t. coord_x)
+__global__ __launch_bounds__(192) void dpn_contract_gpe_kernel(const float* g_out, const float* gpe, int64_t n, float* g_pe) {
+    const int64_t pt = blockIdx.x;
+    const int c = threadIdx.x;
+    float s_ = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_ = fmaf(g_out[pt * 6 + k], gpe[(pt * 6 + k) * kPe + c], s_);
+    g_pe[pt * kPe + c] = s_;
 }
 
 // ------------------------------------------------------------------------------------------------ residuals
@@ -1887,12 +1907,18 @@ int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, vo
 int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
             const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream) {
     if (!coord_data || !freqs || !geo || !packed || !out_n || n <= 0 || (prec != 1 && prec != 2)) return -1;
-    if (pe_in ? (jac_n != nullptr) : (!x || !y || !t)) return -1;       // the Jacobian needs the raw coordinates
+    if (!pe_in && (!x || !y || !t)) return -1;
     FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
     if (prec == 1) hipLaunchKernelGGL(dpn_fwd_kernel<1>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(dpn_fwd_kernel<2>, grid, dim3(256), 0, s, a);
+    return ck(hipGetLastError());
+}
+
+int dpn_contract_gpe(const float* g_out, const float* gpe, int64_t n, float* g_pe, void* stream) {
+    if (!g_out || !gpe || !g_pe || n <= 0) return -1;
+    hipLaunchKernelGGL(dpn_contract_gpe_kernel, dim3((unsigned)n), dim3(192), 0, reinterpret_cast<hipStream_t>(stream), g_out, gpe, n, g_pe);
     return ck(hipGetLastError());
 }
 

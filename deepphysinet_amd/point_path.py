@@ -131,7 +131,8 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     dev = coord_data.device
     L.check(lib.dpn_pack_weights(nets, cfg.prec, _ptr(ws.packed), _stream()), 'dpn_pack_weights')
     out_n = torch.empty((n, 6), dtype=torch.float32, device=dev)
-    jac_n = torch.empty((n, 6, 3), dtype=torch.float32, device=dev) if want_jac else None
+    # with caller-encoded coordinates the kernel hands back d out / d pe_in [n, 6, 192] in place of the (x, y, t) Jacobian
+    jac_n = torch.empty((n, 6, 3 if pe_in is None else 192), dtype=torch.float32, device=dev) if want_jac else None
     if want_saved:
         ws.alloc_saved()
     geo = cfg.geometry()
@@ -164,8 +165,25 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
     return g_heads, g_evec, g_stat
 
 
+class _NoSecondOrder(torch.autograd.Function):
+    """Identity whose backward raises: marks a first derivative that cannot be differentiated again."""
+
+    @staticmethod
+    def forward(ctx, v):
+        return v.view_as(v)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise RuntimeError('deepphysinet_amd: d(fields)/d(coordinates) of PhysicsNet.forward is first-order only; training through the '
+                           'standalone *_equation methods needs its parameter derivative -- use InterfacePhysics.place_one_batch (fused '
+                           'residual kernels) for that')
+
+
 class _PointFieldsFn(torch.autograd.Function):
-    """out_n [N,6] = six VariableNets at N points.  First-order differentiable w.r.t. the weights."""
+    """out_n [N,6] = six VariableNets at N points.  First-order differentiable w.r.t. the weights and -- when the coordinates come in
+    already encoded (pe_in, the reference's PhysicsNet.forward surface) -- w.r.t. pe_in, so that the reference's `gradient(u, x)`
+    (interface_physics.py:90-95) evaluates on the outputs of the HIP model.  Differentiating such a derivative again (training through the
+    standalone equation methods) raises (_NoSecondOrder); place_one_batch is the fused path for that."""
 
     @staticmethod
     def forward(ctx, cfg, x, y, t, pe_in, coord_data, heads, evec, *statics):
@@ -175,20 +193,29 @@ class _PointFieldsFn(torch.autograd.Function):
         x_, y_, t_, pe_, cd_, hd_, ev_ = tens
         st = [_f32c(s) for s in statics]
         need_grad = any(v.requires_grad for v in (heads, evec) + tuple(statics))
+        want_gpe = pe_in is not None and pe_in.requires_grad
         ws = _Workspace(cd_.shape[0], cfg.prec, cd_.device)
         nets = _net_ptrs(hd_, ev_, st)
-        out_n, _ = _forward_points(cfg, ws, nets, x_, y_, t_, pe_, cd_, want_jac=False, want_saved=need_grad)
-        ctx.cfg, ctx.ws = cfg, ws
+        out_n, gpe = _forward_points(cfg, ws, nets, x_, y_, t_, pe_, cd_, want_jac=want_gpe, want_saved=need_grad)
+        ctx.cfg, ctx.ws, ctx.gpe = cfg, ws, gpe
         ctx.keep = (x_, y_, t_, pe_, cd_, hd_, ev_, st)
         return out_n
 
     @staticmethod
     def backward(ctx, g_out):
         x_, y_, t_, pe_, cd_, hd_, ev_, st = ctx.keep
-        nets = _net_ptrs(hd_, ev_, st)
         g = _f32c(g_out)
+        g_pe = None
+        if ctx.needs_input_grad[4] and ctx.gpe is not None:
+            g_pe = torch.empty((g.shape[0], 192), dtype=torch.float32, device=g.device)
+            L.check(L.load().dpn_contract_gpe(_ptr(g), _ptr(ctx.gpe), g.shape[0], _ptr(g_pe), _stream()), 'dpn_contract_gpe')
+            if torch.is_grad_enabled():                # create_graph=True (the reference's gradient()): a later backward through this
+                g_pe = _NoSecondOrder.apply(g_pe.requires_grad_(True))      # derivative must fail loudly, not drop its parameter part
+        if not any(ctx.needs_input_grad[6:]):
+            return (None, None, None, None, g_pe) + (None,) * (3 + len(st))
+        nets = _net_ptrs(hd_, ev_, st)
         ghd, gev, gst = _backward_points(ctx.cfg, ctx.ws, nets, x_, y_, t_, pe_, cd_, g, None, st)
-        return (None, None, None, None, None, None, ghd, gev, *gst)
+        return (None, None, None, None, g_pe, None, ghd, gev, *gst)
 
 
 class _PdeLossFn(torch.autograd.Function):

@@ -89,11 +89,15 @@ int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, vo
  *   x,y,t [N] raw coordinates (metres, metres, seconds), OR pe_in [N][192]: coordinates already encoded by the
  *   caller in the reference's SineCosPE channel order (then x,y,t and jac_n must be NULL);
  *   coord_data [N][6]; freqs [48]; out_n [N][6] normalised fields;
- *   jac_n [N][6][3] = d out_n / d(x,y,t)  (may be NULL: value-only);
+ *   jac_n [N][6][3] = d out_n / d(x,y,t)  (may be NULL: value-only); with pe_in it is [N][6][192] = d out_n / d pe_in instead
+ *         (the caller chains it through its own coordinate encoding; dpn_contract_gpe contracts it with a cotangent of out_n);
  *   saved: state for the backward pass (may be NULL: inference only). */
 int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n_points,
             const float* freqs, const DpnGeometry* geo, const void* packed, int prec,
             float* out_n, float* jac_n, void* saved, void* stream);
+
+/* g_pe[N][192] = sum_k g_out[N][k] * gpe[N][k][192]: backward of PhysicsNet.forward w.r.t. its encoded-coordinate input. */
+int dpn_contract_gpe(const float* g_out, const float* gpe, int64_t n_points, float* g_pe, void* stream);
 
 /* inverse_norm + six residual losses (interface_physics.py:97-185,232-262).
  *   loss_sums [ceil(N/256)][6] fp64: per-block sums over points of residual^2 (written, not accumulated: no zeroing, no atomics;

@@ -580,3 +580,33 @@ def test_layernorm_folded_into_gemm_both_modes():
     gs_ref = rstd_ref[:, None] * (tg - tg.mean(1, keepdim=True) - xh * (tg * xh).mean(1, keepdim=True))
     assert torch.allclose(gs, gs_ref, rtol=1e-4, atol=1e-5) and torch.allclose(C2, gs_ref @ Bm, rtol=1e-4, atol=1e-4)
     assert torch.allclose(partial[:, 0].sum(0), (g * xh).sum(0), rtol=1e-4, atol=1e-4) and torch.allclose(partial[:, 1].sum(0), g.sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_reference_equation_methods_on_hip_module_outputs():
+    """The reference's own call pattern (interface_physics.py:276-300): fields = physics_net(field, encoding_coord(x, y, t), ...),
+    de-normalise, then the six *_equation methods, each taking its derivatives with gradient() = autograd.grad(..., create_graph=True).
+    PhysicsNet.forward is differentiable w.r.t. the encoded coordinates (the kernel hands back d out / d pe), so the methods evaluate on
+    the HIP outputs and reproduce the oracle's six losses; differentiating such a loss again raises (place_one_batch is the training path)."""
+    N = 256
+    m = _model('bf16x2')
+    inp = synthetic_inputs(N, GEO.lon, GEO.lat, GEO.dx, GEO.dy)
+    ref = _oracle(inp, want_grads=False)
+    g = _gpu(inp)
+    x, y, t = (g[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
+    lf = m.train_cfg['losses']['loss_factor']
+    crit = torch.nn.MSELoss()
+    pe = m.encoding_coord(x, y, t, m.pred_t_span)
+    fields = m.physics_net(g['field_data'], pe, g['coord_data'], g['forecast_h'])
+    u, v, p, T, q, rio = m.inverse_norm(*fields, m.obs_norm_cfg)
+    f = g['f']
+    losses = [m.montion_equation_u(x, y, t, u, v, p, rio, f, crit, factor=lf['motion_u_factor']),
+              m.montion_equation_v(x, y, t, u, v, p, rio, f, crit, factor=lf['motion_v_factor']),
+              m.continuous_equation(x, y, t, u, v, rio, crit, factor=lf['continuous_factor']),
+              m.energy_equation(x, y, t, u, v, p, T, rio, q, crit, factor=lf['energy_factor']),
+              m.vapor_equation(x, y, t, u, v, p, T, q, crit, factor=lf['vapor_factor']),
+              m.gas_equation(p, T, rio, q, crit, factor=lf['gas_factor'])]
+    got = np.array([float(l_.detach()) for l_ in losses])
+    rel = np.abs(got - ref['parts']) / np.abs(ref['parts'])
+    assert np.all(rel <= 5e-4), (got, ref['parts'], rel)      # first derivatives through torch's fp32 sin/cos chain + bf16x2 kernel
+    with pytest.raises(RuntimeError):
+        losses[0].backward()                                   # second-order through the standalone methods: refused loudly
