@@ -109,3 +109,14 @@ class CollocationSampler:
         ys = torch.arange(c.lat_size, dtype=torch.int32, device=dev).repeat(c.lon_size)
         ts = torch.full_like(xs, int(time_id))
         return self.get_margin_grid(xs, ys, ts)
+
+    def training_batch(self, field_data, forecast_h, n_margin: int = 20480, n_inter: int = 4096):
+        """One sample of PhysicsDataset.__getitem__ (physics_dataset.py:501-519) as the dict InterfacePhysics.training_step takes: the
+        field sample and lead time given by the caller, 20 480 margin (grid-node, labelled) and 4 096 interior collocation points drawn,
+        interpolated and labelled on the device (batch sizes: cfg:111, physics_dataset.py:30)."""
+        mx, my, mt, mlab, mf, mcd = self.get_item_label_data(n_margin)
+        ix, iy, it, icd, if_ = self.get_inter_data(n_inter)
+        col = lambda v: v.reshape(-1, 1)
+        return {'field_data': field_data, 'forecast_h': forecast_h,
+                'margin_x': col(mx), 'margin_y': col(my), 'margin_t': col(mt), 'margin_f': mf, 'margin_data': mlab, 'margin_input_data': mcd,
+                'inter_x': col(ix), 'inter_y': col(iy), 'inter_t': col(it), 'inter_f': if_, 'inter_data': icd}

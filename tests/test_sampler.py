@@ -130,3 +130,32 @@ def test_explicit_grid_and_full_grid_maps():
         cfg = m.point_config()
         want = SO.grid_maps(fields, 257, 145, cfg.mean, cfg.std, cfg.clip_lo, cfg.clip_hi, clip)
         np.testing.assert_array_equal(maps.cpu().numpy(), want)     # same two fp32 roundings on both sides: bit-exact
+
+
+@pytest.mark.gpu
+def test_sampler_feeds_the_training_step():
+    """Dataset -> step entirely on the device: a batch drawn by the sampler (reference sizes: 20 480 margin + 4 096 interior points) through
+    InterfacePhysics.training_step (data loss + both PDE losses + clip + Adam): finite losses, parameters move, fresh points every call."""
+    from deepphysinet_amd.configs import ncep_config
+    from deepphysinet_amd.interface import builder_models
+    from deepphysinet_amd.optim import FusedClipAdam
+    from oracle.fill import fill_state_dict_, synthetic_inputs
+    s, _, _ = _sampler(seed=4)
+    dev = s.cube.device
+    m = builder_models(**ncep_config(), precision='bf16')
+    sd = m.physics_net.state_dict()
+    fill_state_dict_(sd, gain=1.0)
+    m.physics_net.load_state_dict(sd)
+    m = m.to(dev)
+    opt = FusedClipAdam(m.physics_net.parameters(), lr=1e-4, weight_decay=1e-4)
+    inp = synthetic_inputs(8, 257, 145, 27000.0, 27000.0)
+    field, fh = inp['field_data'].to(dev), inp['forecast_h'].to(dev)
+    before = m.physics_net.U_net.out_fc.weight.detach().clone()
+    b1 = s.training_batch(field, fh)
+    assert b1['margin_x'].shape == (20480, 1) and b1['inter_data'].shape == (4096, 6) and b1['margin_data'].shape == (20480, 6)
+    loss, parts, gnorm = m.training_step(b1, opt, with_pde=True)
+    assert torch.isfinite(loss) and all(torch.isfinite(v) for v in parts.values()) and torch.isfinite(gnorm).all()
+    assert set(parts) == {'margin_loss', 'inter_pde_loss', 'margin_pde_loss'}
+    assert not torch.equal(before, m.physics_net.U_net.out_fc.weight.detach())
+    b2 = s.training_batch(field, fh)
+    assert not torch.equal(b1['inter_x'], b2['inter_x'])
