@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a0) {
     load_head_rows(Vs, a.v, head, 0, kLmax, L);
     load_head_rows(Qs, a.q, head, q0, 32, L);
     __syncthreads();
+#if defined(DPN_ATTN_STAGE) && DPN_ATTN_STAGE == 1
+    return;
+#endif
     // scores: column tile ct belongs to wave ct % 4 (whole K = 32 per tile, no cross-wave reduction)
     for (int ct = wave; ct < kLmax / 32; ct += 4) {
         f32x16 acc = (f32x16)0.f;
@@ -118,25 +121,57 @@ __global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a0) {
         }
     }
     __syncthreads();
-    {   // softmax: 8 threads per row
-        const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
-        float m = -INFINITY;
-        for (int c = sub; c < kLmax; c += 8) m = fmaxf(m, Ss[row][c]);
+#if defined(DPN_ATTN_STAGE) && DPN_ATTN_STAGE == 2
+    return;
+#endif
+    {   // softmax: one wave per 8 rows, the 64 lanes stride the 288 columns (LDS row stride 289: consecutive lanes hit consecutive
+        // banks; the probabilities leave as coalesced 256-byte stores); row max / sum by wave shuffles
+        // the 8 rows of a wave are independent chains (LDS read -> shuffle max -> exp -> shuffle sum): all eight run interleaved
+        float e[8][5], mx[8], sm[8];
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float s = 0.f;
-        for (int c = sub; c < kLmax; c += 8) { const float e = expf(Ss[row][c] - m); Ss[row][c] = e; s += e; }
+        for (int rr = 0; rr < 8; ++rr) {
+            mx[rr] = -INFINITY;
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float inv = 1.f / s;
-        const bool rok = q0 + row < L;
-        for (int c = sub; c < kLmax; c += 8) {
-            const float p = rok ? Ss[row][c] * inv : 0.f;
-            Ss[row][c] = p;
-            if (rok) a.P[((int64_t)head * kLmax + q0 + row) * kLmax + c] = p;
+            for (int q = 0; q < 5; ++q) {
+                const int c = lane + 64 * q;
+                e[rr][q] = (c < kLmax) ? Ss[wave * 8 + rr][c] : -INFINITY;
+                mx[rr] = fmaxf(mx[rr], e[rr][q]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) mx[rr] = fmaxf(mx[rr], __shfl_xor(mx[rr], o));
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            sm[rr] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { e[rr][q] = __expf(e[rr][q] - mx[rr]); sm[rr] += e[rr][q]; }    // v_exp_f32 (1e-6 rel.); exp(-inf) = 0 for the padding columns
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) sm[rr] += __shfl_xor(sm[rr], o);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr;
+            const float inv = 1.f / sm[rr];
+            const bool rok = q0 + row < L;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int c = lane + 64 * q;
+                if (c < kLmax) {
+                    const float p = rok ? e[rr][q] * inv : 0.f;
+                    Ss[row][c] = p;
+                    if (rok) a.P[((int64_t)head * kLmax + q0 + row) * kLmax + c] = p;
+                }
+            }
         }
     }
     __syncthreads();
+#if defined(DPN_ATTN_STAGE) && DPN_ATTN_STAGE == 3
+    return;
+#endif
     f32x16 acc = (f32x16)0.f;
     mma_tile(acc, kLmax / 2, [&](int r, int k) { return Ss[r][k]; }, [&](int k, int c) { return Vs[k][c]; });
     reduce_tile(acc, part, [&](int r, int c, float v) {
