@@ -28,18 +28,44 @@ DEV f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f
 // rows [r0, r0+nr) x 32 head columns of a [L][256] matrix -> LDS [row][33]; rows >= L are zero
 // (all 16-byte loads are issued before the first LDS store: one memory round trip, not one per element)
 template <int NR>
-DEV void load_rows16(float (*dst)[33], const float* src, int64_t row_stride, int64_t col0, int r0, int L) {
+struct Rows16 { float4 v[(NR * 8 + 255) / 256]; };
+template <int NR>
+DEV void rows16_fetch(Rows16<NR>& R, const float* src, int64_t row_stride, int64_t col0, int r0, int L) {
     constexpr int N = (NR * 8 + 255) / 256;
-    float4 v[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         const int e = threadIdx.x + 256 * q, r = e >> 3, c4 = e & 7;
-        v[q] = (r < NR && r0 + r < L) ? *reinterpret_cast<const float4*>(src + (int64_t)(r0 + r) * row_stride + col0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        R.v[q] = (r < NR && r0 + r < L) ? *reinterpret_cast<const float4*>(src + (int64_t)(r0 + r) * row_stride + col0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+}
+template <int NR>
+DEV void rows16_store(float (*dst)[33], const Rows16<NR>& R) {
+    constexpr int N = (NR * 8 + 255) / 256;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         const int e = threadIdx.x + 256 * q, r = e >> 3, c4 = e & 7;
-        if (r < NR) { dst[r][c4 * 4] = v[q].x; dst[r][c4 * 4 + 1] = v[q].y; dst[r][c4 * 4 + 2] = v[q].z; dst[r][c4 * 4 + 3] = v[q].w; }
+        if (r < NR) { dst[r][c4 * 4] = R.v[q].x; dst[r][c4 * 4 + 1] = R.v[q].y; dst[r][c4 * 4 + 2] = R.v[q].z; dst[r][c4 * 4 + 3] = R.v[q].w; }
+    }
+}
+template <int NR>
+DEV void load_rows16(float (*dst)[33], const float* src, int64_t row_stride, int64_t col0, int r0, int L) {
+    Rows16<NR> R;
+    rows16_fetch<NR>(R, src, row_stride, col0, r0, L);
+    rows16_store<NR>(dst, R);
+}
+// D[r] = sum_e gO[r][e] * O[r][e] over the 32 columns of a head, rows r0 .. r0 + nrows: 8 lanes per row, one float4 of each operand per
+// lane (all loads in flight at once), joined by three shuffles
+DEV void head_rowdot(float* dst, const float* go, const float* o, int head, int r0, int nrows, int L) {
+    for (int base = 0; base < nrows; base += 32) {
+        const int r = base + (threadIdx.x >> 3), c4 = threadIdx.x & 7;
+        float d = 0.f;
+        if (r < nrows && r0 + r < L) {
+            const float4 g4 = *reinterpret_cast<const float4*>(go + (int64_t)(r0 + r) * kD + head * kE + c4 * 4);
+            const float4 o4 = *reinterpret_cast<const float4*>(o + (int64_t)(r0 + r) * kD + head * kE + c4 * 4);
+            d = fmaf(g4.x, o4.x, fmaf(g4.y, o4.y, fmaf(g4.z, o4.z, g4.w * o4.w)));
+        }
+        d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+        if (c4 == 0 && r < nrows) dst[r] = d;
     }
 }
 DEV void load_head_rows(float (*dst)[33], const float* src, int head, int r0, int nr, int L) {
@@ -208,13 +234,7 @@ DEV void attn_bwd_query_role(const AttnArgs& a, char* smem) {
             Ss[r][c4 * 4] = pv[q].x; Ss[r][c4 * 4 + 1] = pv[q].y; Ss[r][c4 * 4 + 2] = pv[q].z; Ss[r][c4 * 4 + 3] = pv[q].w;
         }
     }
-    if (threadIdx.x < 32) {
-        const int r = threadIdx.x;
-        float d = 0.f;
-        if (q0 + r < L)
-            for (int c = 0; c < kE; ++c) d = fmaf(a.go[(int64_t)(q0 + r) * kD + head * kE + c], a.o[(int64_t)(q0 + r) * kD + head * kE + c], d);
-        Drow[r] = d;
-    }
+    head_rowdot(Drow, a.go, a.o, head, q0, 32, L);
     __syncthreads();
     for (int ct = wave; ct < kLmax / 32; ct += 4) {
         f32x16 acc = (f32x16)0.f;
@@ -247,13 +267,10 @@ DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
     load_head_rows(Rs, a.go, head, 0, kLmax, L);
     load_rows16<kLmax>(Cs, a.P + (int64_t)head * kLmax * kLmax, kLmax, j0, 0, L);
     load_head_rows(Vt, a.v, head, j0, 32, L);
-    for (int r = threadIdx.x; r < kLmax; r += 256) {
-        float d = 0.f;
-        if (r < L)
-            for (int c = 0; c < kE; ++c) d = fmaf(a.go[(int64_t)r * kD + head * kE + c], a.o[(int64_t)r * kD + head * kE + c], d);
-        Dl[r] = d;
-    }
+    head_rowdot(Dl, a.go, a.o, head, 0, kLmax, L);
     __syncthreads();
+    Rows16<kLmax> qreg;                                                                      // Q is needed last: its loads fly under dV and dS
+    rows16_fetch<kLmax>(qreg, a.q, kD, head * kE, 0, L);
     f32x16 acc = (f32x16)0.f;
     mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dV[j][e] = sum_i P[i][j] gO[i][e]
     reduce_tile(acc, part, [&](int r, int c, float v) {
@@ -271,7 +288,7 @@ DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
         }
     }
     __syncthreads();
-    load_head_rows(Rs, a.q, head, 0, kLmax, L);
+    rows16_store<kLmax>(Rs, qreg);
     __syncthreads();
     acc = (f32x16)0.f;
     mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dK[j][e] = sum_i dS[i][j] Q[i][e]
