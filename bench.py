@@ -1,15 +1,20 @@
 #!/usr/bin/env python
 """Benchmark of the physics-informed training step on MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py [--gpus 1 --steps 200 --warmup 20] [--prec bf16x2] [--leads 61]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg2"): one field sample on the 0.25 degree grid (257 x 145 =
 37 265 collocation points, every grid node, t drawn per point), all six primitive-equation residual losses.
 One step = place_one_batch (encoder + hyper-network heads + fused HIP forward/Jacobian + residuals) + backward to
-all 155 parameter tensors + clip_grad_norm_(2.5e7) + Adam step; inputs are resident in HBM.  With N > 1 every rank
-runs its own field sample (weak scaling, as the reference's DistributedSampler does) and gradients are averaged with
-one RCCL all-reduce per step.  Prints ONE JSON line on rank 0.
+all 155 parameter tensors + clip_grad_norm_(2.5e7) + Adam step, captured in one hipGraph; inputs are resident in HBM.
+With N > 1 every rank runs its own field sample (weak scaling, as the reference's DistributedSampler does), the compute part is
+the graph and the gradient all-reduce (one RCCL call per step) + fused optimiser run eagerly behind it.
+--leads B: BASELINE configs[2], B field samples x 37 265 points in one step (place_lead_batch).
+
+Prints ONE JSON line on rank 0: the contract keys, `roofline` (dpn_fwd_kernel, MFMA-bound; duration from a HIP event pair around every
+launch inside a pre-queued replay of the point path), `roofline_hbm_kernel` (dpn_wgrad_kernel), `pde_losses` (the six scalars of the
+workload), `other_precision_mode`, `cpu_baseline` (the oracle on the host cores, reference schedule + shared-derivative variant).
 """
 import argparse
 import json
