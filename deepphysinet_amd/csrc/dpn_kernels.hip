@@ -1116,27 +1116,43 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     for (int m = 0; m < 4; ++m) { acc[m][0] = (f32x16)0.f; acc[m][1] = (f32x16)0.f; }
     float vecA[4] = {0.f, 0.f, 0.f, 0.f}, vecB[2] = {0.f, 0.f}, gsum = 0.f;
 
-    auto compute = [&](const char* buf) __attribute__((always_inline)) {
-        const float* gl = reinterpret_cast<const float*>(buf + NS * 32768 + wave * 256);
+    // LDS reads by inline asm with a counted wait: a read hipcc can see is ordered behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)
+    // in front of the first ds_read of every tile), which serialised fetch and compute -- DMA alone 156 us, compute alone 131 us,
+    // together 246 us before this, measured with stage-exit builds
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    auto rd128 = [&](u32x4& v, const unsigned addr) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    };
+    auto compute = [&](const int slot_) __attribute__((always_inline)) {
+        const unsigned buf = lds_base + slot_ * kSlot;
+        const unsigned gl = buf + NS * 32768 + wave * 256;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const float4 g0 = *reinterpret_cast<const float4*>(gl + 16 * kk + 4 * h), g1 = *reinterpret_cast<const float4*>(gl + 16 * kk + 4 * h + 8);
-            const float gp[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            u32x4 gq0, gq1;
+            u32x4 fa[NS][4], fb[NS][2];
+            rd128(gq0, gl + (16 * kk + 4 * h) * 4);
+            rd128(gq1, gl + (16 * kk + 4 * h + 8) * 4);
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) rd128(fa[s2][m], buf + s2 * 16384 + ((kk * 8 + wm * 4 + m) * 64 + lane) * 16);   // s2 >= nsx: dummy area, unused
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) rd128(fb[s2][n2], buf + NS * 16384 + s2 * 16384 + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
+            }
+            // every value passes through the wait, so no use can be scheduled in front of it
+            if constexpr (NS == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
+                             "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
+                             "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
+                             "+v"(fb[1][0]), "+v"(fb[1][1]) :: "memory");
+            }
+            const float gp[8] = {__uint_as_float(gq0[0]), __uint_as_float(gq0[1]), __uint_as_float(gq0[2]), __uint_as_float(gq0[3]),
+                                 __uint_as_float(gq1[0]), __uint_as_float(gq1[1]), __uint_as_float(gq1[2]), __uint_as_float(gq1[3])};
             if (prod == 1 && wave == 0 && i == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gsum += gp[e];
-            }
-            u32x4 fa[NS][4], fb[NS][2];
-#pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) {
-                if (s2 < nsx) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        fa[s2][m] = *reinterpret_cast<const u32x4*>(buf + s2 * 16384 + ((kk * 8 + wm * 4 + m) * 64 + lane) * 16);
-                }
-#pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2)
-                    fb[s2][n2] = *reinterpret_cast<const u32x4*>(buf + NS * 16384 + s2 * 16384 + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -1186,7 +1202,7 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
             const int64_t nt = tile + RING - 1;
             issue(nt < t1 ? nt : tl, (slot + RING - 1) % RING);          // refill the slot that compute(tile-1) just released
         }
-        if (active) compute(lds + slot * kSlot);
+        if (active) compute(slot);
         slot = (slot + 1) % RING;
     }
     wait_vmcnt<0>();
