@@ -1126,23 +1126,37 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     auto compute = [&](const int slot_) __attribute__((always_inline)) {
         const unsigned buf = lds_base + slot_ * kSlot;
         const unsigned gl = buf + NS * 32768 + wave * 256;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 gq0, gq1;
-            u32x4 fa[NS][4], fb[NS][2];
-            rd128(gq0, gl + (16 * kk + 4 * h) * 4);
-            rd128(gq1, gl + (16 * kk + 4 * h + 8) * 4);
+        constexpr int KB = (NS == 1) ? 2 : 1;                       // single-bf16 fragments: both k-steps of the tile are read up front
+        u32x4 gqa[KB][2], faa[KB][NS][4], fba[KB][NS][2];
+        auto issue_reads = [&](const int kk, const int b) __attribute__((always_inline)) {
+            rd128(gqa[b][0], gl + (16 * kk + 4 * h) * 4);
+            rd128(gqa[b][1], gl + (16 * kk + 4 * h + 8) * 4);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) rd128(fa[s2][m], buf + s2 * 16384 + ((kk * 8 + wm * 4 + m) * 64 + lane) * 16);   // s2 >= nsx: dummy area, unused
+                for (int m = 0; m < 4; ++m) rd128(faa[b][s2][m], buf + s2 * 16384 + ((kk * 8 + wm * 4 + m) * 64 + lane) * 16);   // s2 >= nsx: dummy area, unused
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) rd128(fb[s2][n2], buf + NS * 16384 + s2 * 16384 + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
+                for (int n2 = 0; n2 < 2; ++n2) rd128(fba[b][s2][n2], buf + NS * 16384 + s2 * 16384 + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
             }
-            // every value passes through the wait, so no use can be scheduled in front of it
+        };
+        if constexpr (NS == 1) { issue_reads(0, 0); issue_reads(1, 1); }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int b = (NS == 1) ? kk : 0;
+            if constexpr (NS == 2) issue_reads(kk, 0);
+            u32x4 (&fa)[NS][4] = faa[b];
+            u32x4 (&fb)[NS][2] = fba[b];
+            u32x4& gq0 = gqa[b][0];
+            u32x4& gq1 = gqa[b][1];
+            // every value passes through the wait, so no use can be scheduled in front of it (LDS reads retire in order: with the
+            // second k-step's eight reads still behind, the first k-step is complete at lgkmcnt(8))
             if constexpr (NS == 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
-                             "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory");
+                if (kk == 0)
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
+                                 "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
+                                 "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
                              "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
