@@ -473,8 +473,10 @@ DEV void store_d_as_k(const KMat& m, int net, int ns, int s, int64_t tile32, int
     uint4 a, b;
     a.x = pack2(d[0], d[1]); a.y = pack2(d[2], d[3]); a.z = pack2(d[4], d[5]); a.w = pack2(d[6], d[7]);
     b.x = pack2(d[8], d[9]); b.y = pack2(d[10], d[11]); b.z = pack2(d[12], d[13]); b.w = pack2(d[14], d[15]);
-    *reinterpret_cast<uint4*>(kmat_ptr(m, net, ns, s, tile32, ct, lane, 0)) = a;
-    *reinterpret_cast<uint4*>(kmat_ptr(m, net, ns, s, tile32, ct, lane, 1)) = b;
+    // streaming stores: 0.4 GB of operands per launch pass through once and must not evict the L2-resident weight stream
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    __builtin_nontemporal_store(u32x4_t{a.x, a.y, a.z, a.w}, reinterpret_cast<u32x4_t*>(kmat_ptr(m, net, ns, s, tile32, ct, lane, 0)));
+    __builtin_nontemporal_store(u32x4_t{b.x, b.y, b.z, b.w}, reinterpret_cast<u32x4_t*>(kmat_ptr(m, net, ns, s, tile32, ct, lane, 1)));
 }
 // transpose-store the two fragments (k-steps 2ct, 2ct+1) that make up column tile ct; zero rows of invalid points
 template <int NS, int NSTORE>
