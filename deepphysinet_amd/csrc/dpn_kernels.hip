@@ -209,6 +209,10 @@ DEV void dma16(const char* gsrc_lane, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
+DEV void dma16_nt(const char* gsrc_lane, char* lds_wave_base) {       // read-once streams (weight-gradient operands): non-temporal hint
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 2);
+}
 DEV void dma4(const char* gsrc_lane, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 4, 0, 0);
@@ -1108,7 +1112,7 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                 src = yb + (((int64_t)net * NS + s2) * tiles + tile) * ybytes + ry * 1024;
                 dst = sl + NS * 16384 + s2 * 16384 + (r - 16) * 1024;
             }
-            dma16(src + lane * 16, dst);
+            dma16_nt(src + lane * 16, dst);
         }
         dma4(reinterpret_cast<const char*>(gnet + tile * 32) + lane * 4, sl + NS * 32768 + wave * 256);
     };
