@@ -1293,7 +1293,7 @@ DEV int slot_of_pe6(int orig) {
 
 DEV float part_sum(const float* partials, int k_splits, int net, int off) {
     float s = 0.f;
-    for (int k = 0; k < k_splits; ++k) s += partials[((int64_t)k * kNets + net) * kPartFloats + off];
+    for (int k = 0; k < k_splits; ++k) s += __builtin_nontemporal_load(partials + ((int64_t)k * kNets + net) * kPartFloats + off);   // read once
     return s;
 }
 
@@ -1862,10 +1862,19 @@ __global__ __launch_bounds__(256) void dpn_adam_kernel(Table t, const double* su
     if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
         const int end4 = base + ((end - base) & ~3);
         for (int i = base + 4 * threadIdx.x; i < end4; i += 1024) {
-            float4 P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i), V = *reinterpret_cast<float4*>(v + i);
-            const float4 G = *reinterpret_cast<const float4*>(g + i);
+            // the moments and the gradient are touched by nobody else: streamed past the caches (the parameters stay cacheable, the
+            // next step reads them first)
+            typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+            float4 P = *reinterpret_cast<float4*>(p + i);
+            const f32x4_t Mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(m + i));
+            const f32x4_t Vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(v + i));
+            const f32x4_t Gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(g + i));
+            float4 M = make_float4(Mv[0], Mv[1], Mv[2], Mv[3]), V = make_float4(Vv[0], Vv[1], Vv[2], Vv[3]);
+            const float4 G = make_float4(Gv[0], Gv[1], Gv[2], Gv[3]);
             upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
-            *reinterpret_cast<float4*>(p + i) = P; *reinterpret_cast<float4*>(m + i) = M; *reinterpret_cast<float4*>(v + i) = V;
+            *reinterpret_cast<float4*>(p + i) = P;
+            __builtin_nontemporal_store(f32x4_t{M.x, M.y, M.z, M.w}, reinterpret_cast<f32x4_t*>(m + i));
+            __builtin_nontemporal_store(f32x4_t{V.x, V.y, V.z, V.w}, reinterpret_cast<f32x4_t*>(v + i));
         }
         scalar_from = end4;
     }
