@@ -900,7 +900,7 @@ __global__ __launch_bounds__(384) void dpn_residual_finish_kernel(const double* 
 }
 
 __global__ __launch_bounds__(256) void dpn_smooth_l1_kernel(const float* out_n, const float* labels, int64_t n, float beta, float scale,
-                                                            double* loss_sum, float* g_out) {
+                                                            double* loss_sum, float* g_out, int accumulate, const float* scale_dev) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // one element of [N][6]
     const bool valid = i < n * 6;
     float l = 0.f;
@@ -908,7 +908,10 @@ __global__ __launch_bounds__(256) void dpn_smooth_l1_kernel(const float* out_n, 
         const float d = out_n[i] - labels[i];
         const float ad = fabsf(d);
         l = (ad < beta) ? 0.5f * d * d / beta : ad - 0.5f * beta;    // nn.SmoothL1Loss(beta), weights_loss.py:15-19
-        if (g_out) g_out[i] = scale * ((ad < beta) ? d / beta : (d > 0.f ? 1.f : -1.f));
+        if (g_out) {
+            const float gv = scale * (scale_dev ? scale_dev[0] : 1.f) * ((ad < beta) ? d / beta : (d > 0.f ? 1.f : -1.f));
+            g_out[i] = accumulate ? g_out[i] + gv : gv;             // accumulate: joins the PDE cotangent of the same points
+        }
     }
     if (!loss_sum) return;
     double s = (double)l;                          // one fp64 partial per block, fixed order, no atomics: the caller adds the blocks up
@@ -1981,10 +1984,11 @@ int dpn_residual_finish(const double* loss_sums, int64_t n, const DpnPhysics* ph
     return ck(hipGetLastError());
 }
 
-int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n, float beta, float scale, double* loss_sum, float* g_out, void* stream) {
+int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n, float beta, float scale, double* loss_sum, float* g_out, int accumulate,
+                  const float* scale_dev, void* stream) {
     if (!out_n || !labels || n <= 0) return -1;
     hipLaunchKernelGGL(dpn_smooth_l1_kernel, dim3((unsigned)((n * 6 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       out_n, labels, n, beta, scale, loss_sum, g_out);
+                       out_n, labels, n, beta, scale, loss_sum, g_out, accumulate, scale_dev);
     return ck(hipGetLastError());
 }
 

@@ -235,17 +235,30 @@ class InterfacePhysics(nn.Module):
         lf = self.train_cfg['losses']['loss_factor']
         self.physics_net.clear_field_cache()
         b = batch
-        loss = self.data_loss(b['margin_x'], b['margin_y'], b['margin_t'], b['field_data'], b['margin_input_data'], b['margin_data'],
-                              b['forecast_h'], lf['margin_factor'], use_cache=True)
-        parts = {'margin_loss': loss}
-        if with_pde:
-            crit = nn.MSELoss()
-            parts['inter_pde_loss'] = self.place_one_batch(b['inter_x'], b['inter_y'], b['inter_t'], b['inter_f'], b['field_data'],
-                                                           b['inter_data'], b['forecast_h'], crit, lf, 0, 0, b['field_data'].device,
-                                                           use_cache=True)
-            parts['margin_pde_loss'] = self.place_one_batch(b['margin_x'], b['margin_y'], b['margin_t'], b['margin_f'], b['field_data'],
-                                                            b['margin_input_data'], b['forecast_h'], crit, lf, 0, 0,
-                                                            b['field_data'].device, prefix='margin', use_cache=True)
+        if with_pde and b['field_data'].is_cuda:
+            # one point pass for everything: [interior | margin] points, PDE means per group, SmoothL1 on the margin rows; the margin
+            # forward serves both of its losses and all points share one backward (point_path._StepLossFn)
+            from ..point_path import step_losses
+            cfg = self.point_config(lf)
+            heads, evec, statics = self.physics_net.field_weights(b['field_data'], b['forecast_h'])
+            cat = lambda a_, b_: torch.cat([a_.reshape(a_.shape[0], -1), b_.reshape(b_.shape[0], -1)], dim=0)
+            _, inter_total, _, margin_total, data = step_losses(
+                cfg, b['inter_x'].shape[0], cat(b['inter_x'], b['margin_x']), cat(b['inter_y'], b['margin_y']), cat(b['inter_t'], b['margin_t']),
+                cat(b['inter_f'], b['margin_f']), cat(b['inter_data'], b['margin_input_data']), b['margin_data'], heads, evec, statics,
+                beta=0.1, margin_factor=lf['margin_factor'])
+            parts = {'margin_loss': data, 'inter_pde_loss': inter_total.float(), 'margin_pde_loss': margin_total.float()}
+        else:
+            loss = self.data_loss(b['margin_x'], b['margin_y'], b['margin_t'], b['field_data'], b['margin_input_data'], b['margin_data'],
+                                  b['forecast_h'], lf['margin_factor'], use_cache=True)
+            parts = {'margin_loss': loss}
+            if with_pde:
+                crit = nn.MSELoss()
+                parts['inter_pde_loss'] = self.place_one_batch(b['inter_x'], b['inter_y'], b['inter_t'], b['inter_f'], b['field_data'],
+                                                               b['inter_data'], b['forecast_h'], crit, lf, 0, 0, b['field_data'].device,
+                                                               use_cache=True)
+                parts['margin_pde_loss'] = self.place_one_batch(b['margin_x'], b['margin_y'], b['margin_t'], b['margin_f'], b['field_data'],
+                                                                b['margin_input_data'], b['forecast_h'], crit, lf, 0, 0,
+                                                                b['field_data'].device, prefix='margin', use_cache=True)
         train_loss = 0
         for v in parts.values():
             train_loss = train_loss + v

@@ -337,6 +337,78 @@ class _PdeLossBatchFn(torch.autograd.Function):
         return (None, None, None, None, None, None, g_heads, g_evec, *gst)
 
 
+class _StepLossFn(torch.autograd.Function):
+    """The loss of the reference's step body (interface_physics.py:464-501) in ONE point pass: the first n_inter points are the interior
+    collocation points, the rest the margin (grid-node, labelled) points.  Returns (inter_terms [6], inter_total, margin_terms [6],
+    margin_total, data_loss): the PDE means are taken per group, the SmoothL1 data loss over the margin points; the margin points'
+    forward serves both of their losses, and all 24 576 points share one backward / weight-gradient / finish sequence."""
+
+    @staticmethod
+    def forward(ctx, cfg, n_inter, beta, margin_factor, x, y, t, f, coord_data, labels, heads, evec, *statics):
+        for nm, v in (('x', x), ('coord_data', coord_data), ('heads', heads), ('labels', labels)):
+            _require_gpu(v, nm)
+        lib = L.load()
+        x_, y_, t_, f_ = (_f32c(v).reshape(-1) for v in (x, y, t, f))
+        cd_, hd_, ev_, lab_ = _f32c(coord_data), _f32c(heads), _f32c(evec), _f32c(labels)
+        st = [_f32c(s) for s in statics]
+        n = cd_.shape[0]
+        n_m = n - n_inter
+        assert 0 < n_inter < n and lab_.shape[0] == n_m
+        dev = cd_.device
+        need_grad = any(v.requires_grad for v in (heads, evec) + tuple(statics))
+        ws = _Workspace(n, cfg.prec, dev)
+        nets = _net_ptrs(hd_, ev_, st)
+        out_n, jac_n = _forward_points(cfg, ws, nets, x_, y_, t_, None, cd_, want_jac=True, want_saved=need_grad)
+        geo, ph = cfg.geometry(), cfg.physics()
+        losses = torch.empty((2, 7), dtype=torch.float32, device=dev)
+        for gi, (a0, a1) in enumerate(((0, n_inter), (n_inter, n))):
+            sums = torch.empty(((a1 - a0 + 255) // 256) * 6, dtype=torch.float64, device=dev)
+            L.check(lib.dpn_residual(_ptr(out_n[a0:]), _ptr(jac_n[a0:]), _ptr(f_[a0:]), a1 - a0, ctypes.byref(geo), ctypes.byref(ph), None, None,
+                                     _ptr(sums), None, None, _stream()), 'dpn_residual')
+            L.check(lib.dpn_residual_finish(_ptr(sums), a1 - a0, ctypes.byref(ph), _ptr(losses[gi]), _stream()), 'dpn_residual_finish')
+        dsum = torch.empty((n_m * 6 + 255) // 256, dtype=torch.float64, device=dev)
+        L.check(lib.dpn_smooth_l1(_ptr(out_n[n_inter:]), _ptr(lab_), n_m, beta, 1.0, _ptr(dsum), None, 0, None, _stream()), 'dpn_smooth_l1')
+        data = (dsum.sum() / (6.0 * n_m)).float() * margin_factor
+        ctx.cfg, ctx.ws, ctx.n_inter, ctx.beta, ctx.margin_factor = cfg, ws, n_inter, beta, margin_factor
+        ctx.keep = (x_, y_, t_, f_, cd_, lab_, hd_, ev_, st, out_n, jac_n)
+        ctx.set_materialize_grads(False)
+        return losses[0, :6], losses[0, 6], losses[1, :6], losses[1, 6], data
+
+    @staticmethod
+    def backward(ctx, g_la, g_ta, g_lb, g_tb, g_data):
+        lib = L.load()
+        cfg, n_inter = ctx.cfg, ctx.n_inter
+        x_, y_, t_, f_, cd_, lab_, hd_, ev_, st, out_n, jac_n = ctx.keep
+        n = cd_.shape[0]
+        n_m = n - n_inter
+        dev = cd_.device
+        if all(v is None for v in (g_la, g_ta, g_lb, g_tb, g_data)):
+            return (None,) * (12 + len(st))
+        g_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
+        g_jxi = torch.empty((n, 6, 3), dtype=torch.float32, device=dev)
+        geo, ph = cfg.geometry(), cfg.physics()
+        zero6 = None
+        for (a0, a1), gl, gt in (((0, n_inter), g_la, g_ta), ((n_inter, n), g_lb, g_tb)):
+            if gl is None and gt is None:                     # this group's PDE losses are unused: zero cotangent
+                zero6 = torch.zeros(6, dtype=torch.float32, device=dev) if zero6 is None else zero6
+                gl = zero6
+            L.check(lib.dpn_residual(_ptr(out_n[a0:]), _ptr(jac_n[a0:]), _ptr(f_[a0:]), a1 - a0, ctypes.byref(geo), ctypes.byref(ph),
+                                     None if gl is None else _ptr(_f32c(gl)), None if gt is None else _ptr(_f32c(gt).reshape(1)), None,
+                                     _ptr(g_out[a0:]), _ptr(g_jxi[a0:]), _stream()), 'dpn_residual(grad)')
+        if g_data is not None:                                # + d(data loss)/d out on the margin rows
+            L.check(lib.dpn_smooth_l1(_ptr(out_n[n_inter:]), _ptr(lab_), n_m, ctx.beta, ctx.margin_factor / (6.0 * n_m), None,
+                                      _ptr(g_out[n_inter:]), 1, _ptr(_f32c(g_data).reshape(1)), _stream()), 'dpn_smooth_l1(grad)')
+        nets = _net_ptrs(hd_, ev_, st)
+        ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st)
+        return (None,) * 10 + (ghd, gev, *gst)
+
+
+def step_losses(cfg: PointConfig, n_inter, x, y, t, f, coord_data, labels, heads, evec, statics, beta=0.1, margin_factor=1.0):
+    """(inter_terms [6], inter_total, margin_terms [6], margin_total, data_loss) of the reference's step body in one point pass; the first
+    n_inter rows of x, y, t, f, coord_data are the interior points, the rest the margin points whose labels are `labels` (_StepLossFn)."""
+    return _StepLossFn.apply(cfg, int(n_inter), float(beta), float(margin_factor), x, y, t, f, coord_data, labels, heads, evec, *statics)
+
+
 def pde_losses_batch(cfg: PointConfig, x, y, t, f, coord_data, heads, evec, statics):
     """(losses [B,6], totals [B]) for B field samples with N points each; tensors carry a leading B (see _PdeLossBatchFn)."""
     return _PdeLossBatchFn.apply(cfg, x, y, t, f, coord_data, heads, evec, *statics)
@@ -382,7 +454,7 @@ class _SmoothL1Fn(torch.autograd.Function):
         n = o.shape[0]
         s = torch.empty((n * 6 + 255) // 256, dtype=torch.float64, device=o.device)      # per-block partial sums
         g = torch.empty_like(o)
-        L.check(lib.dpn_smooth_l1(_ptr(o), _ptr(l), n, beta, factor / (6.0 * n), _ptr(s), _ptr(g), _stream()), 'dpn_smooth_l1')
+        L.check(lib.dpn_smooth_l1(_ptr(o), _ptr(l), n, beta, factor / (6.0 * n), _ptr(s), _ptr(g), 0, None, _stream()), 'dpn_smooth_l1')
         ctx.save_for_backward(g)
         return ((s.sum() / (6.0 * n)).float() * factor)
 

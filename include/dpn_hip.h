@@ -127,7 +127,8 @@ int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_
 /* SmoothL1(beta) data loss on the normalised fields (losses/weights_loss.py:17-20): per-block sums -> loss_sum[ceil(6N/256)] (fp64,
  * written not accumulated; the caller adds them in a fixed order), g_out = scale * dSmoothL1 (may be NULL). */
 int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, float beta, float scale,
-                  double* loss_sum, float* g_out, void* stream);
+                  double* loss_sum, float* g_out, int accumulate /* g_out += instead of = */,
+                  const float* scale_dev /* optional device scalar multiplied into scale (an upstream cotangent) */, void* stream);
 
 /* Small fp32 GEMM for the per-field tensors (encoder linears of model/attn.py:177-196 and transformer_net.py:28-44, the
  * hyper-network heads of variable_net.py:59-65):  C[M][N] = op(A)[M][K] op(B)[K][N] (+ bias[N]) (+ C if accumulate);
