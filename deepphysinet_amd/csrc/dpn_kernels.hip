@@ -597,6 +597,9 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
             m1w[T >> 1] |= ((p0 > 0.f) ? (1u << (16 * (T & 1) + r)) : 0u) | ((p1 > 0.f) ? (2u << (16 * (T & 1) + r)) : 0u);
             frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, relu1(p0), relu1(p1));
         }
+        // pin the mask word HERE: left alone, the scheduler postpones the compares to the first use of m1w (after fc1) and keeps the
+        // tile's 16 pre-activations alive until then -- in AGPRs for bf16, in SCRATCH for the hi+lo mode, whose reloads drain the DMA ring
+        asm volatile("" : "+v"(m1w[T >> 1]));
     };
     {
         Frag<NS> pe[12];
