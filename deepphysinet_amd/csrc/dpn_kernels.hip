@@ -228,7 +228,7 @@ DEV void wait_vmcnt_n(const int n) {        // n is a compile-time constant afte
     }
 }
 // k-steps of chunk c in stream order (dpn_layout.h): w1 8x12 | w2 8x16 | Wd 8x12 | W1 8x16 | W1^T 8x16 | w2^T 8x16 | w1^T 6x16
-DPN_HD int stream_nk(int c, int end) { return (c < 0 || c >= end) ? 0 : (c < 8 ? 12 : c < 16 ? 16 : c < 24 ? 12 : 16); }
+DPN_HD __attribute__((always_inline)) int stream_nk(int c, int end) { return (c < 0 || c >= end) ? 0 : (c < 8 ? 12 : c < 16 ? 16 : c < 24 ? 12 : 16); }
 
 template <int NS>
 struct Pipe {

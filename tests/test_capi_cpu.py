@@ -115,3 +115,25 @@ def test_point_path_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         m.place_one_batch(z, z, z, z, torch.zeros(1, 159, 2405), torch.zeros(n, 6), torch.zeros(1, 1, 1), torch.nn.MSELoss(),
                           m.train_cfg['losses']['loss_factor'], 0, 0, 'cpu')
+
+
+def test_inline_asm_lds_reads_are_waited_for_before_any_use(tmp_path):
+    """The point kernels read LDS with inline-asm ds_read_b128 + counted lgkmcnt waits the compiler knows nothing about:
+    scan the generated gfx950 assembly for any instruction that touches a destination register before its wait
+    (tools/lds_hazard_check.py).  Build-time check, no GPU needed."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = str(tmp_path / 'dpn_kernels.s')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', '-I' + os.path.join(root, 'include'),
+                    os.path.join(root, 'deepphysinet_amd', 'csrc', 'dpn_kernels.hip'), '-o', asm], check=True, capture_output=True)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'lds_hazard_check.py'), asm,
+                        'dpn_fwd_kernel', 'dpn_bwd_kernel', 'dpn_wgrad_kernel'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert r.stdout.count(' 0 hazards') == 6, r.stdout
+    text = open(asm).read()
+    assert 's_swappc_b64' not in text, 'a helper was not inlined: the kernels must not make calls'

@@ -1,0 +1,89 @@
+"""Static check of the inline-asm LDS reads in the point kernels.
+
+The forward / backward / weight-gradient kernels read their LDS operands with
+inline-asm `ds_read_b128` and counted `s_waitcnt lgkmcnt(N)` (hipcc would drain
+every LDS-DMA in flight before a read it can see).  The compiler does not know
+those destination registers are pending, so nothing but the source order stops
+it from touching one (a copy to an AGPR, a spill) before the wait that covers
+it.  This tool scans the device assembly of a kernel in program order, models
+the LGKM counter (LDS operations retire in order) and reports every instruction
+that names a register whose ds_read has not been waited for.
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -Iinclude \
+        deepphysinet_amd/csrc/dpn_kernels.hip -o /tmp/k.s
+    python tools/lds_hazard_check.py /tmp/k.s dpn_fwd_kernel dpn_bwd_kernel dpn_wgrad_kernel
+
+Control flow is ignored (the scan is linear), which is exact for the unrolled
+pipelines of these kernels: no ds_read is pending across a backward branch.
+"""
+import re
+import sys
+
+REG = re.compile(r'\b([va])(?:(\d+)|\[(\d+):(\d+)\])')
+LGKM = re.compile(r'^(ds_|s_load|s_buffer_load|s_sendmsg|s_memtime|s_memrealtime)')
+WAIT = re.compile(r'lgkmcnt\((\d+)\)')
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        kind = m.group(1)
+        if m.group(2) is not None:
+            out.add((kind, int(m.group(2))))
+        else:
+            out.update((kind, i) for i in range(int(m.group(3)), int(m.group(4)) + 1))
+    return out
+
+
+def check(lines, name):
+    pending = []                     # one entry per outstanding LGKM operation: set of destination registers (empty for writes)
+    hazards = 0
+    n_reads = 0
+    max_pending = 0
+    for no, raw in lines:
+        ins = raw.split(';')[0].strip()
+        if not ins or ins.endswith(':') or ins.startswith('.'):
+            continue
+        op = ins.split()[0]
+        touched = regs_of(ins[len(op):])
+        live = set().union(*pending) if pending else set()
+        bad = touched & live
+        if bad:
+            hazards += 1
+            print(f'{name}: line {no}: `{ins}` touches pending {sorted(bad)[:4]}')
+        if op == 's_waitcnt':
+            m = WAIT.search(ins)
+            if m:
+                n = int(m.group(1))
+                pending = pending[len(pending) - n:] if n else []
+            elif 'lgkmcnt' not in ins and re.fullmatch(r's_waitcnt\s+(0x[0-9a-f]+|\d+)', ins):
+                pending = []         # raw immediate: treat as a full wait only if the lgkm field is 0 (not emitted by this code base)
+        elif LGKM.match(op):
+            dst = set()
+            if op.startswith('ds_read') or op.startswith('ds_bpermute') or op.startswith('ds_permute') or op.startswith('ds_swizzle'):
+                first = ins[len(op):].split(',')[0]
+                dst = regs_of(first)
+                n_reads += op.startswith('ds_read')
+            pending.append(dst)
+            max_pending = max(max_pending, len(pending))
+    print(f'{name}: {n_reads} ds_read, at most {max_pending} LGKM operations in flight (the counter holds 15: issue stalls beyond), {hazards} hazards')
+    return hazards
+
+
+def main():
+    path, wanted = sys.argv[1], sys.argv[2:]
+    text = open(path).read().split('\n')
+    starts = [(i, l.split(':')[0]) for i, l in enumerate(text) if re.match(r'^_Z\w+:', l)]
+    total = 0
+    for idx, (i, sym) in enumerate(starts):
+        if wanted and not any(w in sym for w in wanted):
+            continue
+        end = next((j for j in range(i, len(text)) if text[j].strip().startswith('s_endpgm')), len(text))
+        # kernels with several exits: run to the .Lfunc_end label
+        end = next((j for j in range(i, len(text)) if text[j].startswith('.Lfunc_end')), end)
+        total += check([(j + 1, text[j]) for j in range(i + 1, end)], sym)
+    sys.exit(1 if total else 0)
+
+
+if __name__ == '__main__':
+    main()
