@@ -65,7 +65,7 @@ def test_library_is_the_hip_one_and_layout_selftest_passes():
 
 
 @pytest.mark.parametrize('prec', ['bf16x2', 'bf16'])
-@pytest.mark.parametrize('n', [256, 200, 1])
+@pytest.mark.parametrize('n', [1037, 256, 200, 1])       # 1037: nine 128-point workgroups, five 256-row loss blocks, a ragged tail of 13
 def test_fields_jacobian_losses_gradients_vs_oracle(prec, n):
     import deepphysinet_amd as dpn
     tol = TOL[prec]
@@ -80,7 +80,17 @@ def test_fields_jacobian_losses_gradients_vs_oracle(prec, n):
     assert float((out_n.cpu() - ref['fields']).abs().max() / ref['fields'].abs().max()) < tol['field']
     for k in range(6):
         r = ref['jac_n'][:, k]
-        assert float((jac_n.cpu()[:, k] - r).abs().max() / r.abs().max()) < tol['jac'], k
+        err = (jac_n.cpu()[:, k] - r).abs()
+        if n <= 256:
+            assert float(err.max() / r.abs().max()) < tol['jac'], k
+        else:
+            # The Jacobian of a ReLU network is piecewise constant in the hidden signs: with enough points one pre-activation lands
+            # within rounding distance of zero and its sign -- hence one point's Jacobian entries -- differs between any two
+            # arithmetics (fp32 autograd vs hi+lo bf16 MFMA; measured: 2 such points among 1037 x 6 nets, tools/jac_diag.py).
+            # So: the same bound for 99.5 % of the entries, and the entries beyond it are isolated (< 0.2 %).
+            bound = tol['jac'] * float(r.abs().max())
+            assert float(torch.quantile(err.flatten(), 0.995)) < bound, k
+            assert float((err > bound).float().mean()) < 2e-3, k
     m.physics_net.zero_grad()
     terms = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'])
     terms.sum().backward()
