@@ -1297,10 +1297,26 @@ DEV int slot_of_pe6(int orig) {
     return 16 * ks + 8 * h + 2 * p + fn;
 }
 
-DEV float part_sum(const float* partials, int k_splits, int net, int off) {
-    float s = 0.f;
-    for (int k = 0; k < k_splits; ++k) s += __builtin_nontemporal_load(partials + ((int64_t)k * kNets + net) * kPartFloats + off);   // read once
-    return s;
+// NQ sums over the k_splits partial buffers, ALL their loads in flight at once (a loop of load -> wait -> add, which is what hipcc
+// makes of the obvious code, costs one HBM round trip per split and per sum: 40 in a row per thread).  Splits beyond k_splits re-read
+// the last one and are not added; the additions keep the split order, so the result does not depend on how the loads are grouped.
+constexpr int kMaxSplits = 10;                  // choose_splits() never returns more
+template <int NQ>
+DEV void part_sums(const float* partials, int k_splits, int net, const int (&off)[NQ], float (&out)[NQ]) {
+    float v[kMaxSplits][NQ];
+#pragma unroll
+    for (int k = 0; k < kMaxSplits; ++k) {
+        const float* base = partials + ((int64_t)min(k, k_splits - 1) * kNets + net) * kPartFloats;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[k][q] = __builtin_nontemporal_load(base + off[q]);   // read once
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxSplits; ++k) t += (k < k_splits) ? v[k][q] : 0.f;
+        out[q] = t;
+    }
 }
 
 // one block per (output row o, net): reduces the splits, un-permutes, writes dW1, d(w2b2), d(w1b1), dWd rows and r[o]
@@ -1314,13 +1330,25 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
     const float* vec = reinterpret_cast<const float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
     const int T = o >> 5, w = o & 31, hh = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);
     const float uo = vec[kVecU * 256 + hh * 128 + T * 16 + r];
-    const float Goi = part_sum(a.partials, a.k_splits, net, part_off(0) + so * 256 + i);   // Z's columns are in natural order (SWAP output)
+    // thread 0 also owns the row's three vector entries: fetched with everything else, not after the reduction
+    float rowv[3] = {0.f, 0.f, 0.f};
+    if (i == 0) {
+        const int offv[3] = {kPartVec + 0 * 256 + so, kPartVec + 2 * 256 + so, kPartVec + 3 * 256 + so};
+        part_sums<3>(a.partials, a.k_splits, net, offv, rowv);
+    }
+    const int off2[2] = {part_off(0) + so * 256 + i, part_off(1) + so * 256 + si};      // Z's columns are in natural order (SWAP output)
+    float g2[2];
+    part_sums<2>(a.partials, a.k_splits, net, off2, g2);
+    const float Goi = g2[0];
     Gd.W1[o * 256 + i] = uo * Goi;
     red[i] = P.W1[o * 256 + i] * Goi;
-    Gd.w2b2[o * Gd.ld_w2b2 + i] = part_sum(a.partials, a.k_splits, net, part_off(1) + so * 256 + si);
+    Gd.w2b2[o * Gd.ld_w2b2 + i] = g2[1];
     if (i < kPe) {
-        Gd.Wd[o * kPe + i] = part_sum(a.partials, a.k_splits, net, part_off(2) + so * 192 + slot_of_pe6(i));
-        Gd.w1b1[o * Gd.ld_w1b1 + i] = part_sum(a.partials, a.k_splits, net, part_off(3) + so * 192 + slot_of_pe3(i));
+        const int offp[2] = {part_off(2) + so * 192 + slot_of_pe6(i), part_off(3) + so * 192 + slot_of_pe3(i)};
+        float gp[2];
+        part_sums<2>(a.partials, a.k_splits, net, offp, gp);
+        Gd.Wd[o * kPe + i] = gp[0];
+        Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[1];
     }
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -1328,9 +1356,7 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
         __syncthreads();
     }
     if (i == 0) {
-        const float mvec = part_sum(a.partials, a.k_splits, net, kPartVec + 0 * 256 + so);
-        const float gcv = part_sum(a.partials, a.k_splits, net, kPartVec + 2 * 256 + so);
-        const float db1 = part_sum(a.partials, a.k_splits, net, kPartVec + 3 * 256 + so);
+        const float mvec = rowv[0], gcv = rowv[1], db1 = rowv[2];
         a.scratch_r[net * 256 + o] = red[0] + P.bf1[o] * mvec;
         Gd.bf1[o] = uo * mvec;
         Gd.w2b2[o * Gd.ld_w2b2 + 256] = gcv;
@@ -1346,6 +1372,11 @@ __global__ __launch_bounds__(256) void dpn_finish_fc2_kernel(FinishArgs a) {
     const DpnNetPtrs& P = a.net[net];
     const DpnNetGradPtrs& Gd = a.grad[net];
     __shared__ float red[256];
+    float sq[2] = {0.f, 0.f};
+    if (o == 0) {
+        const int offv[2] = {kPartVec + 4 * 256, kPartVec + 1 * 256 + op};
+        part_sums<2>(a.partials, a.k_splits, net, offv, sq);
+    }
     const float r = a.scratch_r[net * 256 + o];
     const float wop = P.wo[op];
     Gd.W2[op * 256 + o] = wop * r;
@@ -1356,8 +1387,7 @@ __global__ __launch_bounds__(256) void dpn_finish_fc2_kernel(FinishArgs a) {
         __syncthreads();
     }
     if (o == 0) {
-        const float s = part_sum(a.partials, a.k_splits, net, kPartVec + 4 * 256);
-        const float q = part_sum(a.partials, a.k_splits, net, kPartVec + 1 * 256 + op);
+        const float s = sq[0], q = sq[1];
         Gd.bf2[op] = wop * s;
         Gd.wo[op] = red[0] + P.bf2[op] * s + 2.f * q;
         if (op == 0) Gd.bo[0] = s;
@@ -1915,15 +1945,12 @@ __global__ void dpn_selftest_kernel(float* out) {
 // ------------------------------------------------------------------------------------------------ C ABI
 static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 static inline int choose_splits(int64_t n_pad) {
-#ifdef DPN_EXP_SPLITS
-    return DPN_EXP_SPLITS;
-#endif
     // 24 workgroups (4 products x 6 nets) per split and one 8-wave workgroup per CU (LDS ring): 10 splits = 240 workgroups is
     // the largest single round on 256 CUs.  Measured at 37 265 points: 10 -> 19.3 M points/s, 11 -> 18.1 M (tail round),
     // 21 -> 18.7 M (two rounds, twice the partials for dpn_finish_rows to reduce).
     int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
-    if (c > 10) c = 10;
+    if (c > kMaxSplits) c = kMaxSplits;         // dpn_finish_* keep one load per split in flight
     return (int)c;
 }
 static inline int ck(hipError_t e) { return (int)e; }
