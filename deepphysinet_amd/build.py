@@ -21,13 +21,34 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+# (source, extra flags, object name).  dpn_kernels.hip is two translation units: the point forward / backward kernels are compiled with
+# MFMA results in VGPRs (no v_accvgpr_read per epilogue element: forward kernel -10 %), the rest (weight-gradient kernel, GEMMs,
+# optimiser) measures better with hipcc's default AGPR accumulators -- see the DPN_TU comment in the source.
+UNITS = [(SRCS[0], ['-DDPN_TU=1', '-mllvm', '-amdgpu-mfma-vgpr-form'], 'dpn_point.o'),
+         (SRCS[0], ['-DDPN_TU=2'], 'dpn_rest.o'),
+         (SRCS[1], [], 'dpn_encoder.o'),
+         (SRCS[2], [], 'dpn_sampler.o')]
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: libdpn_hip.so cannot be built (no CPU fallback exists)')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', *SRCS, '-o', LIB + '.tmp']
+    obj_dir = os.path.join(HERE, 'csrc', '_obj')
+    os.makedirs(obj_dir, exist_ok=True)
+    procs = []
+    for src, flags, obj in UNITS:                                   # the four units compile side by side
+        cmd = [hipcc, *COMMON, *flags, '-I' + os.path.join(os.path.dirname(HERE), 'include'), '-c', src, '-o', os.path.join(obj_dir, obj)]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *[os.path.join(obj_dir, u[2]) for u in UNITS], '-o', LIB + '.tmp']
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

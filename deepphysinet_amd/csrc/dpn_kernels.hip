@@ -36,6 +36,21 @@ typedef unsigned short u16;
 
 #define DEV __device__ __forceinline__
 
+// Translation units.  The library is built from this file TWICE (deepphysinet_amd/build.py): DPN_TU=1 holds the point forward and
+// backward kernels and is compiled with -mllvm -amdgpu-mfma-vgpr-form (accumulators in VGPRs: hipcc otherwise parks them in AGPRs and
+// pays a v_accvgpr_read for every element an epilogue touches -- 1775 of the forward kernel's 6457 VALU instructions); DPN_TU=2 holds
+// everything else (the weight-gradient kernel measures slower in that form).  Without DPN_TU the file is one unit.
+#if !defined(DPN_TU) || DPN_TU == 1
+#define DPN_HAS_POINT 1
+#else
+#define DPN_HAS_POINT 0
+#endif
+#if !defined(DPN_TU) || DPN_TU == 2
+#define DPN_HAS_REST 1
+#else
+#define DPN_HAS_REST 0
+#endif
+
 // ------------------------------------------------------------------------------------------------ small helpers
 typedef unsigned int u32;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -171,6 +186,7 @@ DEV void pack_vectors(const PackArgs& a, const int net) {
     }
 }
 
+#if DPN_HAS_REST
 __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
     if (blockIdx.x == gridDim.x - 1) { pack_vectors(a, blockIdx.y); return; }      // last block column: the fp32 vectors of this net
     const int net = blockIdx.y;
@@ -196,6 +212,8 @@ __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
         }
     }
 }
+
+#endif  // DPN_HAS_REST
 
 // ------------------------------------------------------------------------------------------------ weight stream
 // All four waves of a workgroup walk the same packed weight block chunk by chunk (one chunk = the A fragments of one 32-row
@@ -770,6 +788,7 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     }
 }
 
+#if DPN_HAS_REST
 // g_pe[n][c] = sum_k g_out[n][k] * gpe[n][k][c]: the cotangent of caller-encoded coordinates (PhysicsNet.forward backward w.r.t. coord_x)
 __global__ __launch_bounds__(192) void dpn_contract_gpe_kernel(const float* g_out, const float* gpe, int64_t n, float* g_pe) {
     const int64_t pt = blockIdx.x;
@@ -926,6 +945,8 @@ __global__ __launch_bounds__(256) void dpn_smooth_l1_kernel(const float* out_n, 
     if (threadIdx.x == 0) loss_sum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+#endif  // DPN_HAS_REST
+
 // ------------------------------------------------------------------------------------------------ backward, stage 1
 struct BwdArgs {
     const float *x, *y, *t, *coord_data, *freqs, *pe_in;
@@ -1046,6 +1067,7 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
     }
 }
 
+#if DPN_HAS_REST
 // ------------------------------------------------------------------------------------------------ backward, stage 2
 // Points-reduction GEMMs  D[so][si] = sum_pt X[pt][so] * Y[pt][si]  for the four products of a net:
 //   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q = Z^T 1
@@ -1942,8 +1964,11 @@ __global__ void dpn_selftest_kernel(float* out) {
     for (int r = 0; r < 16; ++r) { out[lane * 16 + r] = acc1[r]; out[1024 + lane * 16 + r] = acc2[r]; }
 }
 
+#endif  // DPN_HAS_REST
+
 // ------------------------------------------------------------------------------------------------ C ABI
 static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
+#if DPN_HAS_REST
 static inline int choose_splits(int64_t n_pad) {
     // 24 workgroups (4 products x 6 nets) per split and one 8-wave workgroup per CU (LDS ring): 10 splits = 240 workgroups is
     // the largest single round on 256 CUs.  Measured at 37 265 points: 10 -> 19.3 M points/s, 11 -> 18.1 M (tail round),
@@ -1953,10 +1978,12 @@ static inline int choose_splits(int64_t n_pad) {
     if (c > kMaxSplits) c = kMaxSplits;         // dpn_finish_* keep one load per split in flight
     return (int)c;
 }
+#endif  // DPN_HAS_REST
 static inline int ck(hipError_t e) { return (int)e; }
 
 extern "C" {
 
+#if DPN_HAS_REST
 int dpn_version(void) { return 1; }
 
 int dpn_sizes(int64_t n, int prec, DpnSizes* out) {
@@ -1982,6 +2009,8 @@ int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, vo
     return ck(hipGetLastError());
 }
 
+#endif  // DPN_HAS_REST
+#if DPN_HAS_POINT
 int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
             const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream) {
     if (!coord_data || !freqs || !geo || !packed || !out_n || n <= 0 || (prec != 1 && prec != 2)) return -1;
@@ -1994,6 +2023,8 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
     return ck(hipGetLastError());
 }
 
+#endif  // DPN_HAS_POINT
+#if DPN_HAS_REST
 int dpn_contract_gpe(const float* g_out, const float* gpe, int64_t n, float* g_pe, void* stream) {
     if (!g_out || !gpe || !g_pe || n <= 0) return -1;
     hipLaunchKernelGGL(dpn_contract_gpe_kernel, dim3((unsigned)n), dim3(192), 0, reinterpret_cast<hipStream_t>(stream), g_out, gpe, n, g_pe);
@@ -2022,6 +2053,8 @@ int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n, float beta
     return ck(hipGetLastError());
 }
 
+#endif  // DPN_HAS_REST
+#if DPN_HAS_POINT
 int dpn_bwd_points(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
                    const DpnGeometry* geo, const void* packed, int prec, const float* g_out, const float* g_jxi, const void* saved,
                    void* operands, void* stream) {
@@ -2036,6 +2069,8 @@ int dpn_bwd_points(const float* x, const float* y, const float* t, const float* 
     return ck(hipGetLastError());
 }
 
+#endif  // DPN_HAS_POINT
+#if DPN_HAS_REST
 int dpn_wgrad(int64_t n, int prec, const float* g_out, const void* saved, const void* operands, void* partials, void* stream) {
     if (!g_out || !saved || !operands || !partials || n <= 0 || (prec != 1 && prec != 2)) return -1;
     WgradArgs a{n, pad_points(n), choose_splits(pad_points(n)), const_cast<void*>(saved), const_cast<void*>(operands),
@@ -2249,5 +2284,7 @@ int dpn_selftest(void* scratch_dev, void* stream) {
         }
     return 0;
 }
+
+#endif  // DPN_HAS_REST
 
 }  // extern "C"

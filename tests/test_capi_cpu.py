@@ -128,12 +128,16 @@ def test_inline_asm_lds_reads_are_waited_for_before_any_use(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    asm = str(tmp_path / 'dpn_kernels.s')
-    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', '-I' + os.path.join(root, 'include'),
-                    os.path.join(root, 'deepphysinet_amd', 'csrc', 'dpn_kernels.hip'), '-o', asm], check=True, capture_output=True)
-    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'lds_hazard_check.py'), asm,
-                        'dpn_fwd_kernel', 'dpn_bwd_kernel', 'dpn_wgrad_kernel'], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:]
-    assert r.stdout.count(' 0 hazards') == 6, r.stdout
-    text = open(asm).read()
-    assert 's_swappc_b64' not in text, 'a helper was not inlined: the kernels must not make calls'
+    from deepphysinet_amd.build import COMMON, UNITS
+    src = os.path.join(root, 'deepphysinet_amd', 'csrc', 'dpn_kernels.hip')
+    checked = 0
+    for (usrc, flags, _), kernels in zip(UNITS[:2], (['dpn_fwd_kernel', 'dpn_bwd_kernel'], ['dpn_wgrad_kernel'])):   # as the library builds them
+        assert os.path.samefile(usrc, src)
+        asm = str(tmp_path / ('unit%d.s' % checked))
+        subprocess.run([hipcc, *[f for f in COMMON if f != '-fPIC'], *flags, '--cuda-device-only', '-S', '-I' + os.path.join(root, 'include'),
+                        src, '-o', asm], check=True, capture_output=True)
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'lds_hazard_check.py'), asm, *kernels], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert r.stdout.count(' 0 hazards') == 2 * len(kernels), r.stdout
+        assert 's_swappc_b64' not in open(asm).read(), 'a helper was not inlined: the kernels must not make calls'
+        checked += 1

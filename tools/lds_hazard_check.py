@@ -9,9 +9,10 @@ it.  This tool scans the device assembly of a kernel in program order, models
 the LGKM counter (LDS operations retire in order) and reports every instruction
 that names a register whose ds_read has not been waited for.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -Iinclude \
-        deepphysinet_amd/csrc/dpn_kernels.hip -o /tmp/k.s
-    python tools/lds_hazard_check.py /tmp/k.s dpn_fwd_kernel dpn_bwd_kernel dpn_wgrad_kernel
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -Iinclude -DDPN_TU=1 -mllvm -amdgpu-mfma-vgpr-form \
+        deepphysinet_amd/csrc/dpn_kernels.hip -o /tmp/k1.s          # the flags of deepphysinet_amd/build.py UNITS
+    python tools/lds_hazard_check.py /tmp/k1.s dpn_fwd_kernel dpn_bwd_kernel
+    (DPN_TU=2 without the -mllvm flag for dpn_wgrad_kernel; tests/test_capi_cpu.py runs both)
 
 Control flow is ignored (the scan is linear), which is exact for the unrolled
 pipelines of these kernels: no ds_read is pending across a backward branch.
