@@ -227,6 +227,10 @@ DEV void dma16(const char* gsrc_lane, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
+template <int OFF> DEV void dma16_at(const char* gsrc_lane, char* lds_wave_base) {     // OFF: the instruction's immediate, added to both addresses
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, OFF, 0);
+}
 DEV void dma16_nt(const char* gsrc_lane, char* lds_wave_base) {       // read-once streams (weight-gradient operands): non-temporal hint
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 2);
@@ -265,9 +269,21 @@ struct Pipe {
     DEV void issue(const int c) {                                       // chunk c -> slot c % 4
         const int n = dmas(stream_nk(c, end));
         char* slot = lds + (c & (kRing - 1)) * kSlotBytes;
-#pragma unroll
-        for (int i = 0; i < 4 * NS; ++i)
-            if (i < n) dma16(g + (i * 4 + wave) * 1024 + lane * 16, slot + (i * 4 + wave) * 1024);
+        // The slot is a byte image of the chunk; wave w copies the CONTIGUOUS quarter [w n KiB, (w+1) n KiB) of it, so that its pieces
+        // differ only in the instruction's immediate offset (which moves the global and the LDS address alike, < 4 KiB): one
+        // address pair + one M0 per four pieces instead of five address instructions per piece (a sixth of the kernel's issue slots).
+        const char* src = g + wave * (n * 1024) + lane * 16;
+        char* dst = slot + wave * (n * 1024);
+        if (n > 0) dma16_at<0>(src, dst);
+        if (n > 1) dma16_at<1024>(src, dst);
+        if (n > 2) dma16_at<2048>(src, dst);
+        if (n > 3) dma16_at<3072>(src, dst);
+        if constexpr (NS == 2) {
+            if (n > 4) dma16_at<0>(src + 4096, dst + 4096);
+            if (n > 5) dma16_at<1024>(src + 4096, dst + 4096);
+            if (n > 6) dma16_at<2048>(src + 4096, dst + 4096);
+            if (n > 7) dma16_at<3072>(src + 4096, dst + 4096);
+        }
         g += n * 4096;
     }
     DEV void prime() { issue(0); issue(1); issue(2); }
