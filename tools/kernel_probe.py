@@ -33,7 +33,10 @@ with torch.no_grad():
     def k_bwd(): L.check(lib.dpn_bwd_points(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed), cfg.prec, PP._ptr(g_out), PP._ptr(g_jxi), PP._ptr(ws.saved), PP._ptr(operands), s), 'bwd')
     def k_wgrad(): L.check(lib.dpn_wgrad(n, cfg.prec, PP._ptr(g_out), PP._ptr(ws.saved), PP._ptr(operands), PP._ptr(partials), s), 'wgrad')
     def k_pack(): L.check(lib.dpn_pack_weights(nets, cfg.prec, PP._ptr(ws.packed), s), 'pack')
-    for name, fn in (('pack', k_pack), ('fwd', k_fwd), ('bwd', k_bwd), ('wgrad', k_wgrad)):
+    def k_fwd_nosave(): L.check(lib.dpn_fwd(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed), cfg.prec, PP._ptr(out_n), PP._ptr(jac_n), None, s), 'fwd')
+    def k_fwd_fields(): L.check(lib.dpn_fwd(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed), cfg.prec, PP._ptr(out_n), None, None, s), 'fwd')
+    extra = (('fwd, nothing saved', k_fwd_nosave), ('fwd, fields only', k_fwd_fields)) if os.environ.get('DPN_PROBE_VARIANTS') else ()
+    for name, fn in (('pack', k_pack), ('fwd', k_fwd), ('bwd', k_bwd), ('wgrad', k_wgrad)) + extra:
         for _ in range(3): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
