@@ -141,3 +141,18 @@ def test_inline_asm_lds_reads_are_waited_for_before_any_use(tmp_path):
         assert r.stdout.count(' 0 hazards') == 2 * len(kernels), r.stdout
         assert 's_swappc_b64' not in open(asm).read(), 'a helper was not inlined: the kernels must not make calls'
         checked += 1
+
+
+def test_hazard_checker_flags_a_read_before_its_wait(tmp_path):
+    """The checker itself: a register touched between its ds_read and the covering lgkmcnt wait is reported, in-order retirement
+    (lgkmcnt(N) leaves the N youngest outstanding) is modelled, and a clean stream passes."""
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'lds_hazard_check.py')
+    bad = tmp_path / 'bad.s'
+    bad.write_text('_Z3badv:\n\tds_read_b128 v[0:3], v9\n\tds_read_b128 v[4:7], v9 offset:16\n\ts_waitcnt lgkmcnt(1)\n'
+                   '\tv_add_f32_e32 v8, v0, v1\n\tv_accvgpr_write_b32 a0, v5\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v8, v6\n\ts_endpgm\n.Lfunc_end0:\n')
+    r = subprocess.run([sys.executable, tool, str(bad), 'bad'], capture_output=True, text=True)
+    assert r.returncode == 1 and ' 1 hazards' in r.stdout and 'v_accvgpr_write_b32 a0, v5' in r.stdout, r.stdout
+    good = tmp_path / 'good.s'
+    good.write_text(bad.read_text().replace('\tv_accvgpr_write_b32 a0, v5\n', ''))
+    r = subprocess.run([sys.executable, tool, str(good), 'bad'], capture_output=True, text=True)
+    assert r.returncode == 0 and ' 0 hazards' in r.stdout, r.stdout
