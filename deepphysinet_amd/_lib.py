@@ -98,6 +98,8 @@ EXPORTS = {
     'dpn_embed_assemble': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_sample_points': (c_int, [POINTER(DpnSampler), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_uint64,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_sample_points_replay': (c_int, [POINTER(DpnSampler), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_uint64,
+                                         c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_grid_maps': (c_int, [c_void_p, c_int, c_int, POINTER(DpnPhysics), c_int, c_void_p, c_void_p]),
     'dpn_clip_adam_flat_floats': (c_int64, [c_int, c_void_p]),
     'dpn_clip_adam_flat': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,

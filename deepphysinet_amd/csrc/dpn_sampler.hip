@@ -32,6 +32,8 @@ struct SampleArgs {
     const int32_t *xi, *yi, *ti;
     int64_t n;
     uint64_t seed, offset;
+    const int32_t* step_dev;      // optional device-side step counter: the draw counter starts at offset + *step_dev * stride
+    uint64_t stride;
     int mode;
     float *x, *y, *t, *f, *coord_data, *label_out;
     double* raw;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void dpn_sample_kernel(SampleArgs a) {
         xr = a.xi[i]; yr = a.yi[i]; tr = a.ti[i];
     } else {
         uint32_t w[4], v[4];
-        const uint64_t ctr = a.offset + (uint64_t)i;
+        const uint64_t ctr = a.offset + (a.step_dev ? (uint64_t)(uint32_t)(*a.step_dev) * a.stride : 0ull) + (uint64_t)i;
         philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w);
         philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), v);
         if (a.mode == DPN_SAMPLE_INTERIOR) {                            // np.random.rand(n) * (size - 1)   (:442-443)
@@ -125,12 +127,18 @@ extern "C" {
 int dpn_sample_points(const DpnSampler* s, const float* cube, const float* labels, int mode, const int32_t* xi, const int32_t* yi,
                       const int32_t* ti, int64_t n, uint64_t seed, uint64_t offset, float* x, float* y, float* t, float* f,
                       float* coord_data, float* label_out, double* raw, void* stream) {
+    return dpn_sample_points_replay(s, cube, labels, mode, xi, yi, ti, n, seed, offset, nullptr, 0, x, y, t, f, coord_data, label_out, raw, stream);
+}
+
+int dpn_sample_points_replay(const DpnSampler* s, const float* cube, const float* labels, int mode, const int32_t* xi, const int32_t* yi,
+                             const int32_t* ti, int64_t n, uint64_t seed, uint64_t offset, const int32_t* step_dev, uint64_t stride,
+                             float* x, float* y, float* t, float* f, float* coord_data, float* label_out, double* raw, void* stream) {
     if (!s || !cube || !x || !y || !t || !f || !coord_data || n <= 0) return -1;
     if (mode != DPN_SAMPLE_INTERIOR && mode != DPN_SAMPLE_MARGIN && mode != DPN_SAMPLE_EXPLICIT) return -1;
     if (mode == DPN_SAMPLE_EXPLICIT && (!xi || !yi || !ti)) return -1;
     if (s->lon_in < 2 || s->lat_in < 2 || s->t_in < 2 || s->lon < 2 || s->lat < 2) return -1;
     if (label_out && (!labels || mode == DPN_SAMPLE_INTERIOR)) return -1;          // labels exist at grid nodes only
-    SampleArgs a{*s, cube, labels, xi, yi, ti, n, seed, offset, mode, x, y, t, f, coord_data, label_out, raw};
+    SampleArgs a{*s, cube, labels, xi, yi, ti, n, seed, offset, step_dev, stride, mode, x, y, t, f, coord_data, label_out, raw};
     hipLaunchKernelGGL(dpn_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

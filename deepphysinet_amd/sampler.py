@@ -61,6 +61,21 @@ class CollocationSampler:
                 raise ValueError('labels must be [%d, 6, %d, %d]' % (hours, c.lat_size, c.lon_size))
             self.labels = labels.detach().float().contiguous()
         self.seed, self.offset = int(seed), 0
+        self._step_dev, self._stride = None, 0
+
+    def bind_step_counter(self, step_count: torch.Tensor, points_per_step: int):
+        """Draw from the DEVICE-side step counter: after this, every draw uses Philox counter = (offset inside the step) +
+        step_count * points_per_step, step_count being read by the kernel (FusedClipAdam.step_count: int32[1] on the device, bumped
+        once per optimiser step).  A sampler launch captured in a hipGraph then draws fresh points on every replay; host-side state no
+        longer advances between steps (begin_step() rewinds the offset inside the step; training_batch() calls it)."""
+        _require_gpu(step_count, 'step_count')
+        if step_count.dtype != torch.int32 or step_count.numel() != 1:
+            raise ValueError('step_count must be one int32 on the device')
+        self._step_dev, self._stride, self.offset = step_count, int(points_per_step), 0
+
+    def begin_step(self):
+        if self._step_dev is not None:
+            self.offset = 0
 
     def _run(self, mode, n, xi=None, yi=None, ti=None, want_labels=False, want_raw=False):
         dev = self.cube.device
@@ -71,9 +86,12 @@ class CollocationSampler:
         if want_labels and self.labels is None:
             raise RuntimeError('this sampler was built without labels')
         lib = L.load()
-        L.check(lib.dpn_sample_points(ctypes.byref(self._s), _ptr(self.cube), _ptr(self.labels) if want_labels else None, mode,
-                                      _ptr(xi), _ptr(yi), _ptr(ti), n, self.seed, self.offset, _ptr(x), _ptr(y), _ptr(t), _ptr(f),
-                                      _ptr(cd), _ptr(lab), _ptr(raw), _stream()), 'dpn_sample_points')
+        if self._step_dev is not None and mode != L.SAMPLE_EXPLICIT and self.offset + n > self._stride:
+            raise RuntimeError('more points drawn in one step (%d) than bind_step_counter() reserved (%d)' % (self.offset + n, self._stride))
+        L.check(lib.dpn_sample_points_replay(ctypes.byref(self._s), _ptr(self.cube), _ptr(self.labels) if want_labels else None, mode,
+                                             _ptr(xi), _ptr(yi), _ptr(ti), n, self.seed, self.offset, _ptr(self._step_dev), self._stride,
+                                             _ptr(x), _ptr(y), _ptr(t), _ptr(f), _ptr(cd), _ptr(lab), _ptr(raw), _stream()),
+                'dpn_sample_points_replay')
         if mode != L.SAMPLE_EXPLICIT:
             self.offset += n                                   # the next call continues the Philox counter
         return x, y, t, f, cd, lab, raw
@@ -114,6 +132,7 @@ class CollocationSampler:
         """One sample of PhysicsDataset.__getitem__ (physics_dataset.py:501-519) as the dict InterfacePhysics.training_step takes: the
         field sample and lead time given by the caller, 20 480 margin (grid-node, labelled) and 4 096 interior collocation points drawn,
         interpolated and labelled on the device (batch sizes: cfg:111, physics_dataset.py:30)."""
+        self.begin_step()
         mx, my, mt, mlab, mf, mcd = self.get_item_label_data(n_margin)
         ix, iy, it, icd, if_ = self.get_inter_data(n_inter)
         col = lambda v: v.reshape(-1, 1)

@@ -249,6 +249,14 @@ typedef struct DpnSampler {
 int dpn_sample_points(const DpnSampler* s, const float* cube, const float* labels, int mode, const int32_t* xi, const int32_t* yi,
                       const int32_t* ti, int64_t n, uint64_t seed, uint64_t offset, float* x, float* y, float* t, float* f,
                       float* coord_data, float* label_out, double* raw, void* stream);
+/* The same draw with the Philox counter advanced on the DEVICE: counter = offset + *step_dev * stride + point index.  step_dev is the
+ * optimiser's device-side step counter (dpn_clip_adam_flat's step_dev, bumped once per step), stride the points drawn per step, so a
+ * sampler launch captured in a hipGraph draws fresh points on every replay (a captured host-side offset would freeze them).
+ * step_dev == NULL is dpn_sample_points.  Replaces the per-__getitem__ np.random draws of physics_dataset.py:334-338,442-446 inside a
+ * captured training step. */
+int dpn_sample_points_replay(const DpnSampler* s, const float* cube, const float* labels, int mode, const int32_t* xi, const int32_t* yi,
+                             const int32_t* ti, int64_t n, uint64_t seed, uint64_t offset, const int32_t* step_dev, uint64_t stride,
+                             float* x, float* y, float* t, float* f, float* coord_data, float* label_out, double* raw, void* stream);
 /* Normalised fields of all lon*lat nodes in the reference's node order (x outer, y inner; interface_physics.py:538-543),
  * out_n[lon*lat][6] -> de-normalised maps[6][lat][lon] (inverse_norm :232-262 + the scatter loop :583-591). */
 int dpn_grid_maps(const float* out_n, int lon, int lat, const DpnPhysics* phys, int with_clip, float* maps, void* stream);

@@ -159,3 +159,51 @@ def test_sampler_feeds_the_training_step():
     assert not torch.equal(before, m.physics_net.U_net.out_fc.weight.detach())
     b2 = s.training_batch(field, fh)
     assert not torch.equal(b1['inter_x'], b2['inter_x'])
+
+
+@pytest.mark.gpu
+def test_captured_sampler_draws_fresh_points_on_every_replay():
+    """The sampler inside a hipGraph: bound to the optimiser's device-side step counter, a captured training_batch() draws the points of
+    step k on replay k -- the same points an unbound sampler draws with the host-side offset k * points_per_step."""
+    from deepphysinet_amd.optim import FusedClipAdam
+    from oracle.fill import synthetic_inputs
+    n_m, n_i = 2048, 512
+    s, _, _ = _sampler(seed=11)
+    dev = s.cube.device
+    p = torch.nn.Parameter(torch.zeros(8, device=dev))
+    p.grad = torch.ones_like(p)
+    opt = FusedClipAdam([p], lr=1e-3, weight_decay=0.0)
+    s.bind_step_counter(opt.step_count, n_m + n_i)
+    inp = synthetic_inputs(8, 257, 145, 27000.0, 27000.0)
+    field, fh = inp['field_data'].to(dev), inp['forecast_h'].to(dev)
+
+    def step():
+        b = s.training_batch(field, fh, n_margin=n_m, n_inter=n_i)
+        opt.step()
+        return b
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                               # eager step 0 (warm-up on the capture stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        b = step()
+    seen = []
+    for _ in range(3):                                       # replays = steps 1, 2, 3
+        g.replay()
+        torch.cuda.synchronize()
+        seen.append({k: b[k].clone() for k in ('margin_x', 'margin_t', 'margin_data', 'inter_x', 'inter_y', 'inter_data')})
+    assert int(opt.step_count) == 4
+    assert not torch.equal(seen[0]['inter_x'], seen[1]['inter_x']) and not torch.equal(seen[1]['margin_x'], seen[2]['margin_x'])
+    ref, _, _ = _sampler(seed=11)                            # host-side offsets: step k starts at k * (n_m + n_i)
+    for k, got in enumerate(seen, start=1):
+        ref.offset = k * (n_m + n_i)
+        want = ref.training_batch(field, fh, n_margin=n_m, n_inter=n_i)
+        for key, v in got.items():
+            assert torch.equal(v, want[key]), (k, key)
+    with pytest.raises(RuntimeError):                        # more points than the stride reserved
+        s.begin_step()
+        s.get_inter_data(n_m + n_i + 1)

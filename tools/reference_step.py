@@ -1,5 +1,6 @@
 """The reference-shaped training step (interface_physics.py:443-515): data loss on 20 480 margin points, PDE losses on 4 096 interior +
-20 480 margin points, backward, clip, Adam -- batch drawn on the device by the sampler, step captured in a hipGraph.  Prints one JSON line."""
+20 480 margin points, backward, clip, Adam -- the batch is drawn on the device by the sampler INSIDE the captured step (Philox counter
+advanced by the optimiser's device-side step counter: fresh points on every replay), the whole thing one hipGraph.  Prints one JSON line."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,10 +20,13 @@ g = np.random.default_rng(0)
 smp = CollocationSampler(SamplerConfig(), torch.from_numpy(g.standard_normal((6, 37, 65, 5)).astype(np.float32)).to(dev),
                          torch.from_numpy(g.standard_normal((25, 6, 145, 257)).astype(np.float32)).to(dev), seed=1)
 b0 = synth_batch(8, dev, seed=1)
-batch = smp.training_batch(b0['field_data'], b0['forecast_h'])
+smp.bind_step_counter(opt.step_count, 20480 + 4096)
+drawn = {}
 
 
 def step():
+    batch = smp.training_batch(b0['field_data'], b0['forecast_h'])       # 2 sampler launches, captured with the step
+    drawn['inter_x'] = batch['inter_x']
     m.training_step(batch, opt, with_pde=True)
 
 
@@ -36,9 +40,14 @@ torch.cuda.synchronize()
 graph = torch.cuda.CUDAGraph()
 with torch.cuda.graph(graph):
     step()
-for _ in range(10):
+first = None
+for i in range(10):
     graph.replay()
+    if i == 0:
+        torch.cuda.synchronize()
+        first = drawn['inter_x'].clone()
 torch.cuda.synchronize()
+assert not torch.equal(first, drawn['inter_x']), 'the captured sampler must draw fresh points on every replay'
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(200):
@@ -46,5 +55,5 @@ for _ in range(200):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 200
-print(json.dumps({'workload': 'reference-shaped step: data loss 20480 pts + PDE 4096 interior + PDE 20480 margin, bwd, clip, Adam', 'precision': prec,
+print(json.dumps({'workload': 'reference-shaped step: data loss 20480 pts + PDE 4096 interior + PDE 20480 margin, bwd, clip, Adam', 'precision': prec, 'sampler': 'inside the captured step (device-side Philox offset)',
                   'ms_per_step': ms, 'pde_points_per_s': 24576 / ms * 1e3}))
