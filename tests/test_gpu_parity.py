@@ -65,7 +65,7 @@ def test_library_is_the_hip_one_and_layout_selftest_passes():
 
 
 @pytest.mark.parametrize('prec', ['bf16x2', 'bf16'])
-@pytest.mark.parametrize('n', [1037, 256, 200, 1])       # 1037: nine 128-point workgroups, five 256-row loss blocks, a ragged tail of 13
+@pytest.mark.parametrize('n', [5197, 1037, 256, 200, 1])   # 5197: all ten weight-gradient splits, 41 workgroups per net; 1037: nine workgroups, a ragged tail of 13
 def test_fields_jacobian_losses_gradients_vs_oracle(prec, n):
     import deepphysinet_amd as dpn
     tol = TOL[prec]
@@ -102,8 +102,17 @@ def test_fields_jacobian_losses_gradients_vs_oracle(prec, n):
         if name.endswith('key_projection.bias'):
             continue                      # mathematically zero gradient (softmax shift invariance): rounding noise on both sides
         r = ref['grads'][name]
-        err = float((p.grad.cpu() - r).abs().max() / (r.abs().max() + 1e-30))
-        assert err < tol['grad'] * (20.0 if n == 1 else 1.0), (name, err)
+        d = (p.grad.cpu() - r).abs()
+        err = float(d.max() / (r.abs().max() + 1e-30))
+        if n <= 1100:
+            assert err < tol['grad'] * (20.0 if n == 1 else 1.0), (name, err)
+        else:
+            # Thousands of points: some hidden unit of some point sits within rounding distance of its ReLU kink and its mask bit differs
+            # between the arithmetics; that moves ONE element of a bias / weight-row gradient by that point's whole contribution
+            # (the fp32 oracle against the fp64 oracle shows the same pattern on the same tensors, cat_fc1.fc.0.*, at 2e-4 max-norm;
+            # tools/grad_diag.py).  So: the bound in the tensor's L2 norm, and 5x the bound on the single worst element.
+            l2 = float(d.pow(2).mean().sqrt() / (r.pow(2).mean().sqrt() + 1e-30))
+            assert l2 < tol['grad'] and err < 5.0 * tol['grad'], (name, l2, err)
 
 
 def test_place_one_batch_matches_reference_golden(golden_dir):
