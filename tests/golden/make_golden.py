@@ -70,8 +70,20 @@ def load_reference():
     return m, cfg
 
 
+def write_f10(m, run_pde):
+    """F10: the PDE path on GRID-NODE points (x, y exact multiples of dx, dy incl. both domain edges: xi = 0 and 1), a ragged batch of 200
+    and the longest lead time (336 h) -- a second, independent pin of a2-a16 next to F3-F5 (interior points, 24 h)."""
+    from oracle.fill import synthetic_inputs
+    inp = synthetic_inputs(200, tag='f10', margin=True, forecast_h=336.0 / 360.0)
+    inp['x'][0, 0], inp['y'][0, 0] = 0.0, 0.0                                     # both corners of the domain
+    inp['x'][1, 0], inp['y'][1, 0] = 256 * 27000.0, 144 * 27000.0
+    rec, _ = run_pde(m, inp, True, torch.float32)
+    np.savez_compressed(os.path.join(HERE, 'f10_grid_nodes_h336_fp32.npz'), x=inp['x'].numpy(), y=inp['y'].numpy(), **rec)
+
+
 def main():
     from oracle.fill import fill_state_dict_, synthetic_inputs
+    only_f10 = '--only-f10' in sys.argv
     torch.manual_seed(0)
     torch.set_num_threads(8)
     m, cfg = load_reference()
@@ -146,6 +158,11 @@ def main():
                                       summary=None, prefix='inter', log_step=100)
         rec['total'] = np.array(float(total), dtype=np.float64)
         return rec, total
+
+    if only_f10:                               # add the one fixture without rewriting (re-zipping) the others
+        write_f10(m, run_pde)
+        print('f10 written')
+        return
 
     # ---- F3/F4/F5: VariableNet outputs, Jacobian, residuals (a6-a16), fp32, clip on/off
     for wc in (True, False):
@@ -223,6 +240,7 @@ def main():
         rec, _ = run_pde(m, synthetic_inputs(128, tag='f9'), wc, torch.float32)
         np.savez_compressed(os.path.join(HERE, 'f9_wide_clip%d_fp32.npz' % int(wc)), **rec)
     net.load_state_dict(sd0)
+    write_f10(m, run_pde)
     print('golden vectors written to', HERE)
     for fn_ in sorted(os.listdir(HERE)):
         if fn_.endswith('.npz'):

@@ -129,6 +129,31 @@ def test_place_one_batch_matches_reference_golden(golden_dir):
     assert np.all(np.abs(terms - d['parts']) <= 1e-4 * np.abs(d['parts']))
 
 
+def test_grid_node_points_longest_lead_match_reference_golden(golden_dir):
+    """Fixture F10 -- the REFERENCE on 200 grid-node points (x, y exact multiples of the cell size, both domain corners: xi = 0 and 1)
+    at the longest lead time (336 h): the six losses and their sum within the north-star 1e-4, fields and Jacobian within the mode's bars."""
+    import deepphysinet_amd as dpn
+    d = np.load(os.path.join(golden_dir, 'f10_grid_nodes_h336_fp32.npz'))
+    inp = synthetic_inputs(200, tag='f10', margin=True, forecast_h=336.0 / 360.0)
+    inp['x'][0, 0], inp['y'][0, 0] = 0.0, 0.0
+    inp['x'][1, 0], inp['y'][1, 0] = 256 * 27000.0, 144 * 27000.0
+    assert np.array_equal(inp['x'].numpy(), d['x']) and np.array_equal(inp['y'].numpy(), d['y'])
+    m = _model('bf16x2')
+    g = _gpu(inp)
+    lf = m.train_cfg['losses']['loss_factor']
+    total = m.place_one_batch(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'], torch.nn.MSELoss(), lf,
+                              global_step=2, local_rank=0, device=_dev())
+    assert abs(float(total) - float(d['total'])) <= 1e-4 * abs(float(d['total']))
+    terms = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).detach().cpu().numpy()
+    assert np.all(np.abs(terms - d['parts']) <= 1e-4 * np.abs(d['parts'])), (terms, d['parts'])
+    cfg = m.point_config()
+    with torch.no_grad():
+        heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
+        out_n, jac_n = dpn.pde_fields_and_jacobian(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
+    ref_n = torch.from_numpy(d['fields_norm'])
+    assert float((out_n.cpu() - ref_n).abs().max() / ref_n.abs().max()) < TOL['bf16x2']['field']
+
+
 @pytest.mark.parametrize('with_clip', [True, False])
 def test_clip_masks_wide_outputs(golden_dir, with_clip):
     """out_fc gain 5: many P/T/q/rho points sit on a clip bound -> zero Jacobian rows, zero gradient there (fixture F9)."""

@@ -88,6 +88,30 @@ def test_f345_fields_jacobian_residuals(golden_dir, state, with_clip):
         assert abs(float(total.detach()) - float(d['total'])) <= 1e-5 * abs(float(d['total']))
 
 
+def _f10_inputs():
+    inp = synthetic_inputs(200, tag='f10', margin=True, forecast_h=336.0 / 360.0)
+    inp['x'][0, 0], inp['y'][0, 0] = 0.0, 0.0                                     # both corners of the domain (tests/golden/make_golden.py)
+    inp['x'][1, 0], inp['y'][1, 0] = 256 * 27000.0, 144 * 27000.0
+    return inp
+
+
+def test_f10_grid_node_points_longest_lead(golden_dir, state):
+    """Second, independent pin of the PDE path: the REFERENCE on 200 grid-node points (both domain corners included) at 336 h lead."""
+    d = _load(golden_dir, 'f10_grid_nodes_h336_fp32.npz')
+    inp = _f10_inputs()
+    assert np.array_equal(inp['x'].numpy(), d['x']) and np.array_equal(inp['y'].numpy(), d['y'])
+    total, parts, fn, ph, jac = _run_pde(state, inp, True)
+    assert _rel(fn.detach().numpy(), d['fields_norm']) < 2e-6
+    assert _rel(ph.detach().numpy(), d['fields_phys']) < 2e-6
+    j, jr = jac.detach().numpy(), d['jac']
+    assert np.array_equal(j == 0, jr == 0)
+    for k in range(6):
+        assert _rel(j[:, k], jr[:, k]) < 2e-5
+    mine = np.array([float(p.detach()) for p in parts])
+    assert np.all(np.abs(mine - d['parts']) <= 2e-5 * np.abs(d['parts']))
+    assert abs(float(total.detach()) - float(d['total'])) <= 1e-5 * abs(float(d['total']))
+
+
 @pytest.mark.parametrize('with_clip', [True, False])
 def test_f9_wide_outputs_clip_masks(golden_dir, with_clip):
     st = O.make_state(gain=5.0)
