@@ -1575,7 +1575,9 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     // one workgroup = one 32x32 output tile.  K is walked in 32-wide tiles that are loaded COALESCED (the fast index follows each
     // operand's contiguous dimension) into double-buffered LDS, two tiles ahead in registers; inside a tile the four waves take
     // BK/4 k-values each (v_mfma_f32_32x32x2_f32, exact fp32) and their partial tiles are summed through LDS in a fixed order.
-    // <128, 2>: double-buffered LDS, two k-tiles in flight (long / multi-term reductions).  <256, 1>: the whole K of a 256-wide encoder
+    // <64, 2>: double-buffered LDS, two k-tiles in flight (long / multi-term reductions); 64-deep tiles = 34 KB of LDS = four
+    // workgroups per CU, so the 500-800 tiles of a backward launch are one round (128-deep: two per CU, measured +7 us per step;
+    // 96-deep: slower, the non-power-of-two index arithmetic).  <256, 1>: the whole K of a 256-wide encoder
     // GEMM is ONE tile -- one LDS stage, one barrier pair, 32 loads per operand in flight (used when every problem is a single tile).
     constexpr int BM = 32, BN = 32, NL = BK * 32 / 256;   // NL loads per operand per thread per k-tile
     if ((int)blockIdx.z >= batch.n) {
@@ -1618,12 +1620,12 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
         for (int q = 0; q < NL; ++q) {
             const int e = threadIdx.x + 256 * q;
             {
-                const int kk = a.ta ? (e >> 5) : (e & (BK - 1)), mm = a.ta ? (e & 31) : (e / BK);
+                const int kk = a.ta ? (e >> 5) : (e % BK), mm = a.ta ? (e & 31) : (e / BK);
                 const int gm = m0 + mm, gk = k0 + kk;
                 ra[q] = (gm < a.M && gk < K) ? (a.ta ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
             }
             {
-                const int kk = a.tb ? (e & (BK - 1)) : (e >> 5), nn = a.tb ? (e / BK) : (e & 31);
+                const int kk = a.tb ? (e % BK) : (e >> 5), nn = a.tb ? (e / BK) : (e & 31);
                 const int gk = k0 + kk, gn = n0 + nn;
                 rb[q] = (gk < K && gn < a.N) ? (a.tb ? B[(int64_t)gn * ldb + gk] : B[(int64_t)gk * ldb + gn]) : 0.f;
             }
@@ -1635,8 +1637,8 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
             const int e = threadIdx.x + 256 * q;
-            As[buf][a.ta ? (e >> 5) : (e & (BK - 1))][a.ta ? (e & 31) : (e / BK)] = ra[q];
-            Bs[buf][a.tb ? (e & (BK - 1)) : (e >> 5)][a.tb ? (e / BK) : (e & 31)] = rb[q];
+            As[buf][a.ta ? (e >> 5) : (e % BK)][a.ta ? (e & 31) : (e / BK)] = ra[q];
+            Bs[buf][a.tb ? (e % BK) : (e >> 5)][a.tb ? (e / BK) : (e & 31)] = rb[q];
         }
     };
     if constexpr (NBUF == 2) {
@@ -2143,7 +2145,7 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
 }
 
 // measured on the encoder backward (A2 phase): threshold 1 -> 778 us, 2 -> 804 us, 3 -> 798 us: multi-tile problems want the
-// double-buffered <128,2> pipeline
+// double-buffered <64,2> pipeline
 constexpr int kSingleStageMaxTiles = 1;
 static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream) {
     if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems || n_jobs < 0 || n_jobs > 2 || (n_jobs && !jobs)) return -1;
@@ -2180,7 +2182,7 @@ static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, in
         single_tile = single_tile && tiles <= kSingleStageMaxTiles;
     }
     if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
-    else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<128, 2>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<64, 2>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
     return ck(hipGetLastError());
 }
 
