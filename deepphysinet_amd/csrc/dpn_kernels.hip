@@ -2147,6 +2147,7 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
 // measured on the encoder backward (A2 phase): threshold 1 -> 778 us, 2 -> 804 us, 3 -> 798 us: multi-tile problems want the
 // double-buffered <64,2> pipeline
 constexpr int kSingleStageMaxTiles = 1;
+constexpr long kSingleStageMaxOutTiles = 512;      // one round of <256,1>; thresholds 256 ... 700 measure the same, none or 1024 worse
 static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream) {
     if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems || n_jobs < 0 || n_jobs > 2 || (n_jobs && !jobs)) return -1;
     SgemmBatch b;
@@ -2174,13 +2175,19 @@ static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, in
         b.job[i] = SgemmColsum{jobs[i].partial, jobs[i].out_a, jobs[i].out_b, jobs[i].n_blocks, 0};
     }
     const int gz = n_problems + n_jobs;
-    // <256,1> (one LDS stage of 256 k) when every problem is a single such tile
+    // <256,1> (one LDS stage of 256 k) when every problem is a single such tile AND the launch is one round of it (68 KB of LDS: two
+    // workgroups per CU, 512 at a time); launches with more output tiles than that (batches of fields: 548 row tiles per GEMM) run
+    // better four to a CU in the pipelined <64,2> form (single field: 1.309 -> 1.286 ms per step, the heads' 728-tile launch among
+    // them; configs[2]: 51.1 -> 50.4 ms)
     bool single_tile = true;
+    long out_tiles = 0;
     for (int i = 0; i < n_problems; ++i) {
         int tiles = 0;
         for (int t = 0; t < b.p[i].nterms; ++t) tiles += (b.t[b.p[i].term0 + t].K + 255) / 256;
         single_tile = single_tile && tiles <= kSingleStageMaxTiles;
+        out_tiles += (long)((b.p[i].M + 31) / 32) * ((b.p[i].N + 31) / 32);
     }
+    single_tile = single_tile && out_tiles <= kSingleStageMaxOutTiles;
     if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
     else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<64, 2>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
     return ck(hipGetLastError());
