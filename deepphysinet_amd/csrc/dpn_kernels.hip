@@ -1570,22 +1570,25 @@ struct SgemmBatch {
 typedef float f32x1;
 DEV f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-template <int BK, int NBUF>
-__global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
+template <int BK, int NBUF, int NT = 256>
+__global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     // one workgroup = one 32x32 output tile.  K is walked in 32-wide tiles that are loaded COALESCED (the fast index follows each
     // operand's contiguous dimension) into double-buffered LDS, two tiles ahead in registers; inside a tile the four waves take
     // BK/4 k-values each (v_mfma_f32_32x32x2_f32, exact fp32) and their partial tiles are summed through LDS in a fixed order.
     // <64, 2>: double-buffered LDS, two k-tiles in flight (long / multi-term reductions); 64-deep tiles = 34 KB of LDS = four
     // workgroups per CU, so the 500-800 tiles of a backward launch are one round (128-deep: two per CU, measured +7 us per step;
     // 96-deep: slower, the non-power-of-two index arithmetic).  <256, 1>: the whole K of a 256-wide encoder
-    // GEMM is ONE tile -- one LDS stage, one barrier pair, 32 loads per operand in flight (used when every problem is a single tile).
-    constexpr int BM = 32, BN = 32, NL = BK * 32 / 256;   // NL loads per operand per thread per k-tile
+    // GEMM is ONE tile -- one LDS stage, one barrier pair, 16 loads per operand in flight (used when every problem is a single tile);
+    // it runs with EIGHT waves (NT = 512): half the MFMA chain and half the loads per thread of a latency-bound tile, -15 us per step.
+    constexpr int BM = 32, BN = 32, NL = BK * 32 / NT;    // NL loads per operand per thread per k-tile
+    constexpr int NW = NT / 64;                           // waves: each takes BK / NW k-values of a tile
     if ((int)blockIdx.z >= batch.n) {
         // ride-along job: out_a[c] = sum_b partial[b][c], out_b[c] = sum_b partial[b][256 + c] (fixed order) -- the reduction of
         // dpn_add_ln_bwd's per-block partial sums, finished in the shadow of the GEMM tiles instead of in a launch of its own
         if (blockIdx.x || blockIdx.y) return;
         const SgemmColsum& j = batch.job[blockIdx.z - batch.n];
         const int c = threadIdx.x;
+        if (c >= 256) return;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
         for (int b = 0; b < j.nblocks; ++b) { s1 += j.partial[(int64_t)b * 512 + c]; s2 += j.partial[(int64_t)b * 512 + 256 + c]; }
@@ -1600,7 +1603,7 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     __shared__ float As[NBUF][BK][BM + 1];
     __shared__ float Bs[NBUF][BK][BN + 1];
     float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(&As[0][0][0]);
-    static_assert(sizeof(As) >= 4 * 32 * 33 * sizeof(float), "partial tiles must fit in the A staging buffers");
+    static_assert(sizeof(As) >= NW * 32 * 33 * sizeof(float), "partial tiles must fit in the A staging buffers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     f32x16 acc = (f32x16)0.f;
@@ -1618,7 +1621,7 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
         const int lda = T.lda, ldb = T.ldb, K = T.K, k0 = lk0;
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
-            const int e = threadIdx.x + 256 * q;
+            const int e = threadIdx.x + NT * q;
             {
                 const int kk = a.ta ? (e >> 5) : (e % BK), mm = a.ta ? (e & 31) : (e / BK);
                 const int gm = m0 + mm, gk = k0 + kk;
@@ -1636,7 +1639,7 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
-            const int e = threadIdx.x + 256 * q;
+            const int e = threadIdx.x + NT * q;
             As[buf][a.ta ? (e >> 5) : (e % BK)][a.ta ? (e & 31) : (e / BK)] = ra[q];
             Bs[buf][a.tb ? (e % BK) : (e >> 5)][a.tb ? (e / BK) : (e & 31)] = rb[q];
         }
@@ -1651,8 +1654,8 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
             if (it + 1 < total) lstore(buf ^ 1);                  // tile it+1 (loaded during the previous iteration) -> other LDS buffer
             if (it + 2 < total) gload();                          // tile it+2 in flight under the MFMAs
 #pragma unroll
-            for (int u = 0; u < BK / 8; ++u) {
-                const int kk = wave * (BK / 4) + 2 * u + h;
+            for (int u = 0; u < BK / (2 * NW); ++u) {
+                const int kk = wave * (BK / NW) + 2 * u + h;
                 acc = mfma_f32(As[buf][kk][i], Bs[buf][kk][i], acc);
             }
             if (do_asum && it < ktiles0 && threadIdx.x < BM) {
@@ -1668,8 +1671,8 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
             __syncthreads();
             if (it + 1 < total) gload();                          // next tile in flight under the MFMAs
 #pragma unroll 8
-            for (int u = 0; u < BK / 8; ++u) {
-                const int kk = wave * (BK / 4) + 2 * u + h;
+            for (int u = 0; u < BK / (2 * NW); ++u) {
+                const int kk = wave * (BK / NW) + 2 * u + h;
                 acc = mfma_f32(As[0][kk][i], Bs[0][kk][i], acc);
             }
             if (do_asum && it < ktiles0 && threadIdx.x < BM) {
@@ -1684,10 +1687,11 @@ __global__ __launch_bounds__(256) void dpn_sgemm_batch_kernel(SgemmBatch batch) 
     for (int r = 0; r < 16; ++r) part[wave][drow32(r, h) * 33 + i] = acc[r];
     __syncthreads();
 #pragma unroll
-    for (int e = threadIdx.x; e < 1024; e += 256) {
+    for (int e = threadIdx.x; e < 1024; e += NT) {
         const int r = e >> 5, c = e & 31, o = r * 33 + c;
         if (m0 + r < a.M && n0 + c < a.N) {
             float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+            if constexpr (NW == 8) v = (((v + part[4][o]) + part[5][o]) + part[6][o]) + part[7][o];
             v += a.bias ? a.bias[n0 + c] : 0.f;
             const int64_t idx = (int64_t)(m0 + r) * a.ldc + n0 + c;
             if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = v; v = gelu_exact(v); }
@@ -2188,7 +2192,7 @@ static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, in
         out_tiles += (long)((b.p[i].M + 31) / 32) * ((b.p[i].N + 31) / 32);
     }
     single_tile = single_tile && out_tiles <= kSingleStageMaxOutTiles;
-    if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1, 512>), dim3(gx, gy, gz), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), b);
     else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<64, 2>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
     return ck(hipGetLastError());
 }
