@@ -1719,30 +1719,33 @@ struct LnGemmArgs {
     const float* aux;
     float* aux_out;
 };
-template <int MODE>
-__global__ __launch_bounds__(256) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
+template <int MODE, int NT = 512>
+__global__ __launch_bounds__(NT) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
     constexpr int BK = 256;
+    constexpr int NW = NT / 64;                 // waves: BK / NW k-values each (eight: half the MFMA chain and loads of a latency-bound tile)
+    constexpr int TPR = NT / 32, CW = 256 / TPR;  // threads per row of the A tile, columns per thread
     __shared__ float As[BK][33];
     __shared__ float Bs[BK][33];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const bool keep = blockIdx.x == 0;
     // ---- B tile -> registers (stored to LDS after the LayerNorm phase, which may borrow Bs)
-    float rb[32];
+    constexpr int NLB = BK * 32 / NT;
+    float rb[NLB];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const int e = t + 256 * q;
+    for (int q = 0; q < NLB; ++q) {
+        const int e = t + NT * q;
         const int kk = a.tb ? (e & 255) : (e >> 5), nn = a.tb ? (e >> 8) : (e & 31);
         const int gn = n0 + nn;
         rb[q] = (gn < a.N) ? (a.tb ? a.B[(int64_t)gn * a.ldb + kk] : a.B[(int64_t)kk * a.ldb + gn]) : 0.f;
     }
-    // ---- A rows in registers: thread t holds columns [32 c, 32 c + 32) of row m (c = t & 7, m = t >> 3): a row is 8 adjacent lanes,
-    // so the row statistics are three xor-shuffles -- no LDS pass, no barrier
-    const int m = t >> 3, c0 = (t & 7) * 32, gm = m0 + m;
+    // ---- A rows in registers: thread t holds columns [CW c, CW c + CW) of row m (c = t % TPR, m = t / TPR): a row is TPR adjacent lanes,
+    // so the row statistics are log2(TPR) xor-shuffles -- no LDS pass, no barrier
+    const int m = t / TPR, c0 = (t % TPR) * CW, gm = m0 + m;
     const bool ok = gm < a.M;
-    float v[32], w[MODE == 2 ? 32 : 1], gam[32];
+    float v[CW], w[MODE == 2 ? CW : 1], gam[CW];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < CW / 4; ++j) {
         const float4 x4 = ok ? *reinterpret_cast<const float4*>(a.x + (int64_t)gm * 256 + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 g4 = *reinterpret_cast<const float4*>(a.gamma + c0 + 4 * j);
         v[4 * j] = x4.x; v[4 * j + 1] = x4.y; v[4 * j + 2] = x4.z; v[4 * j + 3] = x4.w;
@@ -1759,32 +1762,35 @@ __global__ __launch_bounds__(256) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
     }
     auto row_sum = [&](float s_) __attribute__((always_inline)) {            // over the 8 lanes of the row, fixed order
         s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 4);
+        if constexpr (TPR == 16) s_ += __shfl_xor(s_, 8);
         return s_;
     };
     if (MODE == 2 && keep) {
         // parameter partial sums of this row block need g and xhat column-wise: park them in As / Bs (both still unused), one pass
 #pragma unroll
-        for (int j = 0; j < 32; ++j) { As[c0 + j][m] = v[j]; Bs[c0 + j][m] = w[j]; }
+        for (int j = 0; j < CW; ++j) { As[c0 + j][m] = v[j]; Bs[c0 + j][m] = w[j]; }
         __syncthreads();
-        float dg = 0.f, db = 0.f;
+        if (t < 256) {
+            float dg = 0.f, db = 0.f;
 #pragma unroll 8
-        for (int q = 0; q < 32; ++q) { dg = fmaf(As[t][q], Bs[t][q], dg); db += As[t][q]; }
-        a.partial[(int64_t)blockIdx.y * 512 + t] = dg;
-        a.partial[(int64_t)blockIdx.y * 512 + 256 + t] = db;
+            for (int q = 0; q < 32; ++q) { dg = fmaf(As[t][q], Bs[t][q], dg); db += As[t][q]; }
+            a.partial[(int64_t)blockIdx.y * 512 + t] = dg;
+            a.partial[(int64_t)blockIdx.y * 512 + 256 + t] = db;
+        }
         __syncthreads();
     }
     if (MODE == 1) {
         float s_ = 0.f;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) s_ += v[j];
+        for (int j = 0; j < CW; ++j) s_ += v[j];
         const float mean = row_sum(s_) * (1.f / 256.f);
         float q_ = 0.f;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) { const float d = v[j] - mean; q_ = fmaf(d, d, q_); }
+        for (int j = 0; j < CW; ++j) { const float d = v[j] - mean; q_ = fmaf(d, d, q_); }
         const float rstd = 1.0f / sqrtf(row_sum(q_) * (1.f / 256.f) + 1e-5f);
-        if (keep && ok && (t & 7) == 0) a.rstd_out[gm] = rstd;
+        if (keep && ok && (t % TPR) == 0) a.rstd_out[gm] = rstd;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CW / 4; ++j) {
             const float4 b4 = *reinterpret_cast<const float4*>(a.beta + c0 + 4 * j);
             const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
             float xh[4], yy[4];
@@ -1798,11 +1804,11 @@ __global__ __launch_bounds__(256) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
     } else {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) { const float tk = v[j] * gam[j]; s1 += tk; s2 = fmaf(tk, w[j], s2); }
+        for (int j = 0; j < CW; ++j) { const float tk = v[j] * gam[j]; s1 += tk; s2 = fmaf(tk, w[j], s2); }
         const float m1 = row_sum(s1) * (1.f / 256.f), m2 = row_sum(s2) * (1.f / 256.f);
         const float rs_ = ok ? a.rstd_in[gm] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CW / 4; ++j) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * j + e] = rs_ * (v[4 * j + e] * gam[4 * j + e] - m1 - w[4 * j + e] * m2);
             if (keep && ok) *reinterpret_cast<float4*>(a.y_out + (int64_t)gm * 256 + c0 + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
@@ -1810,18 +1816,18 @@ __global__ __launch_bounds__(256) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
     }
     // ---- transformed A tile and B tile -> LDS
 #pragma unroll
-    for (int j = 0; j < 32; ++j) As[c0 + j][m] = v[j];
+    for (int j = 0; j < CW; ++j) As[c0 + j][m] = v[j];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const int e = t + 256 * q;
+    for (int q = 0; q < NLB; ++q) {
+        const int e = t + NT * q;
         Bs[a.tb ? (e & 255) : (e >> 5)][a.tb ? (e >> 8) : (e & 31)] = rb[q];
     }
     __syncthreads();
-    // ---- the GEMM proper: four waves x 64 k each (exact fp32 MFMA), partial tiles joined in a fixed order
+    // ---- the GEMM proper: NW waves x BK / NW k each (exact fp32 MFMA), partial tiles joined in a fixed order
     f32x16 acc = (f32x16)0.f;
 #pragma unroll 8
-    for (int u = 0; u < BK / 8; ++u) {
-        const int kk = wave * (BK / 4) + 2 * u + h;
+    for (int u = 0; u < BK / (2 * NW); ++u) {
+        const int kk = wave * (BK / NW) + 2 * u + h;
         acc = mfma_f32(As[kk][i], Bs[kk][i], acc);
     }
     __syncthreads();
@@ -1830,10 +1836,11 @@ __global__ __launch_bounds__(256) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
     for (int r = 0; r < 16; ++r) partt[wave][drow32(r, h) * 33 + i] = acc[r];
     __syncthreads();
 #pragma unroll
-    for (int e = t; e < 1024; e += 256) {
+    for (int e = t; e < 1024; e += NT) {
         const int r = e >> 5, c = e & 31, o = r * 33 + c;
         if (m0 + r < a.M && n0 + c < a.N) {
             float vv = ((partt[0][o] + partt[1][o]) + partt[2][o]) + partt[3][o];
+            if constexpr (NW == 8) vv = (((vv + partt[4][o]) + partt[5][o]) + partt[6][o]) + partt[7][o];
             vv += a.bias ? a.bias[n0 + c] : 0.f;
             const int64_t idx = (int64_t)(m0 + r) * a.ldc + n0 + c;
             if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = vv; vv = gelu_exact(vv); }
@@ -2213,8 +2220,8 @@ int dpn_sgemm_ln(const DpnLnGemm* q, void* stream) {
     LnGemmArgs a{q->mode, q->M, q->N, q->tb, q->ldb, q->ldc, q->epi, q->x, q->r, q->gamma, q->beta, q->rstd_in, q->y_out, q->xhat_out,
                  q->rstd_out, q->partial, q->B, q->bias, q->C, q->aux, q->aux_out};
     const dim3 grid((q->N + 31) / 32, (q->M + 31) / 32);
-    if (q->mode == 1) hipLaunchKernelGGL(dpn_sgemm_ln_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(dpn_sgemm_ln_kernel<2>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    if (q->mode == 1) hipLaunchKernelGGL((dpn_sgemm_ln_kernel<1, 512>), grid, dim3(512), 0, reinterpret_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL((dpn_sgemm_ln_kernel<2, 512>), grid, dim3(512), 0, reinterpret_cast<hipStream_t>(stream), a);
     return ck(hipGetLastError());
 }
 
