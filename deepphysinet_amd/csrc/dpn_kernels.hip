@@ -1599,11 +1599,14 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     const SgemmProblem& a = batch.p[blockIdx.z];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= a.M || n0 >= a.N) return;
-    // 66 KB of LDS: two workgroups per CU.  The split-K partial tiles (16.5 KB) reuse the A staging buffers after the last k-tile.
-    __shared__ float As[NBUF][BK][BM + 1];
-    __shared__ float Bs[NBUF][BK][BN + 1];
-    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(&As[0][0][0]);
-    static_assert(sizeof(As) >= NW * 32 * 33 * sizeof(float), "partial tiles must fit in the A staging buffers");
+    // 34 KB (<64,2>) or 68 KB (<256,1>) of LDS: four or two workgroups per CU.  The partial tiles of the waves (eight: 33 KB) reuse the
+    // staging buffers after the last k-tile.  Both forms run with eight waves: -15 us (<256,1>) and -53 us (<64,2>) per step against four.
+    struct Stage { float A[NBUF][BK][BM + 1]; float B[NBUF][BK][BN + 1]; };
+    __shared__ Stage stage;
+    float (&As)[NBUF][BK][BM + 1] = stage.A;
+    float (&Bs)[NBUF][BK][BN + 1] = stage.B;
+    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(&stage);           // the partial tiles reuse the staging buffers
+    static_assert(sizeof(Stage) >= NW * 32 * 33 * sizeof(float), "partial tiles must fit in the staging buffers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     f32x16 acc = (f32x16)0.f;
@@ -2200,7 +2203,7 @@ static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, in
     }
     single_tile = single_tile && out_tiles <= kSingleStageMaxOutTiles;
     if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1, 512>), dim3(gx, gy, gz), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), b);
-    else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<64, 2>), dim3(gx, gy, gz), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), b);
+    else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<64, 2, 512>), dim3(gx, gy, gz), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), b);
     return ck(hipGetLastError());
 }
 
