@@ -1693,8 +1693,9 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     for (int e = threadIdx.x; e < 1024; e += NT) {
         const int r = e >> 5, c = e & 31, o = r * 33 + c;
         if (m0 + r < a.M && n0 + c < a.N) {
-            float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
-            if constexpr (NW == 8) v = (((v + part[4][o]) + part[5][o]) + part[6][o]) + part[7][o];
+            float v = part[0][o];
+#pragma unroll
+            for (int w_ = 1; w_ < NW; ++w_) v += part[w_][o];               // fixed order: wave 0, 1, ... (left fold)
             v += a.bias ? a.bias[n0 + c] : 0.f;
             const int64_t idx = (int64_t)(m0 + r) * a.ldc + n0 + c;
             if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = v; v = gelu_exact(v); }
@@ -1842,8 +1843,9 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_ln_kernel(LnGemmArgs a) {
     for (int e = t; e < 1024; e += NT) {
         const int r = e >> 5, c = e & 31, o = r * 33 + c;
         if (m0 + r < a.M && n0 + c < a.N) {
-            float vv = ((partt[0][o] + partt[1][o]) + partt[2][o]) + partt[3][o];
-            if constexpr (NW == 8) vv = (((vv + partt[4][o]) + partt[5][o]) + partt[6][o]) + partt[7][o];
+            float vv = partt[0][o];
+#pragma unroll
+            for (int w_ = 1; w_ < NW; ++w_) vv += partt[w_][o];            // fixed order: wave 0, 1, ... (left fold)
             vv += a.bias ? a.bias[n0 + c] : 0.f;
             const int64_t idx = (int64_t)(m0 + r) * a.ldc + n0 + c;
             if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = vv; vv = gelu_exact(vv); }
