@@ -25,25 +25,28 @@ constexpr int kD = 256, kH = 8, kE = 32, kLmax = 288, kLp = 289;      // kLp: pa
 
 DEV f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
+// the attention kernels run with kAT threads = kAW waves per workgroup (eight: the score / dS tiles, the softmax rows and the k-pairs of the
+// reductions are spread over twice the waves of the first version -- these kernels are latency chains on 72 ... 144 workgroups)
+constexpr int kAT = 512, kAW = kAT / 64;
 // rows [r0, r0+nr) x 32 head columns of a [L][256] matrix -> LDS [row][33]; rows >= L are zero
 // (all 16-byte loads are issued before the first LDS store: one memory round trip, not one per element)
 template <int NR>
-struct Rows16 { float4 v[(NR * 8 + 255) / 256]; };
+struct Rows16 { float4 v[(NR * 8 + kAT - 1) / kAT]; };
 template <int NR>
 DEV void rows16_fetch(Rows16<NR>& R, const float* src, int64_t row_stride, int64_t col0, int r0, int L) {
-    constexpr int N = (NR * 8 + 255) / 256;
+    constexpr int N = (NR * 8 + kAT - 1) / kAT;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-        const int e = threadIdx.x + 256 * q, r = e >> 3, c4 = e & 7;
+        const int e = threadIdx.x + kAT * q, r = e >> 3, c4 = e & 7;
         R.v[q] = (r < NR && r0 + r < L) ? *reinterpret_cast<const float4*>(src + (int64_t)(r0 + r) * row_stride + col0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 template <int NR>
 DEV void rows16_store(float (*dst)[33], const Rows16<NR>& R) {
-    constexpr int N = (NR * 8 + 255) / 256;
+    constexpr int N = (NR * 8 + kAT - 1) / kAT;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-        const int e = threadIdx.x + 256 * q, r = e >> 3, c4 = e & 7;
+        const int e = threadIdx.x + kAT * q, r = e >> 3, c4 = e & 7;
         if (r < NR) { dst[r][c4 * 4] = R.v[q].x; dst[r][c4 * 4 + 1] = R.v[q].y; dst[r][c4 * 4 + 2] = R.v[q].z; dst[r][c4 * 4 + 3] = R.v[q].w; }
     }
 }
@@ -56,7 +59,7 @@ DEV void load_rows16(float (*dst)[33], const float* src, int64_t row_stride, int
 // D[r] = sum_e gO[r][e] * O[r][e] over the 32 columns of a head, rows r0 .. r0 + nrows: 8 lanes per row, one float4 of each operand per
 // lane (all loads in flight at once), joined by three shuffles
 DEV void head_rowdot(float* dst, const float* go, const float* o, int head, int r0, int nrows, int L) {
-    for (int base = 0; base < nrows; base += 32) {
+    for (int base = 0; base < nrows; base += kAT / 8) {
         const int r = base + (threadIdx.x >> 3), c4 = threadIdx.x & 7;
         float d = 0.f;
         if (r < nrows && r0 + r < L) {
@@ -77,7 +80,7 @@ DEV void load_head_rows(float (*dst)[33], const float* src, int head, int r0, in
 template <class FA, class FB>
 DEV void mma_tile(f32x16& acc, int npairs, FA fa, FB fb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
-    for (int u = wave; u < npairs; u += 4) acc = mfma_f32(fa(i, 2 * u + h), fb(2 * u + h, i), acc);
+    for (int u = wave; u < npairs; u += kAW) acc = mfma_f32(fa(i, 2 * u + h), fb(2 * u + h, i), acc);
 }
 // sum the four waves' partial 32x32 tiles in a fixed order; result(r, c) handed to `sink`
 template <class SINK>
@@ -87,9 +90,12 @@ DEV void reduce_tile(const f32x16& acc, float (*part)[32 * 33], SINK sink) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave][drow32(r, h) * 33 + i] = acc[r];
     __syncthreads();
-    for (int e = threadIdx.x; e < 1024; e += 256) {
+    for (int e = threadIdx.x; e < 1024; e += kAT) {
         const int r = e >> 5, c = e & 31, o = r * 33 + c;
-        sink(r, c, ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
+        float v = part[0][o];
+#pragma unroll
+        for (int w_ = 1; w_ < kAW; ++w_) v += part[w_][o];               // fixed order (left fold over the waves)
+        sink(r, c, v);
     }
 }
 
@@ -118,14 +124,14 @@ DEV AttnArgs attn_field(AttnArgs a, const int b) {
 // ---------------------------------------------------------------------------------------------------- attention forward
 // grid (query tiles of 32, heads); one workgroup keeps K and V of its head in LDS, computes its 32 score rows, the row
 // softmax, the probabilities (saved for the backward pass) and the 32 x 32 output tile.
-__global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a0) {
+__global__ __launch_bounds__(kAT) void dpn_attn_fwd_kernel(AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AttnArgs a = attn_field(a0, blockIdx.z);
     float (*Ks)[33] = reinterpret_cast<float (*)[33]>(smem);                                  // [288][33]
     float (*Vs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);                 // [288][33]
     float (*Qs)[33] = reinterpret_cast<float (*)[33]>(smem + 2 * kLmax * 33 * 4);             // [32][33]
     float (*Ss)[kLp] = reinterpret_cast<float (*)[kLp]>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4);   // [32][289]
-    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4);   // [4][1056]
+    float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(smem + 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4);   // [kAW][1056]
     const int head = blockIdx.y, q0 = blockIdx.x * 32, L = a.L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     load_head_rows(Ks, a.k, head, 0, kLmax, L);
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a0) {
     return;
 #endif
     // scores: column tile ct belongs to wave ct % 4 (whole K = 32 per tile, no cross-wave reduction)
-    for (int ct = wave; ct < kLmax / 32; ct += 4) {
+    for (int ct = wave; ct < kLmax / 32; ct += kAW) {
         f32x16 acc = (f32x16)0.f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = mfma_f32(Qs[i][2 * u + h], Ks[ct * 32 + i][2 * u + h], acc);
@@ -153,23 +159,24 @@ __global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a0) {
     {   // softmax: one wave per 8 rows, the 64 lanes stride the 288 columns (LDS row stride 289: consecutive lanes hit consecutive
         // banks; the probabilities leave as coalesced 256-byte stores); row max / sum by wave shuffles
         // the 8 rows of a wave are independent chains (LDS read -> shuffle max -> exp -> shuffle sum): all eight run interleaved
-        float e[8][5], mx[8], sm[8];
+        constexpr int RPW = 32 / kAW;                                    // rows per wave
+        float e[RPW][5], mx[RPW], sm[RPW];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
+        for (int rr = 0; rr < RPW; ++rr) {
             mx[rr] = -INFINITY;
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 const int c = lane + 64 * q;
-                e[rr][q] = (c < kLmax) ? Ss[wave * 8 + rr][c] : -INFINITY;
+                e[rr][q] = (c < kLmax) ? Ss[wave * RPW + rr][c] : -INFINITY;
                 mx[rr] = fmaxf(mx[rr], e[rr][q]);
             }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) mx[rr] = fmaxf(mx[rr], __shfl_xor(mx[rr], o));
+            for (int rr = 0; rr < RPW; ++rr) mx[rr] = fmaxf(mx[rr], __shfl_xor(mx[rr], o));
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
+        for (int rr = 0; rr < RPW; ++rr) {
             sm[rr] = 0.f;
 #pragma unroll
             for (int q = 0; q < 5; ++q) { e[rr][q] = __expf(e[rr][q] - mx[rr]); sm[rr] += e[rr][q]; }    // v_exp_f32 (1e-6 rel.); exp(-inf) = 0 for the padding columns
@@ -177,10 +184,10 @@ __global__ __launch_bounds__(256) void dpn_attn_fwd_kernel(AttnArgs a0) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) sm[rr] += __shfl_xor(sm[rr], o);
+            for (int rr = 0; rr < RPW; ++rr) sm[rr] += __shfl_xor(sm[rr], o);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = wave * 8 + rr;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int row = wave * RPW + rr;
             const float inv = 1.f / sm[rr];
             const bool rok = q0 + row < L;
 #pragma unroll
@@ -222,21 +229,22 @@ DEV void attn_bwd_query_role(const AttnArgs& a, char* smem) {
     load_head_rows(Vs, a.v, head, 0, kLmax, L);
     load_head_rows(Gs, a.go, head, q0, 32, L);
     {   // P rows of this query tile: 32 x 288 floats = 2304 float4, nine per thread, all in flight at once
-        float4 pv[9];
+        constexpr int NP = (32 * 72 + kAT - 1) / kAT;
+        float4 pv[NP];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int e = threadIdx.x + 256 * q, r = e / 72, c4 = e % 72;
-            pv[q] = (q0 + r < L) ? *reinterpret_cast<const float4*>(a.P + ((int64_t)head * kLmax + q0 + r) * kLmax + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NP; ++q) {
+            const int e = threadIdx.x + kAT * q, r = e / 72, c4 = e % 72;
+            pv[q] = (e < 32 * 72 && q0 + r < L) ? *reinterpret_cast<const float4*>(a.P + ((int64_t)head * kLmax + q0 + r) * kLmax + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int e = threadIdx.x + 256 * q, r = e / 72, c4 = e % 72;
-            Ss[r][c4 * 4] = pv[q].x; Ss[r][c4 * 4 + 1] = pv[q].y; Ss[r][c4 * 4 + 2] = pv[q].z; Ss[r][c4 * 4 + 3] = pv[q].w;
+        for (int q = 0; q < NP; ++q) {
+            const int e = threadIdx.x + kAT * q, r = e / 72, c4 = e % 72;
+            if (e < 32 * 72) { Ss[r][c4 * 4] = pv[q].x; Ss[r][c4 * 4 + 1] = pv[q].y; Ss[r][c4 * 4 + 2] = pv[q].z; Ss[r][c4 * 4 + 3] = pv[q].w; }
         }
     }
     head_rowdot(Drow, a.go, a.o, head, q0, 32, L);
     __syncthreads();
-    for (int ct = wave; ct < kLmax / 32; ct += 4) {
+    for (int ct = wave; ct < kLmax / 32; ct += kAW) {
         f32x16 acc = (f32x16)0.f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = mfma_f32(Gs[i][2 * u + h], Vs[ct * 32 + i][2 * u + h], acc);      // dP tile
@@ -277,7 +285,7 @@ DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
         if (j0 + r < L) a.dv[(int64_t)(j0 + r) * kD + head * kE + c] = v;
     });
     __syncthreads();
-    for (int rt = wave; rt < kLmax / 32; rt += 4) {                                            // dS[rows of tile rt][key tile]
+    for (int rt = wave; rt < kLmax / 32; rt += kAW) {                                            // dS[rows of tile rt][key tile]
         f32x16 dp = (f32x16)0.f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) dp = mfma_f32(Rs[rt * 32 + i][2 * u + h], Vt[i][2 * u + h], dp);              // dP[row][j] = sum_e gO[row][e] V[j][e]
@@ -297,7 +305,7 @@ DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
     });
 }
 
-__global__ __launch_bounds__(256) void dpn_attn_bwd_kernel(AttnArgs a0) {
+__global__ __launch_bounds__(kAT) void dpn_attn_bwd_kernel(AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AttnArgs a = attn_field(a0, blockIdx.z >> 1);        // grid.z = 2 * field + role
     if ((blockIdx.z & 1) == 0) attn_bwd_query_role(a, smem);
@@ -433,8 +441,9 @@ __global__ __launch_bounds__(256) void dpn_sum_parts_kernel(const float* parts, 
     } else if (i < count + zero_tail) out[i] = 0.f;
 }
 
-constexpr int kAttnLds = 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4 + 4 * 32 * 33 * 4;       // 134,144 B
-static_assert(2 * kLmax * 33 * 4 + 32 * 33 * 4 + kLmax * 4 + 4 * 32 * 33 * 4 <= kAttnLds, "the key role fits in the query role's LDS");
+constexpr int kAttnLds = 2 * kLmax * 33 * 4 + 32 * 33 * 4 + 32 * kLp * 4 + kAW * 32 * 33 * 4;     // 151,040 B with eight waves
+static_assert(2 * kLmax * 33 * 4 + 32 * 33 * 4 + kLmax * 4 + kAW * 32 * 33 * 4 <= kAttnLds, "the key role fits in the query role's LDS");
+static_assert(kAttnLds <= 160 * 1024, "one workgroup per CU");
 
 }  // namespace
 
@@ -447,7 +456,7 @@ int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, int batc
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); once = true; }
-    hipLaunchKernelGGL(dpn_attn_fwd_kernel, dim3((L + 31) / 32, kH, batch), dim3(256), kAttnLds, s, a);
+    hipLaunchKernelGGL(dpn_attn_fwd_kernel, dim3((L + 31) / 32, kH, batch), dim3(kAT), kAttnLds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -460,7 +469,7 @@ int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); once = true; }
-    hipLaunchKernelGGL(dpn_attn_bwd_kernel, dim3((L + 31) / 32, kH, 2 * batch), dim3(256), kAttnLds, s, a);
+    hipLaunchKernelGGL(dpn_attn_bwd_kernel, dim3((L + 31) / 32, kH, 2 * batch), dim3(kAT), kAttnLds, s, a);
     return (int)hipGetLastError();
 }
 
