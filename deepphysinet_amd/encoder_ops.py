@@ -156,7 +156,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         L.check(lib.dpn_attn_fwd(_p(q), _p(k), _p(v), Lt, B, _p(o), _p(P), _s()), 'dpn_attn_fwd')
         a = new(n, D)
         _launch([_problem(n, D, D, [(o, D, wo, D)], a, D, 0, 1, bias=bo)])
-        # (LayerNorm forward folded into the conv1 GEMM -- dpn_sgemm_ln mode 1 -- measured slower than the two launches: 21 vs 13.6 us)
+        # (LayerNorm forward folded into the conv1 GEMM -- dpn_sgemm_ln mode 1 -- measured slower than the two launches: 21 vs 13.6 us with four waves, equal with eight)
         x1, xhat1, rstd1 = new(n, D), new(n, D), new(n)
         L.check(lib.dpn_add_ln_fwd(_p(x), _p(a), _p(g1), _p(be1), n, _p(x1), _p(xhat1), _p(rstd1), _s()), 'dpn_add_ln_fwd')
         pre, act = new(n, Fh), new(n, Fh)
