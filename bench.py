@@ -33,8 +33,8 @@ EXEC_MAC_FWD = 409_600                 # MACs per point per net actually issued 
 MFMA_PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
 # HBM bytes per dpn_fwd_kernel launch at 37 265 points from the rocprofv3 PMC passes committed in profiles/
 # (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 FETCH_SIZE correction of the guide applied); bench.py cannot collect PMCs itself.
-PMC_TRAFFIC_FWD = {('bf16', 257 * 145): (2 * 22653.4 + 358738.1) * 1024}
-PMC_TRAFFIC_WGRAD = {('bf16', 257 * 145): (2 * 429678.6 + 54001.9) * 1024}
+PMC_TRAFFIC_FWD = {('bf16', 257 * 145): (2 * 22687.9 + 358747.2) * 1024}
+PMC_TRAFFIC_WGRAD = {('bf16', 257 * 145): (2 * 429202.9 + 54001.9) * 1024}
 HBM_PEAK = 8.0e12                      # HBM3E, MI355X_MICROARCH.md
 
 
