@@ -1,15 +1,21 @@
 #!/usr/bin/env python
 """Benchmark of the physics-informed training step on MI355X (one process per GPU).
 
-    python bench.py [--gpus 1 --steps 200 --warmup 20] [--prec bf16x2] [--leads 61]
+    python bench.py [--gpus N --steps 200 --warmup 20] [--prec bf16] [--leads 61]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (a child `torch.distributed.run`, before this
+process has touched a GPU) and exits with the child's code.
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg2"): one field sample on the 0.25 degree grid (257 x 145 =
 37 265 collocation points, every grid node, t drawn per point), all six primitive-equation residual losses.
 One step = place_one_batch (encoder + hyper-network heads + fused HIP forward/Jacobian + residuals) + backward to
 all 155 parameter tensors + clip_grad_norm_(2.5e7) + Adam step, captured in one hipGraph; inputs are resident in HBM.
-With N > 1 every rank runs its own field sample (weak scaling, as the reference's DistributedSampler does), the compute part is
-the graph and the gradient all-reduce (one RCCL call per step) + fused optimiser run eagerly behind it.
+With N > 1 every rank runs its own field sample (weak scaling, as the reference's DistributedSampler does); the step is cut into three
+hipGraphs where a bucket of gradients is complete (point backward | heads backward | encoder backward) and each bucket's RCCL
+all-reduce -- in place on a slice of the optimiser's flat gradient buffer -- is queued behind its graph, so it runs under the rest of
+the backward pass; the fused optimiser follows the last bucket.
+Default precision: bf16x2 (hi+lo split bf16 MFMA operands), the mode whose PDE losses are parity-tested at 1e-4; plain bf16 operands
+(--prec bf16) are reported under `other_precision_mode`.
 --leads B: BASELINE configs[2], B field samples x 37 265 points in one step (place_lead_batch).
 
 Prints ONE JSON line on rank 0: the contract keys, `roofline` (dpn_fwd_kernel, MFMA-bound; duration from a HIP event pair around every
@@ -31,11 +37,21 @@ ALG_FLOP_FWD_JAC = 11_218_944          # algorithmic FLOP per co
 ALG_FLOP_STEP = 31_887_360             # fwd + Jacobian + bwd
 EXEC_MAC_FWD = 409_600                 # MACs per point per net actually issued by dpn_fwd_kernel
 MFMA_PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
-# HBM bytes per dpn_fwd_kernel launch at 37 265 points from the rocprofv3 PMC passes committed in profiles/
-# (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 FETCH_SIZE correction of the guide applied); bench.py cannot collect PMCs itself.
-PMC_TRAFFIC_FWD = {('bf16', 257 * 145): (2 * 22687.9 + 358747.2) * 1024}
-PMC_TRAFFIC_WGRAD = {('bf16', 257 * 145): (2 * 429202.9 + 54001.9) * 1024}
 HBM_PEAK = 8.0e12                      # HBM3E, MI355X_MICROARCH.md
+# HBM bytes per launch of the two roofline kernels come from the rocprofv3 PMC passes committed in profiles/ (bench.py cannot run PMC
+# passes on itself): profiles/pmc_traffic.json, written by tools/pmc_traffic.py from the FETCH_SIZE / WRITE_SIZE passes of
+# tools/refresh_profiles.sh (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction), keyed "<kernel>|<prec>|<points>".
+PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+
+
+def pmc_traffic(kernel, prec, points):
+    try:
+        with open(PMC_TRAFFIC_FILE) as fh:
+            tab = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    e = tab.get('%s|%s|%d' % (kernel, prec, points))
+    return (e['bytes'], e.get('source')) if e else (None, None)
 
 
 def synth_batch(n_points, device, seed, lon=257, lat=145, dx=27000.0, dy=27000.0):
@@ -79,6 +95,26 @@ def cpu_baseline(sample_points, seed, share_derivatives=False):
     return sample_points / best, best
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD torch.distributed.run (this process has not touched a
+    GPU: torch.cuda.device_count() does not initialise one) and hand back its exit code."""
+    import socket
+    import subprocess
+    one_device = os.environ.get('DPN_BENCH_ONE_DEVICE') == '1'
+    have = torch.cuda.device_count()
+    if have < (1 if one_device else n):
+        print('bench.py --gpus %d: only %d GPU(s) visible on this node' % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL across processes needs it on this pool
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -86,13 +122,22 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--points', type=int, default=257 * 145)
     ap.add_argument('--leads', type=int, default=1, help='field samples per step (BASELINE configs[2]: 61); default 1 = configs[1]')
-    ap.add_argument('--prec', default=os.environ.get('DPN_PREC', 'bf16'), choices=['bf16', 'bf16x2'])
+    ap.add_argument('--prec', default=os.environ.get('DPN_PREC', 'bf16x2'), choices=['bf16', 'bf16x2'],
+                    help='bf16x2 (default): the parity-grade mode (PDE losses within 1e-4 of the fp32 reference); bf16: plain bf16 operands')
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=16384)
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%s: the launcher and the flag disagree' % (args.gpus, env_world))
 
     from deepphysinet_amd import distributed as D
     # DPN_BENCH_BACKEND=gloo + DPN_BENCH_ONE_DEVICE=1: exercise the N > 1 code path with every rank on GPU 0 (test boxes have one GPU)
@@ -110,8 +155,8 @@ def main():
     def build(prec):
         torch.manual_seed(1)                      # identical random-init weights on every rank
         m = builder_models(**ncep_config(), precision=prec).to(dev)
-        from deepphysinet_amd.optim import FusedClipAdam
-        opt = FusedClipAdam(m.physics_net.parameters(), lr=1e-4, weight_decay=1e-4, max_norm=2.5e7)   # clip_grad_norm_ + Adam, cfg:151-155
+        # clip_grad_norm_(2.5e7) + Adam(lr 1e-4, weight_decay 1e-4), cfg:151-155; flat gradient buffer in backward-completion order
+        opt = m.build_optimizer(max_norm=2.5e7)
         return m, opt
 
     batch = synth_batch(args.points, dev, seed=1 + rank)
@@ -123,19 +168,16 @@ def main():
         lead['forecast_h'] = torch.arange(args.leads, device=dev, dtype=torch.float32).mul_(24.0 / 360.0).view(-1, 1, 1)
         del many
     crit = torch.nn.MSELoss()
-    sync = D.GradientAllReduce() if world > 1 else None
-
-    split_step = world > 1 or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1'
+    # N > 1 (or DPN_BENCH_SPLIT_STEP=1 on one GPU, to time the same code path): three graph segments with a bucket all-reduce behind each
+    split_step = (world > 1 or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1') and args.leads == 1
 
     def make_step(m, opt):
-        """Returns (compute, finish): compute = zero_grad + place_one_batch + backward (hipGraph-captured);
-        finish = gradient all-reduce (N > 1) + global-norm clip + Adam.  With one GPU both are captured in a single graph."""
+        """One GPU: [whole] = zero_grad + place_one_batch + backward + clip + Adam, one callable (one hipGraph).
+        N > 1: the StagedPdeStep segments (each its own hipGraph) with the bucket all-reduce queued behind each, then the optimiser."""
         lf = m.train_cfg['losses']['loss_factor']
-        params = list(m.physics_net.parameters())
-
         one = torch.ones((), dtype=torch.float32, device=dev)
 
-        def compute():
+        def whole():
             opt.zero_grad(set_to_none=True)
             if args.leads > 1:
                 loss, _ = m.place_lead_batch(lead['x'], lead['y'], lead['t'], lead['f'], lead['field_data'], lead['coord_data'],
@@ -144,53 +186,71 @@ def main():
                 loss = m.place_one_batch(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'],
                                          batch['forecast_h'], crit, lf, 0, 0, dev)
             loss.backward(one)                         # persistent seed: no ones_like fill per step
+            if world > 1:                              # configs[2] on N GPUs: one bucketed all-reduce behind the whole backward
+                sync()
+            opt.step()                                 # global-norm clip (2.5e7) + Adam in the HIP library
             return loss
 
-        def finish():
-            if sync is not None:
-                sync(params)
-            opt.step()                                 # global-norm clip (2.5e7) + Adam in the HIP library
-
-        return compute, finish
+        if not split_step:
+            return [whole], None
+        from deepphysinet_amd.interface.interface_physics import StagedPdeStep
+        staged = StagedPdeStep(m, opt, batch, lf)
+        return list(staged.stages) + [opt.step], staged
 
     def run(prec, steps, warmup, use_graph):
+        nonlocal sync
         m, opt = build(prec)
-        compute, finish = make_step(m, opt)
+        if world > 1:
+            D.broadcast_parameters(m.physics_net)      # DDP's wrap-time broadcast (the seeds already agree; this makes it a fact)
+        sync = D.GradientAllReduce(opt) if world > 1 else None
+        segments, staged = make_step(m, opt)
+        n_reduce = len(segments) - 1 if split_step else 0     # segment i completes gradient bucket i; the last segment is the optimiser
 
-        def whole():
-            compute()
-            finish()
-        graph = None
-        if use_graph:
-            # one GPU: the whole step is one graph.  N > 1: the compute part is a graph, the collective + optimiser run eagerly
-            # after it (a dozen launches), so no RCCL call is ever captured.
-            captured = compute if split_step else whole
+        def eager():
+            for i, seg in enumerate(segments):
+                seg()
+                if sync is not None and i < n_reduce:
+                    sync.reduce_bucket(i)
+                    if i == n_reduce - 1:
+                        sync.wait()
+        graphs = None
+        capturable = use_graph and not (world > 1 and not split_step)      # a step with the collective inside stays eager
+        if capturable:
             try:
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     for _ in range(2):
-                        whole()
+                        eager()
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    captured()
+                graphs, pool = [], None
+                for seg in segments:                  # one capture stream (torch's default) and one memory pool for all segments:
+                    g = torch.cuda.CUDAGraph()        # the autograd graph built in segment 0 is walked in segments 1 and 2
+                    with torch.cuda.graph(g, pool=pool):
+                        seg()
+                    pool = g.pool()
+                    graphs.append(g)
             except Exception as e:                 # noqa
                 if rank == 0:
                     print('[bench] hipGraph capture failed (%s: %s); running eager' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
-                graph = None
+                graphs = None
                 torch.cuda.synchronize()
                 m, opt = build(prec)
-                compute, finish = make_step(m, opt)
-        if graph is None:
-            fn = whole
-        elif split_step:
-            def fn():
-                graph.replay()
-                finish()
+                sync = D.GradientAllReduce(opt) if world > 1 else None
+                segments, staged = make_step(m, opt)
+        if graphs is None:
+            fn = eager
+        elif len(graphs) == 1:
+            fn = graphs[0].replay
         else:
-            fn = graph.replay
+            def fn():
+                for i, g in enumerate(graphs):
+                    g.replay()
+                    if sync is not None and i < n_reduce:
+                        sync.reduce_bucket(i)         # queued behind segment i, runs under segments i+1..
+                        if i == n_reduce - 1:
+                            sync.wait()               # the optimiser segment waits for every bucket
         for _ in range(warmup):
             fn()
         if world > 1:
@@ -204,11 +264,12 @@ def main():
             torch.distributed.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt = float(tt.item())
-        return m, dt, graph is not None
+        return m, dt, graphs is not None
 
+    sync = None
     m, dt, graphed = run(args.prec, args.steps, args.warmup, not args.no_graph)
     ms_per_step = dt / args.steps * 1e3
     pts_per_s = args.points * args.leads * world * args.steps / dt
@@ -223,7 +284,9 @@ def main():
                                ('configs[2]: %d forecast-lead field samples x %d collocation points per GPU per step (one batched encoder pass, '
                                 'point kernels field after field), six PDE residual losses, fwd+Jacobian+bwd+clip+Adam' % (args.leads, args.points)),
                    'leads': args.leads,
-                   'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world},
+                   'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world,
+                   'step_segments': 4 if split_step else 1},
+        'timed_seconds': dt,
         'algorithmic_tflops_step': pts_per_s * ALG_FLOP_STEP / 1e12,
     }
 
@@ -310,7 +373,8 @@ def main():
         nsplit_bytes = 2 if args.prec == 'bf16x2' else 1
         out['roofline'] = {'bound': 'mfma', 'kernel': 'dpn_fwd_kernel<%d>' % (2 if args.prec == 'bf16x2' else 1),
                            'achieved': ach / 1e12, 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_BF16,
-                           'traffic': PMC_TRAFFIC_FWD.get((args.prec, args.points)), 'traffic_source': 'profiles/round1_pmc_bf16_eager_step.txt',
+                           'traffic': pmc_traffic('dpn_fwd_kernel', args.prec, args.points)[0],
+                           'traffic_source': pmc_traffic('dpn_fwd_kernel', args.prec, args.points)[1],
                            'kernel_ms': k_ms,
                            'algorithmic_flop_per_point': ALG_FLOP_FWD_JAC,
                            'executed_mfma_tflops': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / 1e12,
@@ -320,7 +384,7 @@ def main():
         out['roofline_hbm_kernel'] = {'bound': 'hbm', 'kernel': 'dpn_wgrad_kernel<%d>' % (2 if args.prec == 'bf16x2' else 1),
                                       'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                                       'frac': w_bytes / (w_ms * 1e-3) / HBM_PEAK, 'kernel_ms': w_ms, 'algorithmic_bytes': w_bytes,
-                                      'traffic': PMC_TRAFFIC_WGRAD.get((args.prec, args.points))}
+                                      'traffic': pmc_traffic('dpn_wgrad_kernel', args.prec, args.points)[0]}
         if not args.no_alt and world == 1:
             alt = 'bf16x2' if args.prec == 'bf16' else 'bf16'
             del m

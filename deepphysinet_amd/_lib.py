@@ -104,6 +104,7 @@ EXPORTS = {
     'dpn_clip_adam_flat_floats': (c_int64, [c_int, c_void_p]),
     'dpn_clip_adam_flat': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                    c_float, c_float, c_void_p, c_void_p]),
+    'dpn_clip_adam_flat_dev': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_selftest': (c_int, [c_void_p, c_void_p]),
 }
 

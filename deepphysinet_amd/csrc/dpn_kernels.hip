@@ -1933,10 +1933,15 @@ __global__ __launch_bounds__(256) void dpn_gradnorm_reduce_kernel(const double* 
 }
 template <class Table>
 __global__ __launch_bounds__(256) void dpn_adam_kernel(Table t, const double* sumsq, const int* step, float lr, float b1, float b2, float eps,
-                                                       float wd, float max_norm, float* out_norm) {
-    const float total = (float)sqrt(*sumsq);
+                                                       float wd, float max_norm, float* out_norm, const float* hyper) {
+    // hyper (optional, device): [lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale] read at run time, so that a step captured in
+    // a hipGraph follows a learning-rate schedule (a by-value lr is frozen into the graph); grad_scale multiplies every gradient
+    // before the norm and the update (1 / world_size after a SUM all-reduce)
+    float gscale = 1.f;
+    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; max_norm = hyper[5]; gscale = hyper[6]; }
+    const float total = (float)sqrt(*sumsq) * gscale;
     if (out_norm && blockIdx.x == 0 && threadIdx.x == 0) *out_norm = total;
-    const float coef = fminf(max_norm / (total + 1e-6f), 1.0f);             // clip_grad_norm_'s clamp(max_norm / (norm + 1e-6), max=1)
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.0f) * gscale;    // clip_grad_norm_'s clamp(max_norm / (norm + 1e-6), max=1)
     const float st = (float)(*step);
     const float bc1 = 1.f - powf(b1, st), bc2s = sqrtf(1.f - powf(b2, st));
     const float step_size = lr / bc1;
@@ -2260,7 +2265,7 @@ int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads
             t.chunk_start[t.n] = chunks;
             if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel<AdamTable>, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
             else hipLaunchKernelGGL(dpn_adam_kernel<AdamTable>, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr, beta1,
-                                    beta2, eps, weight_decay, max_norm, out_norm_dev);
+                                    beta2, eps, weight_decay, max_norm, out_norm_dev, (const float*)nullptr);
             base_chunk += chunks;
         }
         if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, base_chunk, sumsq);
@@ -2275,9 +2280,9 @@ int64_t dpn_clip_adam_flat_floats(int n_tensors, const int64_t* numel) {
     return chunks * kAdamChunk;
 }
 
-int dpn_clip_adam_flat(int n_tensors, float* const* params, const float* const* grads, const int64_t* numel, float* exp_avg_flat,
-                       float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, float max_norm, float* out_norm_dev, void* stream) {
+static int clip_adam_flat_impl(int n_tensors, float* const* params, const float* const* grads, const int64_t* numel, float* exp_avg_flat,
+                               float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float max_norm, float* out_norm_dev, const float* hyper_dev, void* stream) {
     if (n_tensors <= 0 || !params || !grads || !numel || !exp_avg_flat || !exp_avg_sq_flat || !scratch_dev || !step_dev) return -1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     double* sumsq = scratch_dev;
@@ -2300,12 +2305,27 @@ int dpn_clip_adam_flat(int n_tensors, float* const* params, const float* const* 
             t.chunk_start[t.n] = chunks;
             if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
             else hipLaunchKernelGGL(dpn_adam_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr,
-                                    beta1, beta2, eps, weight_decay, max_norm, out_norm_dev);
+                                    beta1, beta2, eps, weight_decay, max_norm, out_norm_dev, (const float*)nullptr);
             base_chunk += chunks;
         }
         if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, base_chunk, sumsq);
     }
     return ck(hipGetLastError());
+}
+
+int dpn_clip_adam_flat(int n_tensors, float* const* params, const float* const* grads, const int64_t* numel, float* exp_avg_flat,
+                       float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float max_norm, float* out_norm_dev, void* stream) {
+    return clip_adam_flat_impl(n_tensors, params, grads, numel, exp_avg_flat, exp_avg_sq_flat, scratch_dev, step_dev, lr, beta1, beta2, eps,
+                               weight_decay, max_norm, out_norm_dev, nullptr, stream);
+}
+
+int dpn_clip_adam_flat_dev(int n_tensors, float* const* params, const float* const* grads, const int64_t* numel, float* exp_avg_flat,
+                           float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, const float* hyper_dev, float* out_norm_dev,
+                           void* stream) {
+    if (!hyper_dev) return -1;
+    return clip_adam_flat_impl(n_tensors, params, grads, numel, exp_avg_flat, exp_avg_sq_flat, scratch_dev, step_dev, 0.f, 0.f, 0.f, 0.f,
+                               0.f, 0.f, out_norm_dev, hyper_dev, stream);
 }
 
 int dpn_selftest(void* scratch_dev, void* stream) {

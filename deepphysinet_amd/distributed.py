@@ -1,8 +1,15 @@
 """Data-parallel gradient synchronisation: one process per GPU, collocation batches (field samples) sharded across
-ranks, ONE averaged all-reduce of the 22.4 MB gradient set per step over RCCL/xGMI (backend "nccl" on ROCm).
+ranks, the 22.4 MB gradient set averaged over RCCL/xGMI (backend "nccl" on ROCm) once per step.
 
-Replaces the DistributedDataParallel wrap of the reference (interface/interface_physics.py:901-907); the only
-collective on the path is this gradient all-reduce.  Works with gloo on CPU for tests.
+Replaces the DistributedDataParallel wrap of the reference (interface/interface_physics.py:901-907, fired inside backward at :1056);
+the only collective on the path is this gradient all-reduce.
+
+`GradientAllReduce(optimizer)` works IN PLACE on the optimiser's flat gradient buffer (optim.FusedClipAdam / grad_arena.py): the
+buffer is cut into the optimiser's layout buckets (gradients in the order the backward pass finishes them), each bucket is one
+asynchronous all-reduce on a contiguous slice -- no flatten, no copy back -- and `reduce_bucket(i)` lets the caller start bucket i as
+soon as its segment of the backward pass has been queued, so the transfer runs under the rest of the backward (xGMI rings are per-link
+bound: few large messages, each hidden behind compute).  Without an optimiser it falls back to flattening `p.grad` of the given
+parameters (any device / backend; the CPU tests use it with gloo).
 """
 import os
 
@@ -17,7 +24,7 @@ def init_from_env(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # this pool's driver only supports dmabuf IPC (RCCL needs it)
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
@@ -26,19 +33,84 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-class GradientAllReduce:
-    """Flat-bucket gradient averaging.  `bucket_mb` caps a bucket (xGMI rings are per-link bound: a few large messages,
-    not 155 small ones); buckets are reduced asynchronously and waited on together."""
+def _all_reduce_mean(flat, world, group, async_op):
+    """Average `flat` over the group in place.  RCCL: one AVG all-reduce on the device.  gloo (CPU tests; several ranks on ONE GPU in
+    the single-GPU test box): SUM on a host copy, then the division."""
+    backend = dist.get_backend(group)
+    if backend == 'nccl':
+        return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+    if flat.is_cuda:
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host.div_(world))
+        return None
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=False)
+    flat.div_(world)
+    return None
 
-    def __init__(self, bucket_mb=32.0, group=None):
+
+class GradientAllReduce:
+    def __init__(self, optimizer=None, bucket_mb=32.0, group=None):
+        self.opt = optimizer
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
         self.group = group
+        self._work = []
+        self._checked = False
 
-    def __call__(self, params):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+    def active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    # ---- flat path (the optimiser owns the gradient buffer) ------------------------------------------------------------
+    def _check_layout(self):
+        """Every rank must reduce identically sized buckets, or the collective hangs: compare the layouts once."""
+        if self._checked:
+            return
+        bounds = [b for bb in self.opt.bucket_bounds for b in bb]
+        # a fixed-size fingerprint (an all_gather of differently sized tensors is itself a mismatched collective)
+        mine = torch.tensor([len(bounds), bounds[-1], sum((i + 1) * b for i, b in enumerate(bounds)) % (1 << 62)], dtype=torch.int64)
+        dev = self.opt.flat_gradients().device if dist.get_backend(self.group) == 'nccl' else 'cpu'
+        mine = mine.to(dev)
+        every = [torch.empty_like(mine) for _ in range(dist.get_world_size(self.group))]
+        dist.all_gather(every, mine, group=self.group)
+        if not all(torch.equal(e, mine) for e in every):
+            raise RuntimeError('GradientAllReduce: the ranks hold differently laid out gradient buffers')
+        self._checked = True
+
+    def n_buckets(self):
+        return len(self.opt.bucket_bounds)
+
+    def reduce_bucket(self, i, async_op=True):
+        """Queue the averaging all-reduce of layout bucket i (its gradients must already be queued on the current stream)."""
+        if not self.active():
+            return
+        self._check_layout()
+        a, b = self.opt.bucket_bounds[i]
+        w = _all_reduce_mean(self.opt.flat_gradients()[a:b], dist.get_world_size(self.group), self.group, async_op)
+        if w is not None and async_op:
+            self._work.append(w)
+
+    def wait(self):
+        """The current stream waits for every queued bucket."""
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+    # ---- entry point ---------------------------------------------------------------------------------------------------
+    def __call__(self, params=None):
+        """Average the gradients over the ranks.  With an optimiser: gather stray gradients into the flat buffer (a rank whose backward
+        produced no gradient for a parameter contributes zeros), reduce every bucket, wait."""
+        if not self.active():
+            return
+        if self.opt is not None:
+            self.opt.gather_gradients(zero_missing=True)
+            for i in range(self.n_buckets()):
+                self.reduce_bucket(i)
+            self.wait()
             return
         world = dist.get_world_size(self.group)
-        grads = [p.grad for p in params if p.grad is not None]
+        params = list(params)
+        # generic path: every rank flattens the same parameter list (None gradients count as zeros, so the sizes agree)
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
         buckets, cur, size = [], [], 0
         for g in grads:
             nb = g.numel() * g.element_size()
@@ -49,27 +121,30 @@ class GradientAllReduce:
             size += nb
         if cur:
             buckets.append(cur)
-        work = []
         for b in buckets:
-            flat = torch.cat([g.reshape(-1) for g in b])                # one launch per bucket
-            work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, b))
-        for w, flat, b in work:
-            w.wait()
-            flat.div_(world)
-            views, off = [], 0
+            flat = torch.cat([g.reshape(-1) for g in b])
+            _all_reduce_mean(flat, world, self.group, False)
+            off = 0
             for g in b:
-                n = g.numel()
-                views.append(flat[off:off + n].view_as(g))
-                off += n
-            torch._foreach_copy_(b, views)                              # multi-tensor copy back: a few launches, not one per tensor
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        for p, g in zip(params, grads):
+            if p.grad is None:
+                p.grad = g
 
 
 def broadcast_parameters(module, src=0, group=None):
     """Make every rank start from rank `src`'s parameters (DDP does this at wrap time)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    stage = dist.get_backend(group) != 'nccl'
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if stage and t.is_cuda:
+            host = t.data.cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src=src, group=group)
 
 
 def shard_range(n_items, rank, world):

@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
+from .grad_arena import new_grad
 
 
 def _p(t):
@@ -76,7 +77,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         L.check(lib.dpn_add_ln_fwd(_p(x2), _p(r2), _p(gamma), _p(beta), rows, _p(out), _p(xhat), _p(rstd), _s()), 'dpn_add_ln_fwd')
         ctx.save_for_backward(xhat, rstd, gamma)
-        ctx.has_r, ctx.shape = r is not None, shape
+        ctx.has_r, ctx.shape, ctx.beta = r is not None, shape, beta
         return out.view(shape)
 
     @staticmethod
@@ -85,8 +86,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         xhat, rstd, gamma = ctx.saved_tensors
         g2 = _c(g.reshape(-1, 256))
         gx = torch.empty_like(g2)
-        dgamma = torch.empty(256, dtype=torch.float32, device=g.device)
-        dbeta = torch.empty(256, dtype=torch.float32, device=g.device)
+        dgamma, dbeta = new_grad(gamma), new_grad(ctx.beta)
         scratch = torch.empty(((g2.shape[0] + 3) // 4) * 512, dtype=torch.float32, device=g.device)
         L.check(lib.dpn_add_ln_bwd(_p(g2), _p(xhat), _p(rstd), _p(gamma), g2.shape[0], _p(gx), _p(dgamma), _p(dbeta), _p(scratch), _s()),
                 'dpn_add_ln_bwd')
@@ -167,6 +167,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         L.check(lib.dpn_add_ln_fwd(_p(x1), _p(y), _p(g2), _p(be2), n, _p(out), _p(xhat2), _p(rstd2), _s()), 'dpn_add_ln_fwd')
         ctx.save_for_backward(x, q, k, v, o, P, x1, pre, act, xhat1, rstd1, xhat2, rstd2, wq, wk, wv, wo, wc1, wc2, g1, g2)
         ctx.B, ctx.Lt = B, Lt
+        ctx.biases = (bq, bk, bv, bo, be1, bc1, bc2, be2)            # identify the gradient slots of the bias parameters (grad_arena)
         return out
 
     @staticmethod
@@ -181,25 +182,26 @@ class _EncoderLayerFn(torch.autograd.Function):
         nb = (n + 31) // 32                                       # row blocks of the LayerNorm-in-GEMM launches (their partial sums)
         scratch2, scratch1 = new(nb * 512), new(nb * 512)
         # LN2 backward is applied by the conv2 input-gradient GEMM to its own A tile: d(pre) = (gs2 W_c2) * gelu'(pre); gs2 kept
-        gs2, dg2, dbe2 = new(n, D), new(D), new(D)
+        bq, bk, bv, bo, be1, bc1, bc2, be2 = ctx.biases
+        gs2, dg2, dbe2 = new(n, D), new_grad(g2), new_grad(be2)
         dpre = new(n, Fh)
         _launch_ln(2, n, Fh, _c(g), xhat2, g2, None, rstd2, gs2, None, None, scratch2, wc2, 0, Fh, dpre, Fh, epi=L.EPI_MUL_GELU_GRAD, aux=pre)
         # conv1: d(x1) = dpre W_c1 + gs2 (the residual branch); with it dW_c2 = gs2^T act, dW_c1 = dpre^T x1 and LN2's parameter sums
-        dwc2, dbc2 = new(D, Fh), new(D)
-        dx1, dwc1, dbc1 = new(n, D), new(Fh, D), new(Fh)
+        dwc2, dbc2 = new_grad(wc2, (D, Fh)), new_grad(bc2)
+        dx1, dwc1, dbc1 = new(n, D), new_grad(wc1, (Fh, D)), new_grad(bc1)
         batch = [_problem(n, D, Fh, [(dpre, Fh, wc1, D)], dx1, D, 0, 0, epi=L.EPI_ADD, aux=gs2)]
         _wgrad(batch, D, Fh, n, gs2, D, act, Fh, dwc2, dbc2)
         _wgrad(batch, Fh, D, n, dpre, Fh, x1, D, dwc1, dbc1)
         _launch(batch, colsum_jobs=[(scratch2, n, dg2, dbe2, nb)])
         # LN1 backward is applied by the out-projection input-gradient GEMM: d(o) = gs1 W_o; gs1 kept
-        gs1, dg1, dbe1 = new(n, D), new(D), new(D)
-        do, dwo, dbo = new(n, D), new(D, D), new(D)
+        gs1, dg1, dbe1 = new(n, D), new_grad(g1), new_grad(be1)
+        do, dwo, dbo = new(n, D), new_grad(wo), new_grad(bo)
         _launch_ln(2, n, D, dx1, xhat1, g1, None, rstd1, gs1, None, None, scratch1, wo, 0, D, do, D)
         # attention
         dq, dk, dv = new(n, D), new(n, D), new(n, D)
         L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(do), ctx.Lt, ctx.B, _p(dq), _p(dk), _p(dv), _s()), 'dpn_attn_bwd')
         # q/k/v projections: dx = dq Wq + dk Wk + dv Wv + gs1 (the residual branch)
-        dx, dwq, dwk, dwv, dbq, dbk, dbv = new(n, D), new(D, D), new(D, D), new(D, D), new(D), new(D), new(D)
+        dx, dwq, dwk, dwv, dbq, dbk, dbv = new(n, D), new_grad(wq), new_grad(wk), new_grad(wv), new_grad(bq), new_grad(bk), new_grad(bv)
         batch = [_problem(n, D, D, [(dq, D, wq, D), (dk, D, wk, D), (dv, D, wv, D)], dx, D, 0, 0, epi=L.EPI_ADD, aux=gs1)]
         for gq, gw, gb in ((dq, dwq, dbq), (dk, dwk, dbk), (dv, dwv, dbv)):
             _wgrad(batch, D, D, n, gq, D, x, D, gw, gb)
@@ -274,6 +276,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
                 'dpn_embed_assemble')
         ctx.save_for_backward(xu)
         ctx.n_tok, ctx.w_shape, ctx.tok_shape, ctx.B = n_tok, conv_w.shape, token.shape, B
+        ctx.params = (conv_w, conv_b)
         return out
 
     @staticmethod
@@ -283,8 +286,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
         D, B = ctx.w_shape[0], ctx.B
         g3 = g.reshape(B, -1, D)
         g_emb = _c(g3[:, ctx.n_tok:]).reshape(n, D)              # one field: a contiguous row range (no copy)
-        dw = torch.empty((D, K3), dtype=torch.float32, device=g.device)
-        db = torch.empty((D,), dtype=torch.float32, device=g.device)
+        dw, db = new_grad(ctx.params[0], (D, K3)), new_grad(ctx.params[1])
         batch = []
         _wgrad(batch, D, K3, n, g_emb, D, xu, K3, dw, db)
         if batch:
@@ -345,6 +347,7 @@ class _HeadsFn(torch.autograd.Function):
                 problems.append(q)
             _launch(problems)
         ctx.save_for_backward(m3, pe2, *hw)
+        ctx.params = (hb, fw, fb)                                    # identify the gradient slots (grad_arena); fw: the contiguous weights
         return heads, evec
 
     @staticmethod
@@ -360,16 +363,24 @@ class _HeadsFn(torch.autograd.Function):
         for w in hw:
             offs.append(off)
             off += w.shape[0]
-        # parameter gradients of every field side by side: [B][flat], flat = 12 weights, 12 biases, 6 fore_h_fc weights
-        sizes = [w.shape[0] * 256 for w in hw] + [w.shape[0] for w in hw] + [256 * 192] * 6
-        starts = [0]
-        for sz in sizes:
-            starts.append(starts[-1] + sz)
-        flat = torch.empty((B, starts[-1]), dtype=torch.float32, device=dev)
+        # destinations of the 36 parameter gradients (12 head weights, 12 head biases, 6 fore_h_fc weights, 6 fore_h_fc biases).
+        # One field: the parameters' own gradient tensors (slots of the optimiser's flat gradient buffer when one is registered,
+        # grad_arena).  B fields: side by side in [B][flat], added in a fixed order by one dpn_sum_parts.
+        hb, fw, fb = ctx.params
+        shapes = [(w.shape[0], 256) for w in hw] + [(w.shape[0],) for w in hw] + [(256, 192)] * 6 + [(256,)] * 6
+        if B == 1:
+            dest = [new_grad(t, shp) for t, shp in zip(list(hw) + list(hb) + list(fw) + list(fb), shapes)]
+            ptrs = [[d.data_ptr() for d in dest]]
+        else:
+            starts = [0]
+            for shp in shapes:
+                starts.append(starts[-1] + int(torch.Size(shp).numel()))
+            flat = torch.empty((B, starts[-1]), dtype=torch.float32, device=dev)
+            ptrs = [[flat.data_ptr() + (f * starts[-1] + starts[i]) * 4 for i in range(36)] for f in range(B)]
         parts = torch.empty((4, 256, 256), dtype=torch.float32, device=dev)
         n_tail = (Lt - 256) * 256                                # tokens >= 256 feed no VariableNet: their gradient rows are zero
         for f in range(B):
-            g_ptr, m_ptr, base = gh.data_ptr() + f * 256 * HEADS_COLS * 4, m3.data_ptr() + f * Lt * 256 * 4, flat.data_ptr() + f * starts[-1] * 4
+            g_ptr, m_ptr = gh.data_ptr() + f * 256 * HEADS_COLS * 4, m3.data_ptr() + f * Lt * 256 * 4
             # d_meta[tok][c] = sum_k sum_j W_k[j][tok] g[c][off_k + j]: a 12-term problem would walk 24 k-tiles in sequence, so four
             # 3-term problems run side by side and dpn_sum_parts joins them
             problems = []
@@ -382,23 +393,17 @@ class _HeadsFn(torch.autograd.Function):
                 problems.append(q0)
             for k, w in enumerate(hw):                           # dW_k[j][tok] = sum_c g[c][off + j] meta[tok][c] ; db_k[j] = sum_c g[c][off + j]
                 n_k = w.shape[0]
-                q = _problem(n_k, 256, 256, [(gh, HEADS_COLS, m3, 256)], flat, 256, 1, 1, asum=flat)
-                q.A[0], q.B[0], q.C, q.asum = g_ptr + offs[k] * 4, m_ptr, base + starts[k] * 4, base + starts[12 + k] * 4
+                q = _problem(n_k, 256, 256, [(gh, HEADS_COLS, m3, 256)], parts, 256, 1, 1, asum=parts)
+                q.A[0], q.B[0], q.C, q.asum = g_ptr + offs[k] * 4, m_ptr, ptrs[f][k], ptrs[f][12 + k]
                 problems.append(q)
-            for k in range(6):                                   # d fore_h_fc_k.weight = g_evec[k] (outer) pe_h ; bias gradient = g_evec[k]
-                q = _problem(256, 192, 1, [(ge, 256, pe2, 192)], flat, 192, 1, 0)
-                q.A[0], q.B[0], q.C = ge.data_ptr() + (f * 6 + k) * 256 * 4, pe2.data_ptr() + f * 192 * 4, base + starts[24 + k] * 4
+            for k in range(6):                                   # d fore_h_fc_k.weight = g_evec[k] (outer) pe_h ; its bias gradient = g_evec[k]
+                q = _problem(256, 192, 1, [(ge, 256, pe2, 192)], parts, 192, 1, 0, asum=parts)       # = the "row sums" over the K = 1 reduction
+                q.A[0], q.B[0], q.C, q.asum = ge.data_ptr() + (f * 6 + k) * 256 * 4, pe2.data_ptr() + f * 192 * 4, ptrs[f][24 + k], ptrs[f][30 + k]
                 problems.append(q)
             _launch(problems)
             L.check(lib.dpn_sum_parts(_p(parts), 4, 256 * 256, n_tail, ctypes.c_void_p(d_meta.data_ptr() + f * Lt * 256 * 4), _s()), 'dpn_sum_parts')
         if B > 1:
             total = torch.empty(starts[-1], dtype=torch.float32, device=dev)
             L.check(lib.dpn_sum_parts(_p(flat), B, starts[-1], 0, _p(total), _s()), 'dpn_sum_parts')
-            dfb = [ge[:, k].sum(dim=0) for k in range(6)]
-        else:
-            total = flat[0]
-            dfb = [ge[0, k] for k in range(6)]
-        dws = [total[starts[k]:starts[k + 1]].view(hw[k].shape[0], 256) for k in range(12)]
-        dbs = [total[starts[12 + k]:starts[13 + k]] for k in range(12)]
-        dfw = [total[starts[24 + k]:starts[25 + k]].view(256, 192) for k in range(6)]
-        return (d_meta, None, *dws, *dbs, *dfw, *dfb)
+            dest = [total[starts[i]:starts[i + 1]].view(shapes[i]) for i in range(36)]
+        return (d_meta, None, *dest)

@@ -1,0 +1,56 @@
+"""Flat gradient arena: every parameter gradient of a PhysicsNet lives in ONE fp32 buffer, laid out like the optimiser's flat moment
+buffers (optim.FusedClipAdam), so that the data-parallel gradient all-reduce (reference: the DistributedDataParallel wrap,
+interface/interface_physics.py:901-907, fired inside backward at :1056) runs in place on contiguous bucket slices and the fused
+clip + Adam kernels read the same memory -- no flatten / copy-back passes on the critical path.
+
+The autograd nodes of this package (point_path, encoder_ops, linear) allocate their parameter-gradient outputs with `new_grad(param)`:
+a view of the parameter's slot when an arena is registered for it, an ordinary tensor otherwise.  Autograd then stores that view as
+`param.grad` (AccumulateGrad steals a dense, uniquely referenced gradient instead of copying it).
+
+A slot is LEASED when handed out and stays so until its owner's `zero_grad(set_to_none=True)` has dropped every `param.grad`: a second
+gradient for the same parameter inside one accumulation window (the parameter used by two autograd nodes, or a second backward without
+zero_grad) gets an ordinary tensor and is added by autograd as usual -- writing it into the slot would overwrite the first one.  Like
+DistributedDataParallel(gradient_as_bucket_view=True), a gradient tensor kept by the caller across zero_grad is overwritten by the next
+backward pass."""
+import weakref
+
+import torch
+
+param_epoch = [0]     # bumped by every fused optimiser step (parameters rewritten through raw pointers: no tensor version changes)
+_slots = {}          # param data_ptr -> (weakref(owner), weakref(param), offset, numel)
+
+
+def register(owner, params, offsets):
+    """`owner` holds the flat buffer as `owner._g_flat`; parameter i owns [offsets[i], offsets[i] + numel)."""
+    o = weakref.ref(owner)
+    for p, off in zip(params, offsets):
+        _slots[p.data_ptr()] = (o, weakref.ref(p), int(off), p.numel())
+
+
+def unregister(owner):
+    for k in [k for k, v in _slots.items() if v[0]() is owner or v[0]() is None]:
+        del _slots[k]
+
+
+def slot_of(t, lease=True):
+    """The arena view for the parameter whose storage `t` aliases (same data pointer, same numel), or None (no arena / already leased)."""
+    e = _slots.get(t.data_ptr())
+    if e is None:
+        return None
+    owner, pref, off, n = e[0](), e[1](), e[2], e[3]
+    if owner is None or pref is None or pref.data_ptr() != t.data_ptr() or n != t.numel() or owner._g_flat.device != t.device:
+        return None
+    if lease:
+        if off in owner._leased:
+            return None
+        owner._leased.add(off)
+    return owner._g_flat[off:off + n]
+
+
+def new_grad(param_like, shape=None):
+    """Gradient destination for the parameter aliased by `param_like`: its arena slot (viewed as `shape`) or a fresh tensor."""
+    shape = tuple(param_like.shape) if shape is None else tuple(shape)
+    s = slot_of(param_like)
+    if s is not None:
+        return s.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=param_like.device)

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
+from .grad_arena import new_grad
 
 
 def _p(t):
@@ -90,6 +91,7 @@ class _MultiLinearFn(torch.autograd.Function):
             _launch([_problem(M, w.shape[0], K, [(x2, K, w, K)], y, w.shape[0], 0, 1, bias=b) for w, b, y in zip(ws, bs, ys)])
         ctx.save_for_backward(x2, *ws)
         ctx.n, ctx.has_bias, ctx.x_shape = n, [b is not None for b in bs], x.shape
+        ctx.biases = bs                                  # identify the bias parameters' gradient slots (grad_arena)
         return tuple(y.reshape(x.shape[:-1] + (y.shape[1],)) for y in ys)
 
     @staticmethod
@@ -116,8 +118,8 @@ class _MultiLinearFn(torch.autograd.Function):
         gws, gbs = [], []
         for i, (g, w) in enumerate(zip(gs, ws)):
             N = w.shape[0]
-            gw = torch.empty((N, K), dtype=torch.float32, device=dev)
-            gb = torch.empty((N,), dtype=torch.float32, device=dev) if ctx.has_bias[i] else None
+            gw = new_grad(w, (N, K))
+            gb = new_grad(ctx.biases[i], (N,)) if ctx.has_bias[i] else None
             _wgrad(problems, N, K, M, g, N, x2, K, gw, gb)             # gw = g^T x ; gb = sum_m g (split-K kernel when M is a batch of fields)
             gws.append(gw)
             gbs.append(gb)

@@ -3,6 +3,7 @@
 import torch
 import torch.nn as nn
 
+from .. import grad_arena
 from ..linear import linear
 from .meta_net import MetaNet
 from .variable_net import VariableNet
@@ -34,30 +35,37 @@ class PhysicsNet(nn.Module):
     def nets_in_output_order(self):
         return [getattr(self, n) for n in OUTPUT_ORDER]
 
+    def _cache_key(self, field_x, forecast_h):
+        # the parameters are part of the key: an optimiser step between two calls (torch optimisers bump `_version`; the fused HIP
+        # optimiser writes through raw pointers and bumps grad_arena.param_epoch instead) must not return the previous encoder output
+        pv = sum(p._version for p in self.meta_net.parameters())
+        return (field_x.data_ptr(), field_x._version, forecast_h.data_ptr(), forecast_h._version, torch.is_grad_enabled(), pv,
+                grad_arena.param_epoch[0])
+
     def encode_field(self, field_x, forecast_h, use_cache=False):
         """MetaNet output [1,287,256].  With use_cache the result is reused while (field, lead time, parameters) are unchanged
-        inside one training step (the reference recomputes it three times per step with identical inputs)."""
-        if use_cache and self._meta_cache is not None:
-            key, val = self._meta_cache
-            if key == (field_x.data_ptr(), field_x._version, forecast_h.data_ptr(), forecast_h._version, torch.is_grad_enabled()):
-                return val
+        inside one training step (the reference recomputes it three times per step with identical inputs).  A cached output carries the
+        autograd graph of the call that made it: it serves ONE backward pass (step-scoped; training_step clears it)."""
+        key = self._cache_key(field_x, forecast_h) if use_cache else None
+        if use_cache and self._meta_cache is not None and self._meta_cache[0] == key:
+            return self._meta_cache[1]
         val = self.meta_net(field_x, forecast_h)
         if use_cache:
-            self._meta_cache = ((field_x.data_ptr(), field_x._version, forecast_h.data_ptr(), forecast_h._version,
-                                 torch.is_grad_enabled()), val)
+            self._meta_cache = (key, val)
         return val
 
     def clear_field_cache(self):
         self._meta_cache = None
 
-    def field_weights(self, field_x, forecast_h, use_cache=False):
+    def field_weights(self, field_x, forecast_h, use_cache=False, meta_out=None):
         """Everything the point kernels need for one field sample: (heads [256, 2700], evec [6,256], statics[48]); for a batch of B > 1
         field samples (field_x [B,159,2405], forecast_h [B,1,1]) heads and evec get a leading B.
 
         The twelve hyper-network heads (coord_input_fc / coord_hidden_fc of the six nets, variable_net.py:59-65) share their
         input, so they run as ONE GEMM whose output rows are [w1b1_0..5 | w2b2_0..5]; the six lead-time embeddings
         (variable_net.py:75-78) are one GEMV batch."""
-        meta_out = self.encode_field(field_x, forecast_h, use_cache=use_cache)
+        if meta_out is None:
+            meta_out = self.encode_field(field_x, forecast_h, use_cache=use_cache)
         nets = self.nets_in_output_order()
         if meta_out.is_cuda:
             from ..encoder_ops import _HeadsFn, lead_time_pe
@@ -80,6 +88,19 @@ class PhysicsNet(nn.Module):
             evec = linear(pe_h, wf, bf).view(6, 256)
         statics = [p for n in nets for p in n.static_params()]
         return heads, evec, statics
+
+    def gradient_buckets(self):
+        """The parameters grouped by when the backward pass finishes their gradients: [the 48 tensors the point kernels read directly
+        (ready after the point backward), the hyper-network heads + lead-time embeddings (after _HeadsFn.backward), the encoder].
+        optim.FusedClipAdam(layout=...) lays its flat gradient buffer out in this order and distributed.GradientAllReduce reduces
+        bucket after bucket while the rest of the backward pass runs."""
+        nets = self.nets_in_output_order()
+        statics = [p for n in nets for p in n.static_params()]
+        heads = [p for n in nets for p in (n.coord_input_fc.weight, n.coord_input_fc.bias, n.coord_hidden_fc.weight, n.coord_hidden_fc.bias,
+                                           n.fore_h_fc.weight, n.fore_h_fc.bias)]
+        seen = {id(p) for p in statics + heads}
+        rest = [p for p in self.parameters() if id(p) not in seen]
+        return [statics, heads, rest]
 
     def _cfg(self):
         from ..point_path import PointConfig

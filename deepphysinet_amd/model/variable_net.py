@@ -13,14 +13,17 @@ from ..utils.position_encoding import SineCosPE
 
 
 class ResMLP(nn.Module):
-    """fc.0 -> ReLU -> fc.2, plus the input (variable_net.py:13-24).  Parameter container; the arithmetic is in HIP."""
+    """fc.0 -> ReLU -> fc.2, plus the input (variable_net.py:13-24).  Inside a VariableNet the arithmetic happens in the fused HIP point
+    kernels (which read these parameters directly); called on its own it is the reference's per-row expression on the library's
+    fp32 GEMMs."""
 
     def __init__(self, in_channels):
         super().__init__()
         self.fc = nn.Sequential(nn.Linear(in_channels, in_channels), nn.ReLU(inplace=True), nn.Linear(in_channels, in_channels))
 
     def forward(self, x):
-        raise RuntimeError('ResMLP is evaluated inside the fused HIP point kernels; call PhysicsNet / VariableNet instead')
+        from ..linear import linear
+        return linear(torch.relu(linear(x, self.fc[0].weight, self.fc[0].bias)), self.fc[2].weight, self.fc[2].bias) + x
 
 
 class VariableNet(nn.Module):

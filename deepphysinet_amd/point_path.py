@@ -16,6 +16,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
+from .grad_arena import new_grad
 
 # configs/DeepPhysiNet_NCEP_cfg.py:64-76 -- order u10, v10, pres, t2, q2, rio (network output order)
 OBS_ORDER = ('u10', 'v10', 'pres', 't2', 'q2', 'rio')
@@ -157,12 +158,30 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
     if into is None:
         g_heads = torch.empty((256, HEADS_COLS), dtype=torch.float32, device=dev)
         g_evec = torch.empty((6, 256), dtype=torch.float32, device=dev)
-        g_stat = [torch.empty(STATIC_SHAPES[j], dtype=torch.float32, device=dev) for _ in range(6) for j in range(8)]
+        # the 48 static parameters' gradients go straight into the optimiser's flat gradient buffer when one is registered (grad_arena)
+        # (not when one tensor fills several slots -- VariableNet.forward standalone -- whose gradients must stay separate tensors)
+        arena = len({s.data_ptr() for s in statics}) == len(statics)
+        g_stat = [new_grad(statics[k * 8 + j], STATIC_SHAPES[j]) if arena else torch.empty(STATIC_SHAPES[j], dtype=torch.float32, device=dev)
+                  for k in range(6) for j in range(8)]
     else:
         g_heads, g_evec, g_stat = into
     garr = _net_ptrs(g_heads, g_evec, g_stat, cls=L.DpnNetGradPtrs)
     L.check(lib.dpn_wgrad_finish(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, _stream()), 'dpn_wgrad_finish')
     return g_heads, g_evec, g_stat
+
+
+def _stamp(tensors):
+    """Version counters of the tensors a backward pass will read again through raw pointers (the point path keeps them in ctx.keep, not in
+    save_for_backward: most are detached fp32 views).  _check_stamp raises when one was modified in place between forward and backward
+    (e.g. an optimiser step before a delayed backward), which autograd's own check would catch for saved tensors."""
+    return tuple((t, t._version) for t in tensors if t is not None)
+
+
+def _check_stamp(stamp, what):
+    for t, v in stamp:
+        if t._version != v:
+            raise RuntimeError('deepphysinet_amd %s: a tensor of shape %s needed by the backward pass was modified in place after the '
+                               'forward pass (version %d -> %d)' % (what, tuple(t.shape), v, t._version))
 
 
 class _NoSecondOrder(torch.autograd.Function):
@@ -199,10 +218,12 @@ class _PointFieldsFn(torch.autograd.Function):
         out_n, gpe = _forward_points(cfg, ws, nets, x_, y_, t_, pe_, cd_, want_jac=want_gpe, want_saved=need_grad)
         ctx.cfg, ctx.ws, ctx.gpe = cfg, ws, gpe
         ctx.keep = (x_, y_, t_, pe_, cd_, hd_, ev_, st)
+        ctx.stamp = _stamp((heads, evec) + tuple(statics))
         return out_n
 
     @staticmethod
     def backward(ctx, g_out):
+        _check_stamp(ctx.stamp, 'point_fields')
         x_, y_, t_, pe_, cd_, hd_, ev_, st = ctx.keep
         g = _f32c(g_out)
         g_pe = None
@@ -243,6 +264,7 @@ class _PdeLossFn(torch.autograd.Function):
         L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses7), _stream()), 'dpn_residual_finish')
         ctx.cfg, ctx.ws = cfg, ws
         ctx.keep = (x_, y_, t_, f_, cd_, hd_, ev_, st, out_n, jac_n)
+        ctx.stamp = _stamp((heads, evec) + tuple(statics))
         ctx.set_materialize_grads(False)
         return losses7[:6], losses7[6]
 
@@ -250,6 +272,7 @@ class _PdeLossFn(torch.autograd.Function):
     def backward(ctx, g_losses, g_total):
         lib = L.load()
         cfg = ctx.cfg
+        _check_stamp(ctx.stamp, 'pde_losses')
         x_, y_, t_, f_, cd_, hd_, ev_, st, out_n, jac_n = ctx.keep
         n = cd_.shape[0]
         dev = cd_.device
@@ -298,6 +321,7 @@ class _PdeLossBatchFn(torch.autograd.Function):
             fields.append((ws, out_n, jac_n))
         ctx.cfg, ctx.fields = cfg, fields
         ctx.keep = (x_, y_, t_, f_, cd_, hd_, ev_, st)
+        ctx.stamp = _stamp((heads, evec) + tuple(statics))
         ctx.set_materialize_grads(False)
         return losses7[:, :6], losses7[:, 6]
 
@@ -305,11 +329,15 @@ class _PdeLossBatchFn(torch.autograd.Function):
     def backward(ctx, g_losses, g_total):
         lib = L.load()
         cfg = ctx.cfg
+        _check_stamp(ctx.stamp, 'pde_losses_batch')
         x_, y_, t_, f_, cd_, hd_, ev_, st = ctx.keep
         B, n = cd_.shape[0], cd_.shape[1]
         dev = cd_.device
         if g_losses is None and g_total is None:
             return (None,) * (8 + len(st))
+        if any(fld is None for fld in ctx.fields):
+            raise RuntimeError('deepphysinet_amd pde_losses_batch: the per-field state saved by the forward pass is released as the backward '
+                               'pass consumes it (23 GB at 61 fields); run the forward pass again instead of a second backward')
         gl = None if g_losses is None else _f32c(g_losses)
         gt = None if g_total is None else _f32c(g_total)
         g_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
@@ -371,6 +399,7 @@ class _StepLossFn(torch.autograd.Function):
         data = (dsum.sum() / (6.0 * n_m)).float() * margin_factor
         ctx.cfg, ctx.ws, ctx.n_inter, ctx.beta, ctx.margin_factor = cfg, ws, n_inter, beta, margin_factor
         ctx.keep = (x_, y_, t_, f_, cd_, lab_, hd_, ev_, st, out_n, jac_n)
+        ctx.stamp = _stamp((heads, evec) + tuple(statics))
         ctx.set_materialize_grads(False)
         return losses[0, :6], losses[0, 6], losses[1, :6], losses[1, 6], data
 
@@ -378,6 +407,7 @@ class _StepLossFn(torch.autograd.Function):
     def backward(ctx, g_la, g_ta, g_lb, g_tb, g_data):
         lib = L.load()
         cfg, n_inter = ctx.cfg, ctx.n_inter
+        _check_stamp(ctx.stamp, 'step_losses')
         x_, y_, t_, f_, cd_, lab_, hd_, ev_, st, out_n, jac_n = ctx.keep
         n = cd_.shape[0]
         n_m = n - n_inter

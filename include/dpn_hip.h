@@ -270,6 +270,14 @@ int dpn_clip_adam_flat(int n_tensors, float* const* params, const float* const* 
                        float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, float lr, float beta1, float beta2, float eps,
                        float weight_decay, float max_norm, float* out_norm_dev, void* stream);
 
+/* The same with the hyper-parameters read from DEVICE memory at run time: hyper_dev[7] = {lr, beta1, beta2, eps, weight_decay, max_norm,
+ * grad_scale}.  A step captured in a hipGraph then follows a learning-rate schedule (CosineAnnealingLR stepped per epoch,
+ * interface_physics.py:831-833) -- the host rewrites hyper_dev[0] between replays; grad_scale multiplies every gradient before the norm and
+ * the update (1 / world_size behind a SUM all-reduce of the flat gradient buffer, replacing DistributedDataParallel's averaging, :903-907). */
+int dpn_clip_adam_flat_dev(int n_tensors, float* const* params, const float* const* grads, const int64_t* numel, float* exp_avg_flat,
+                           float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, const float* hyper_dev, float* out_norm_dev,
+                           void* stream);
+
 /* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
 int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);
 

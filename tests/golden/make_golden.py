@@ -81,8 +81,34 @@ def write_f10(m, run_pde):
     np.savez_compressed(os.path.join(HERE, 'f10_grid_nodes_h336_fp32.npz'), x=inp['x'].numpy(), y=inp['y'].numpy(), **rec)
 
 
+def write_f11():
+    """F11: get_coriolis (dataset/physics_dataset.py:521-526) called on the reference class itself (it never touches `self`): the
+    latitude forms its two callers build -- margin points `begin_lat + y_rand * 0.25` with integer node indices (:336-337, :418) and
+    interior points with continuous draws (:444-445, :496) -- 1-D (expanded to [n,1]) and already 2-D; pins the f column of the
+    on-device collocation sampler (the interpolation itself stays scipy-pinned: xarray is absent)."""
+    _stub_third_party()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from DeepPhysiNet.dataset.physics_dataset import PhysicsDataset
+    from oracle.fill import unit_uniform
+    y_nodes = np.arange(145, dtype=np.int64)
+    lat_nodes = 18.0 + y_nodes * 0.25
+    y_cont = (unit_uniform('f11.y', 512).astype(np.float64) + 1.0) * 0.5 * 144.0
+    lat_cont = 18.0 + y_cont * 0.25
+    f_nodes = PhysicsDataset.get_coriolis(None, lat_nodes)
+    f_cont = PhysicsDataset.get_coriolis(None, lat_cont)
+    f_2d = PhysicsDataset.get_coriolis(None, lat_cont[:7].reshape(7, 1))
+    assert f_nodes.shape == (145, 1) and f_cont.shape == (512, 1) and f_2d.shape == (7, 1)
+    np.savez_compressed(os.path.join(HERE, 'f11_coriolis.npz'), y_nodes=y_nodes, lat_nodes=lat_nodes, f_nodes=f_nodes,
+                        f_nodes_f32=torch.from_numpy(f_nodes).float().numpy(), y_cont=y_cont, lat_cont=lat_cont, f_cont=f_cont,
+                        f_cont_f32=torch.from_numpy(f_cont).float().numpy(), f_2d=f_2d)
+
+
 def main():
     from oracle.fill import fill_state_dict_, synthetic_inputs
+    if '--only-f11' in sys.argv:
+        write_f11()
+        return
     only_f10 = '--only-f10' in sys.argv
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -241,6 +267,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, 'f9_wide_clip%d_fp32.npz' % int(wc)), **rec)
     net.load_state_dict(sd0)
     write_f10(m, run_pde)
+    write_f11()
     print('golden vectors written to', HERE)
     for fn_ in sorted(os.listdir(HERE)):
         if fn_.endswith('.npz'):

@@ -63,6 +63,109 @@ def test_gradient_allreduce_equals_union_batch():
     assert torch.allclose(g_a, ref, rtol=1e-5, atol=1e-7)
 
 
+class _FlatOwner:
+    """CPU stand-in for optim.FusedClipAdam's gradient side: one flat buffer, bucket bounds, gather (the real one needs a GPU)."""
+
+    def __init__(self, params, bucket_sizes):
+        self.params = params
+        self._g_flat = torch.zeros(sum(p.numel() for p in params))
+        self._slots, off = [], 0
+        for p in params:
+            self._slots.append(self._g_flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.bucket_bounds, a, k = [], 0, 0
+        for nb in bucket_sizes:
+            b = a + sum(p.numel() for p in params[k:k + nb])
+            self.bucket_bounds.append((a, b))
+            a, k = b, k + nb
+
+    def flat_gradients(self):
+        return self._g_flat
+
+    def gather_gradients(self, zero_missing=False):
+        for p, s in zip(self.params, self._slots):
+            if p.grad is None:
+                assert zero_missing
+                s.zero_()
+            elif p.grad.data_ptr() != s.data_ptr():
+                s.copy_(p.grad)
+            p.grad = s
+
+
+def _worker_flat(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(5)
+    lin = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    params = list(lin.parameters())
+    owner = _FlatOwner(params, [2, 3, 1])
+    sync = GradientAllReduce(owner)
+    torch.manual_seed(50 + rank)
+    x = torch.randn(6, 7)
+    # rank 1 never uses the last layer: its gradients are None there -- the flat buckets still have the same size on every rank
+    out = lin(x) if rank == 0 else lin[1](lin[0](x))
+    out.pow(2).mean().backward()
+    mine = [None if p.grad is None else p.grad.clone() for p in params]
+    sync()                                                       # gather (zeros for the missing ones) + three bucket all-reduces + wait
+    assert all(p.grad.data_ptr() == s.data_ptr() for p, s in zip(params, owner._slots))
+    q.put((rank, [None if g is None else g.tolist() for g in mine], [p.grad.tolist() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_with_uneven_gradient_sets():
+    """The in-place bucketed reducer on a flat gradient buffer: ranks whose sets of p.grad None / non-None differ must not hang
+     and get the mean with zeros for the missing gradients, like DistributedDataParallel(find_unused_parameters)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flat, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, own0, red0), (_, own1, red1) = out
+    assert own1[4] is None and own1[5] is None and own0[4] is not None
+    for i in range(6):
+        a = torch.tensor(own0[i])
+        b = torch.zeros_like(a) if own1[i] is None else torch.tensor(own1[i])
+        want = (a + b) / 2
+        assert torch.equal(torch.tensor(red0[i]), torch.tensor(red1[i]))
+        assert torch.allclose(torch.tensor(red0[i]), want, rtol=1e-6, atol=1e-8)
+
+
+def _worker_mismatch(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    params = [torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(6))]
+    owner = _FlatOwner(params, [1, 1] if rank == 0 else [2])          # differently cut buffers
+    for p in params:
+        p.grad = torch.ones_like(p)
+    try:
+        GradientAllReduce(owner)()
+        q.put((rank, 'no error'))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_refuses_mismatched_layouts():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mismatch, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all('differently laid out' in msg for _, msg in out), out
+
+
 def test_shard_range_partitions():
     for n in (1, 7, 61, 37265):
         for world in (1, 2, 4, 8):

@@ -674,3 +674,73 @@ def test_reference_equation_methods_on_hip_module_outputs():
     assert np.all(rel <= 5e-4), (got, ref['parts'], rel)      # first derivatives through torch's fp32 sin/cos chain + bf16x2 kernel
     with pytest.raises(RuntimeError):
         losses[0].backward()                                   # second-order through the standalone methods: refused loudly
+
+
+def test_full_grid_all_gradients_vs_oracle():
+    """configs[1] at FULL size (37 265 points, the bench workload and its default-initialised weights): the oracle's six losses and all
+    155 parameter gradients on every point (gradients had only been oracle-checked up to 5 197 points).  Bars as in
+    test_fields_jacobian_losses_gradients_vs_oracle for batches of hundreds of points and more."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synth_batch
+    from deepphysinet_amd.configs import ncep_config
+    from deepphysinet_amd.interface import builder_models
+    tol = TOL['bf16x2']
+    n = 257 * 145
+    torch.manual_seed(1)
+    m = builder_models(**ncep_config(), precision='bf16x2').to(_dev())
+    b = synth_batch(n, _dev(), seed=1)
+    m.physics_net.zero_grad(set_to_none=True)
+    terms = m.pde_loss_terms(b['x'], b['y'], b['t'], b['f'], b['field_data'], b['coord_data'], b['forecast_h'])
+    terms.sum().backward()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    st = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and not k.endswith('.pe')) for k, v in m.physics_net.state_dict().items()}
+    cpu = {k: v.cpu() for k, v in b.items()}
+    x, y, t = (cpu[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
+    total, parts, _, _ = O.place_one_batch(st, x, y, t, cpu['f'], cpu['field_data'], cpu['coord_data'], cpu['forecast_h'], GEO, return_parts=True)
+    names = O.param_names(st)
+    ref_g = dict(zip(names, torch.autograd.grad(total, [st[k] for k in names])))
+    ref = np.array([float(p.detach()) for p in parts])
+    mine = terms.detach().cpu().numpy()
+    assert np.all(np.abs(mine - ref) <= tol['loss'] * np.abs(ref)), (mine, ref)
+    assert len(ref_g) == 155
+    worst = {}
+    for name, p in m.physics_net.named_parameters():
+        if name.endswith('key_projection.bias'):
+            continue
+        r = ref_g[name]
+        d = (p.grad.cpu() - r).abs()
+        l2 = float(d.pow(2).mean().sqrt() / (r.pow(2).mean().sqrt() + 1e-30))
+        mx = float(d.max() / (r.abs().max() + 1e-30))
+        worst[name] = (l2, mx)
+        assert l2 < tol['grad'] and mx < 5.0 * tol['grad'], (name, l2, mx)
+    print('full-grid gradient parity: worst L2 %.2e, worst element %.2e' % (max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))
+
+
+def test_config2_full_size_61_leads():
+    """BASELINE configs[2] at FULL size: 61 forecast-lead field samples x 37 265 points in one step (2 273 165 points).  The oracle does
+    not fit there; what must hold at any size: finite losses, the step's loss = the mean over fields, each field's six terms = what
+    place_one_batch gives for that field alone (checked on the first and the last lead), finite gradients for all 155 tensors."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synth_batch
+    B, n = 61, 257 * 145
+    m = _model('bf16x2')
+    dev = _dev()
+    many = [synth_batch(n, dev, seed=1000 + k) for k in range(B)]
+    lead = {k: torch.stack([b_[k].reshape(-1) for b_ in many]) for k in ('x', 'y', 't', 'f')}
+    cd = torch.stack([b_['coord_data'] for b_ in many])
+    field = torch.cat([b_['field_data'] for b_ in many], dim=0)
+    fh = torch.arange(B, device=dev, dtype=torch.float32).mul_(6.0 / 360.0).view(-1, 1, 1)
+    lf = m.train_cfg['losses']['loss_factor']
+    m.physics_net.zero_grad(set_to_none=True)
+    loss, terms = m.place_lead_batch(lead['x'], lead['y'], lead['t'], lead['f'], field, cd, fh, torch.nn.MSELoss(), lf)
+    loss.backward()
+    t_ = terms.detach().double().cpu().numpy()
+    assert t_.shape == (B, 6) and np.all(np.isfinite(t_))
+    totals = ((((t_[:, 0] + t_[:, 1]) + t_[:, 3]) + t_[:, 2]) + t_[:, 4]) + t_[:, 5]
+    assert abs(float(loss) - totals.mean()) <= 1e-5 * abs(totals.mean())
+    for k in (0, B - 1):
+        single = m.pde_loss_terms(lead['x'][k], lead['y'][k], lead['t'][k], lead['f'][k], field[k:k + 1], cd[k], fh[k:k + 1]).detach().double().cpu().numpy()
+        assert np.all(np.abs(single - t_[k]) <= 2e-5 * np.abs(t_[k])), (k, single, t_[k])
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.physics_net.parameters())

@@ -133,3 +133,93 @@ def test_point_config_follows_the_config_file(model):
     model.with_clip = True
     with pytest.raises(NotImplementedError):
         model._check_pde_criterion(torch.nn.L1Loss())
+
+
+# ------------------------------------------------------------------------------------------------ round 2: loops, launcher, arena
+def test_training_loop_surface_resolves_like_the_reference(model):
+    """train.py:47 calls `run_train_interface(checkpoint_path=..., log_path=...)`; the _dist twin exists too (:848).  Without a sample
+    source the loop says what it needs instead of reaching for GeoTIFF files."""
+    import inspect
+    for name in ('run_train_interface', 'run_train_interface_dist'):
+        fn = getattr(model, name)
+        assert list(inspect.signature(fn).parameters) == ['kwargs']
+    m = builder_models(**ncep_config())
+    m.train_cfg['num_epoch'] = 1
+    with pytest.raises((RuntimeError, AssertionError), match='samples|HIP|CUDA|cuda'):
+        m.run_train_interface(checkpoint_path=None, log_path=None, device='cpu')
+
+
+def test_lr_schedule_of_the_config_matches_the_reference_sequence(model):
+    """cfg:160-165 CosineAnnealingLR(T_max=5, eta_min=5e-6) stepped once per epoch (:831-833); the `verbose=True` the config passes
+    (a TypeError under torch >= 2.7) is dropped.  Sequence = SURVEY appendix A probe of the reference."""
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.Adam([{'params': [w], 'initial_lr': 1e-4}], lr=1e-4)
+    model.train_cfg['lr_schedule'] = dict(name='CosineAnnealingLR', T_max=5, eta_min=5e-6, verbose=True)
+    sched = model._build_lr_schedule(opt, current_epoch=0)
+    seq = []
+    for _ in range(6):
+        opt.step()
+        sched.step()
+        seq.append(opt.param_groups[0]['lr'])
+    assert np.allclose(seq, [9.09e-5, 6.72e-5, 3.78e-5, 1.41e-5, 5e-6, 1.41e-5], rtol=5e-3)
+
+
+def test_bench_refuses_more_ranks_than_gpus_and_mismatched_launchers():
+    """bench.py --gpus N must start N ranks or fail loudly -- never report one rank's number as N.  This container has no
+    GPU: the self-launcher exits non-zero before touching a device; a WORLD_SIZE that contradicts --gpus is refused as well."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'DPN_BENCH_ONE_DEVICE')}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and 'GPU(s) visible' in r.stderr and '{' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='4', RANK='0'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'disagree' in r.stderr
+
+
+def test_grad_arena_leases_and_fallbacks():
+    """grad_arena on CPU tensors: a slot is handed out once per accumulation window, views alias the owner's flat buffer, foreign tensors
+    and dead owners fall back to ordinary allocations."""
+    from deepphysinet_amd import grad_arena
+
+    class Owner:
+        pass
+    o = Owner()
+    a, b = torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))
+    o._g_flat, o._leased = torch.zeros(4096), set()
+    grad_arena.register(o, [a, b], [0, 2048])
+    g1 = grad_arena.new_grad(a)
+    assert g1.shape == (3, 4) and g1.data_ptr() == o._g_flat.data_ptr()
+    g2 = grad_arena.new_grad(a)                                      # second request in the same window: not the slot
+    assert g2.data_ptr() != g1.data_ptr()
+    assert grad_arena.new_grad(b.detach()).data_ptr() == o._g_flat[2048:].data_ptr()       # a detached alias of the parameter finds the slot
+    assert grad_arena.new_grad(torch.zeros(5)).data_ptr() not in (g1.data_ptr(), o._g_flat[2048:].data_ptr())
+    o._leased.clear()                                                # zero_grad(set_to_none=True)
+    assert grad_arena.new_grad(a, (12,)).data_ptr() == o._g_flat.data_ptr()
+    del o
+    import gc
+    gc.collect()
+    assert grad_arena.slot_of(a) is None
+    grad_arena.unregister(None)
+
+
+def test_resmlp_and_min_max_inverse_norm_follow_the_reference(model):
+    """VERDICT r1 surface holes: ResMLP.forward (variable_net.py:22-24: fc(x) + x) is callable, and inverse_norm handles the min_max
+    branch (:242-249), both as plain expressions."""
+    from deepphysinet_amd.model.variable_net import ResMLP
+    torch.manual_seed(0)
+    r = ResMLP(16)
+    x = torch.randn(5, 16)
+    want = r.fc[2](torch.relu(r.fc[0](x))) + x
+    assert torch.allclose(r(x), want, atol=1e-6)
+    cfg = {k: dict(v) for k, v in model.obs_norm_cfg.items()}
+    cfg['t2'] = dict(name='t2', norm_factor=[200.0, 320.0], norm_type='min_max', bound=[50, 500], use_norm=True)
+    cfg['q2'] = dict(name='q2', norm_factor=[0.0, 0.2, 1e-5], norm_type='min_max', bound=[1e-6, 10], use_norm=True)
+    v = [torch.full((3, 1), 0.5) for _ in range(6)]
+    model.with_clip = True
+    out = model.inverse_norm(*v, cfg)
+    assert torch.allclose(out[3], torch.full((3, 1), 260.0)) and torch.allclose(out[4], torch.full((3, 1), 0.1 ** 2 + 1e-5))
+    assert torch.allclose(out[0], torch.full((3, 1), 0.5 * 3.0050219075895894 + 0.14507186950562942))

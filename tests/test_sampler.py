@@ -44,6 +44,21 @@ def test_oracle_grid_maps_order():
             assert maps[2, yy, xx] == out[xx * lat + yy, 2]          # result_P[y, x] = inter_P[id], id = x * lat + y
 
 
+def test_oracle_coriolis_matches_reference_vectors(golden_dir):
+    """Fixture F11 = PhysicsDataset.get_coriolis of the reference itself (dataset/physics_dataset.py:521-526) on the latitude forms its
+    callers build: pins the oracle's restatement bit-for-bit (fp64) and through the pipeline's float32 cast."""
+    import os
+    d = np.load(os.path.join(golden_dir, 'f11_coriolis.npz'))
+    assert np.array_equal(SO.coriolis(d['lat_nodes']), d['f_nodes']) and SO.coriolis(d['lat_nodes']).shape == (145, 1)
+    assert np.array_equal(SO.coriolis(d['lat_cont']), d['f_cont'])
+    assert np.array_equal(SO.coriolis(d['lat_cont'][:7].reshape(7, 1)), d['f_2d'])
+    assert np.array_equal(SO.coriolis(d['lat_cont']).astype(np.float32), d['f_cont_f32'])
+    # the point generators: lat = begin_lat + y_rand * 0.25 (:336-337, :444-445)
+    _, _, _, _, f = SO.points_from_draws(_cube().astype(np.float64), np.zeros(512), d['y_cont'], np.zeros(512), 72.0, 18.0, IN_LON, IN_LAT, 6,
+                                         27000.0, 27000.0)
+    assert np.array_equal(f, d['f_cont_f32'])
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 def _sampler(seed=11, with_labels=True):
     from deepphysinet_amd.sampler import CollocationSampler, SamplerConfig
@@ -82,6 +97,18 @@ def test_interior_points_match_oracle_and_are_uniform():
     assert not torch.equal(x, x2)
     s2, _, _ = _sampler()                                              # same seed -> same stream
     assert torch.equal(s2.get_inter_data(n)[0], x)
+
+
+@pytest.mark.gpu
+def test_device_coriolis_matches_reference_vectors(golden_dir):
+    """The f column of the device sampler at every latitude row of the grid against fixture F11 (the reference's get_coriolis output
+    cast to float32 as __getitem__ does, physics_dataset.py:517-519): one ulp (the kernel evaluates sin in fp64 and casts once)."""
+    import os
+    d = np.load(os.path.join(golden_dir, 'f11_coriolis.npz'))
+    s, _, _ = _sampler(with_labels=False)
+    yi = d['y_nodes'].astype(np.int32)
+    _, _, _, _, f = s.get_margin_grid(np.zeros_like(yi), yi, np.zeros_like(yi))
+    np.testing.assert_allclose(f.cpu().numpy(), d['f_nodes_f32'], rtol=1.2e-7, atol=0)
 
 
 @pytest.mark.gpu
