@@ -577,12 +577,30 @@ struct FwdArgs {
     float* out_n;
     float* jac_n;
     void* saved;
+#ifdef DPN_TIMELINE
+    unsigned* timeline;      // [blocks][6 nets][4 waves][64]: s_memtime (low word) at the start of every pipeline step (experiment build only)
+#endif
 };
+
+// Experiment build (-DDPN_TIMELINE, tools/timeline_build.py): every wave keeps the shader clock at the start of each pipeline step in one
+// VGPR (lane i <- stamp i, v_writelane: no memory traffic, no counters touched besides the s_memtime's own lgkmcnt, which is empty at a
+// step boundary) and writes the register out at the end.  Stamp 0 = kernel entry, 1 = ring primed / prologue done, 2 + C = step C, 62 = exit.
+#ifdef DPN_TIMELINE
+#define DPN_STAMP(I)                                                                                          \
+    do {                                                                                                      \
+        unsigned long long t_;                                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(tl) : "s"((u32)t_), "n"(I));                         \
+    } while (0)
+#else
+#define DPN_STAMP(I) do { } while (0)
+#endif
 
 // One pipeline step on chunk C: make it readable (and put chunk C+3 in flight), multiply it, and run the epilogue of the
 // PREVIOUS tile in the shadow of these MFMAs (it only touches that tile's accumulator).
 #define DPN_STEP(C, NK, SWAP, ACT, ACC, EPI_PREV)                                    \
     do {                                                                             \
+        DPN_STAMP(2 + (C));                                                          \
         pipe.acquire(C);                                                             \
         mma_chunk<NS, (NK), (SWAP)>(pipe.buf(C), (ACT), (ACC));                      \
         EPI_PREV;                                                                    \
@@ -597,6 +615,10 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     const int64_t tile32 = (int64_t)blockIdx.x * 4 + wave;
     const char* pk = a.packed + (long)net * pack_bytes_per_net(NS);
     __shared__ __attribute__((aligned(16))) float lds_vec_store[kNumVecs * 256 + 4];
+#ifdef DPN_TIMELINE
+    u32 tl = 0;
+    DPN_STAMP(0);
+#endif
     {   // permuted fp32 vectors of this net -> LDS (published by the barrier below, before the first DMA is issued)
         const float* gv = reinterpret_cast<const float*>(pk + (long)kPackKB * 1024 * NS);
         for (int i = threadIdx.x; i < kNumVecs * 256 + 4; i += 256) lds_vec_store[i] = gv[i];
@@ -618,6 +640,7 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     __syncthreads();
     pipe.init(pk, lds_w, 54);
     pipe.prime();
+    DPN_STAMP(1);
 
     f32x16 acc[8];
     u32 m1w[4] = {0u, 0u, 0u, 0u};
@@ -794,6 +817,10 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     }
     epij(5);
     pipe.drain();
+#ifdef DPN_TIMELINE
+    DPN_STAMP(62);
+    if (a.timeline) a.timeline[(((int64_t)blockIdx.x * kNets + net) * 4 + wave) * 64 + L.lane] = tl;
+#endif
 #pragma unroll
     for (int c = 0; c < 3; ++c) jc[c] += __shfl_xor(jc[c], 32);
     if (L.valid && h == 0 && !a.pe_in) {
@@ -1021,6 +1048,9 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 
     f32x16 acc[8];
     Frag<NS> actA[16];
+#ifdef DPN_TIMELINE
+    u32 tl = 0;          // the step macro stamps; the backward kernel does not report (experiment build only)
+#endif
     // ---------------- Z0 = g * pe + sum_c gJ_c * dpe/dxi_c ; Z1 = m1 (.) (w1 Z0 + g b1)
     auto epi1 = [&](const int T) __attribute__((always_inline)) {
 #pragma unroll
@@ -2050,11 +2080,19 @@ int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, vo
 
 #endif  // DPN_HAS_REST
 #if DPN_HAS_POINT
+#ifdef DPN_TIMELINE
+static unsigned* g_timeline = nullptr;
+int dpn_debug_set_timeline(void* buf) { g_timeline = reinterpret_cast<unsigned*>(buf); return 0; }    // experiment build only, not in dpn_hip.h
+#endif
 int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
             const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream) {
     if (!coord_data || !freqs || !geo || !packed || !out_n || n <= 0 || (prec != 1 && prec != 2)) return -1;
     if (!pe_in && (!x || !y || !t)) return -1;
+#ifdef DPN_TIMELINE
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, g_timeline};
+#else
     FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved};
+#endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
     if (prec == 1) hipLaunchKernelGGL(dpn_fwd_kernel<1>, grid, dim3(256), 0, s, a);
@@ -2305,7 +2343,7 @@ static int clip_adam_flat_impl(int n_tensors, float* const* params, const float*
             t.chunk_start[t.n] = chunks;
             if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
             else hipLaunchKernelGGL(dpn_adam_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr,
-                                    beta1, beta2, eps, weight_decay, max_norm, out_norm_dev, (const float*)nullptr);
+                                    beta1, beta2, eps, weight_decay, max_norm, out_norm_dev, hyper_dev);
             base_chunk += chunks;
         }
         if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, base_chunk, sumsq);

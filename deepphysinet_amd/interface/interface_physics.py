@@ -413,10 +413,8 @@ class StagedPdeStep:
         self.stages = (self.stage_points, self.stage_heads, self.stage_encoder)
         self._seed = None
 
-    @staticmethod
-    def _assign(params, grads):
-        for p, g in zip(params, grads):
-            p.grad = g if g is not None else torch.zeros_like(p)
+    def _assign(self, params, grads):
+        self.opt.place_gradients(params, grads)          # the rare gradient that did not land in its slot is copied there before the all-reduce
 
     def stage_points(self):
         m, b = self.m, self.b

@@ -119,6 +119,19 @@ class FusedClipAdam(torch.optim.Optimizer):
                 continue
             p.grad = s
 
+    def place_gradients(self, params, grads):
+        """`p.grad = g` for gradients handed back by torch.autograd.grad (staged backward): a gradient that is not already the
+        parameter's slot is copied into it (None: zeros), so that the bucket's all-reduce -- which may start right after -- sees it."""
+        if getattr(self, '_slot_of', None) is None:
+            self._slot_of = {id(p): s for p, s in zip(self.params, self._slots)}
+        for p, g in zip(params, grads):
+            s = self._slot_of[id(p)]
+            if g is None:
+                s.zero_()
+            elif g.data_ptr() != s.data_ptr() or not g.is_contiguous():
+                s.copy_(g)
+            p.grad = s
+
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             if set_to_none:
