@@ -55,7 +55,8 @@ def main():
     lib.dpn_debug_set_timeline.argtypes = [ctypes.c_void_p]
     cfg = m.point_config()
     nblk = (n + 127) // 128
-    tl = torch.zeros((nblk, 6, 4, 64), dtype=torch.int32, device=dev)
+    nw = 4 if os.environ.get('DPN_FWD4') == '1' else 8          # waves per workgroup of the kernel dpn_fwd dispatches to
+    tl = torch.zeros((nblk, 6, 8, 64), dtype=torch.int32, device=dev)
     with torch.no_grad():
         heads, evec, statics = m.physics_net.field_weights(b['field_data'], b['forecast_h'])
         x_, y_, t_ = (PP._f32c(b[k]).reshape(-1) for k in ('x', 'y', 't'))
@@ -72,24 +73,24 @@ def main():
             torch.cuda.synchronize()
         print('kernel + pack (instrumented): %.1f us' % (e0.elapsed_time(e1) * 1e3))
     lib.dpn_debug_set_timeline(None)
-    T = tl.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    T = tl.cpu().numpy().astype(np.int64)[:, :, :nw] & 0xFFFFFFFF
     d = (T[..., 1:] - T[..., :-1]) & 0xFFFFFFFF            # wrap-safe deltas, [blk, net, wave, 63]
     total = (T[..., 62] - T[..., 0]) & 0xFFFFFFFF
     print('%s: waves %d, cycles per wave entry -> exit: mean %.0f  min %d  max %d' % (prec, total.size, total.mean(), total.min(), total.max()))
     print('prologue (entry -> ring primed): %.0f   primed -> first step: %.0f' % (d[..., 0].mean(), d[..., 1].mean()))
-    nsplit = 3 if prec == 'bf16x2' else 1
+    nsplit = (3 if prec == 'bf16x2' else 1) * (4.0 / nw)         # the eight-wave kernel's waves multiply half of K each
     print('%-5s %6s %10s %10s %10s %12s' % ('stage', 'chunks', 'cyc/chunk', 'min', 'max', 'MFMA-bound'))
     for name, c0, c1, nk in STAGES:
         seg = d[..., 2 + c0:2 + c1]                        # step C spans stamp 2+C -> 3+C; the last step of the kernel ends at stamp 62
         if c1 == 54:
             seg = np.concatenate([d[..., 2 + c0:2 + c1 - 1], ((T[..., 62] - T[..., 2 + 53]) & 0xFFFFFFFF)[..., None]], axis=-1)
-        print('%-5s %6d %10.0f %10d %10d %12d' % (name, c1 - c0, seg.mean(), seg.min(), seg.max(), nk * 32 * nsplit))
+        print('%-5s %6d %10.0f %10d %10d %12d' % (name, c1 - c0, seg.mean(), seg.min(), seg.max(), int(nk * 32 * nsplit)))
     # per-chunk profile of one workgroup in the middle of the grid, wave 0..3
     blk = nblk // 2
-    for w in range(4):
+    for w in range(nw):
         print('blk %d net 2 wave %d:' % (blk, w), ' '.join('%d' % v for v in d[blk, 2, w, :56]))
     starts = T[blk, 2, :, 2:56]
-    print('inter-wave skew at step starts (max - min over the 4 waves), blk %d net 2:' % blk, ' '.join('%d' % v for v in ((starts.max(0) - starts.min(0)) & 0xFFFFFFFF)))
+    print('inter-wave skew at step starts (max - min over the waves), blk %d net 2:' % blk, ' '.join('%d' % v for v in ((starts.max(0) - starts.min(0)) & 0xFFFFFFFF)))
 
 
 if __name__ == '__main__':
