@@ -110,6 +110,24 @@ EXPORTS = {
 
 _lib = None
 
+# The per-FIELD math (encoder GEMMs, attention, LayerNorm, hyper-network heads, SmoothL1) has plain-torch expressions for host tensors.
+# They exist for the CPU-side tests of the module tree / state_dict contract / encoder math against the reference's golden vectors
+# (the build container has no GPU); the product never takes them: a host tensor reaching one of these ops raises unless reference math
+# has been switched on explicitly (tests do, DPN_CPU_REFERENCE_MATH=1 does).  The per-POINT path has no host form at all.
+_cpu_reference_math = [os.environ.get('DPN_CPU_REFERENCE_MATH') == '1']
+
+
+def enable_cpu_reference_math(on=True):
+    _cpu_reference_math[0] = bool(on)
+
+
+def host_math_or_raise(t, what):
+    """Called where an op is about to evaluate its torch expression instead of a HIP kernel: allowed for device tensors of a shape the
+    kernels do not cover, and for host tensors only in reference-math mode."""
+    if not t.is_cuda and not _cpu_reference_math[0]:
+        raise RuntimeError('deepphysinet_amd: %s got a tensor on %s; the HIP kernels are the only product path (no CPU fallback). '
+                           'deepphysinet_amd._lib.enable_cpu_reference_math() switches the torch expressions on for CPU-side tests.' % (what, t.device))
+
 
 def load():
     """dlopen libdpn_hip.so and declare every prototype; raises if the library is absent."""

@@ -2,7 +2,7 @@
 EncoderLayer and the hyper-network heads as single nodes with hand-scheduled backward passes (a dependent kernel costs >= 4.5 us on
 this machine whatever it does, so the schedule minimises the number of launches on the dependency chain), for one field sample or
 a batch of them; plus per-op wrappers (attention, add + LayerNorm) for modules that do not fit the fused nodes.
-CPU tensors take the equivalent torch expressions (encoder-math tests only)."""
+Host tensors raise unless reference math is switched on (_lib.enable_cpu_reference_math: CPU-side encoder-math tests only)."""
 import ctypes
 
 import torch
@@ -58,6 +58,7 @@ def attention(q, k, v):
     if q.is_cuda and B == 1 and H == 8 and E == 32 and Lq <= 288 and k.shape[1] == Lq:
         o = _AttentionFn.apply(q.reshape(Lq, H * E), k.reshape(Lq, H * E), v.reshape(Lq, H * E))
         return o.view(1, Lq, H, E)
+    L.host_math_or_raise(q, 'attention')
     out = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
     return out.transpose(1, 2).contiguous()
 
@@ -98,6 +99,7 @@ def add_layer_norm(x, r, norm: torch.nn.LayerNorm):
     """norm(x + r) with the module's parameters (r may be None)."""
     if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and norm.elementwise_affine and norm.eps == 1e-5:
         return _AddLayerNormFn.apply(x, r, norm.weight, norm.bias)
+    L.host_math_or_raise(x, 'add_layer_norm')
     return norm(x if r is None else x + r)
 
 

@@ -129,9 +129,10 @@ class _MultiLinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None):
-    """Drop-in for F.linear on fp32 HIP tensors; falls back to torch only for CPU tensors."""
+    """Drop-in for F.linear on fp32 HIP tensors (host tensors: only in reference-math mode, _lib.host_math_or_raise)."""
     if x.is_cuda and x.dtype == torch.float32:
         return _MultiLinearFn.apply(x, weight, bias)[0]
+    L.host_math_or_raise(x, 'linear')
     return F.linear(x, weight, bias)
 
 
@@ -139,4 +140,5 @@ def linear_multi(x, weights, biases):
     """[F.linear(x, w, b) for w, b in ...] as one launch (same output width for all; at most three)."""
     if x.is_cuda and x.dtype == torch.float32 and len(weights) <= 3:
         return _MultiLinearFn.apply(x, *weights, *biases)
+    L.host_math_or_raise(x, 'linear_multi')
     return tuple(F.linear(x, w, b) for w, b in zip(weights, biases))

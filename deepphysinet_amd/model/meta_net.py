@@ -49,6 +49,8 @@ class TokenEmbedding(nn.Module):
             xu = torch.cat([torch.roll(x0, 1, 0), x0, torch.roll(x0, -1, 0)], dim=1)           # [159, 3*c_in], tap-major
             w = self.tokenConv.weight.permute(0, 2, 1).reshape(self.tokenConv.weight.shape[0], -1)   # [d_model, 3*c_in]
             return linear(xu, w, self.tokenConv.bias).unsqueeze(0)
+        from .._lib import host_math_or_raise
+        host_math_or_raise(x, 'TokenEmbedding')
         return self.tokenConv(x.permute(0, 2, 1)).transpose(1, 2)
 
 

@@ -78,6 +78,8 @@ class PhysicsNet(nn.Module):
             if B == 1:
                 heads, evec = heads.view(256, -1), evec.view(6, 256)                   # one field: the shapes the point path takes
         else:
+            from .._lib import host_math_or_raise
+            host_math_or_raise(meta_out, 'PhysicsNet.field_weights')
             m_t = torch.squeeze(meta_out, dim=0)[0:nets[0].token_num].T                # [256 channels, 256 tokens]
             w_cat = torch.cat([n.coord_input_fc.weight for n in nets] + [n.coord_hidden_fc.weight for n in nets], dim=0)
             b_cat = torch.cat([n.coord_input_fc.bias for n in nets] + [n.coord_hidden_fc.bias for n in nets], dim=0)

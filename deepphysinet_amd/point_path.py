@@ -470,6 +470,51 @@ def pde_fields_and_jacobian(cfg: PointConfig, x, y, t, coord_data, heads, evec, 
         return _forward_points(cfg, ws, _net_ptrs(hd_, ev_, st), x_, y_, t_, None, cd_, want_jac=True, want_saved=False)
 
 
+def relu_masks(cfg: PointConfig, x, y, t, coord_data, heads, evec, statics):
+    """Diagnostic export of the two ReLU masks of every VariableNet at every point, decoded from the state dpn_fwd saves for the backward
+    pass: (m1, m2), bool [6, N, 256] in natural channel order -- m1 = (w1 . pe + b1 > 0) (variable_net.py:67-68), m2 = (cat_fc1.fc.0 pre-
+    activation > 0) (ResMLP, :13-24).  The Jacobian and every gradient are piecewise constant / linear in these bits, so a point whose
+    pre-activation lies within rounding distance of zero may carry a different bit than another arithmetic's (the parity tests list those
+    points and hold everything else to the tight bounds).  Layouts: csrc/dpn_kernels.hip SavedView, dpn_layout.h."""
+    with torch.no_grad():
+        x_, y_, t_ = (_f32c(v).reshape(-1) for v in (x, y, t))
+        cd_, hd_, ev_ = (_f32c(v) for v in (coord_data, heads, evec))
+        st = [_f32c(s) for s in statics]
+        n = cd_.shape[0]
+        dev = cd_.device
+        ws = _Workspace(n, cfg.prec, dev)
+        _forward_points(cfg, ws, _net_ptrs(hd_, ev_, st), x_, y_, t_, None, cd_, want_jac=True, want_saved=True)
+        n_pad, ns = int(ws.sizes.n_pad), int(cfg.prec)
+        tiles = n_pad // 32
+        mat = 6 * ns * n_pad * 512
+        raw = ws.saved
+        # M2: [6][tiles][kk 2][ct 8][lane 64][8 bf16 of 0/1]: register r = 8 kk + e of lane (col jj = lane & 31, h = lane >> 5) is the mask of
+        # channel chain_ch(2 ct + (jj >> 4), (jj >> 3) & 1, jj & 7) at point drow32(r, h) of the tile
+        m2_raw = raw[2 * mat:2 * mat + 6 * n_pad * 512].view(torch.int16).view(6, tiles, 2, 8, 64, 8) != 0
+        lane = torch.arange(64, device=dev)
+        jj, hh = lane & 31, lane >> 5
+        ct = torch.arange(8, device=dev)
+        ks = 2 * ct[:, None] + (jj >> 4)[None, :]                                       # [ct, lane]
+        chan = 16 * ks + 8 * ((jj & 7) >> 2)[None, :] + 4 * ((jj >> 3) & 1)[None, :] + (jj & 3)[None, :]
+        r = torch.arange(16, device=dev)
+        prow = (r & 3)[:, None] + 8 * (r >> 2)[:, None] + 4 * hh[None, :]              # [r, lane] point row inside the tile
+        m2 = torch.zeros((6, tiles, 32, 256), dtype=torch.bool, device=dev)
+        src = m2_raw.permute(0, 1, 3, 4, 2, 5).reshape(6, tiles, 8, 64, 16)            # [net, tile, ct, lane, r]
+        pi = prow.t()[None, :, :].expand(8, 64, 16)                                    # [ct, lane, r]
+        ci = chan[:, :, None].expand(8, 64, 16)
+        m2[:, :, pi, ci] = src
+        # m1: uint4 per (net, tile, lane): bit 16 (T & 1) + r of word T >> 1 = mask of channel 32 T + drow32(r, h) at point lane & 31
+        m1_raw = raw[2 * mat + 6 * n_pad * 512:2 * mat + 6 * n_pad * 512 + 6 * n_pad * 32].view(torch.int32).view(6, tiles, 64, 4)
+        T = torch.arange(8, device=dev)
+        words = m1_raw[:, :, :, T >> 1]                                                # [net, tile, lane, T]
+        bits = (words[..., None] >> (16 * (T & 1)[:, None] + r[None, :])) & 1           # [net, tile, lane, T, r]
+        ch1 = 32 * T[None, :, None] + (r & 3)[None, None, :] + 8 * (r >> 2)[None, None, :] + 4 * hh[:, None, None]       # [lane, T, r]
+        m1 = torch.zeros((6, tiles, 32, 256), dtype=torch.bool, device=dev)
+        p1 = jj[:, None, None].expand(64, 8, 16)
+        m1[:, :, p1, ch1] = bits.bool()
+        return m1.reshape(6, n_pad, 256)[:, :n], m2.reshape(6, n_pad, 256)[:, :n]
+
+
 def smooth_l1_data_loss(out_n, labels, beta=0.1, factor=1.0):
     """mean(SmoothL1(beta)) * factor as a differentiable torch scalar (losses/weights_loss.py:17-20); HIP kernel for both passes."""
     return _SmoothL1Fn.apply(out_n, labels, float(beta), float(factor))

@@ -148,15 +148,21 @@ def test_grid_node_points_longest_lead_match_reference_golden(golden_dir):
                               global_step=2, local_rank=0, device=_dev())
     assert abs(float(total) - float(d['total'])) <= 1e-4 * abs(float(d['total']))
     terms = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).detach().cpu().numpy()
-    # 200 points: ONE point on the other side of a ReLU kink / clip bound than in the reference's fp32 run moves a term by a few 1e-4
-    # (which point depends on the last bits of the hyper-weights, i.e. on the summation order of the encoder kernels: the terms were all
-    # within 1e-4 before the attention kernels went to eight waves, two of them sit at 2.5e-4 since).  The sum keeps the 1e-4 bar above.
-    rel = np.abs(terms - d['parts']) / np.abs(d['parts'])
-    assert np.all(rel <= 1e-3) and np.median(rel) <= 5e-5, (terms, d['parts'])
     cfg = m.point_config()
     with torch.no_grad():
         heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
         out_n, jac_n = dpn.pde_fields_and_jacobian(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
+        from deepphysinet_amd.point_path import relu_masks
+        m1, m2 = relu_masks(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
+    # per term: 1e-4, the north-star bar -- unless one of the 200 points carries a ReLU / clip / vapour-switch bit that differs from the
+    # oracle arithmetic's (then that point, named here, moves a term by a few 1e-4 in ANY two fp32-class arithmetics: the reference's own
+    # fp32 run against its fp64 run does the same; test_kink_flips_are_listed_and_every_other_point_is_tight holds the rest to 1e-4)
+    o1, o2, oclip, odelta = _oracle_masks(inp)
+    clip, delta = _clip_and_delta(out_n, jac_n)
+    flipped = ((m1.cpu() != o1) | (m2.cpu() != o2)).any(dim=2).any(dim=0) | (clip != oclip).any(dim=1) | (delta != odelta)
+    rel = np.abs(terms - d['parts']) / np.abs(d['parts'])
+    print('F10: points with a differing switch bit:', torch.nonzero(flipped).flatten().tolist(), 'per-term rel. error', rel)
+    assert np.all(rel <= (1e-4 if int(flipped.sum()) == 0 else 1e-3)), (terms, d['parts'], int(flipped.sum()))
     ref_n = torch.from_numpy(d['fields_norm'])
     assert float((out_n.cpu() - ref_n).abs().max() / ref_n.abs().max()) < TOL['bf16x2']['field']
 
@@ -781,3 +787,127 @@ def test_config2_full_size_61_leads():
         single = m.pde_loss_terms(lead['x'][k], lead['y'][k], lead['t'][k], lead['f'][k], field[k:k + 1], cd[k], fh[k:k + 1]).detach().double().cpu().numpy()
         assert np.all(np.abs(single - t_[k]) <= 2e-5 * np.abs(t_[k])), (k, single, t_[k])
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.physics_net.parameters())
+
+
+# ------------------------------------------------------------------------------------------------ kink-aware parity, as a proof
+def _oracle_masks(inp):
+    """ReLU masks [6, N, 256] x 2, clip mask [N, 6] and the vapour switch delta [N] of the fp32 oracle arithmetic (oracle/kernel_model.py)."""
+    from oracle import kernel_model as KM
+    st = O.make_state()
+    with torch.no_grad():
+        meta = O.meta_net_forward(st, inp['field_data'], inp['forecast_h'])
+        xi = torch.cat([inp['x'] / GEO.dx / (GEO.lon - 1), inp['y'] / GEO.dy / (GEO.lat - 1), inp['t'] / GEO.pred_t_span], 1)
+        pe, dpe = KM.pe_and_tangent(xi)
+        pe6 = O.sine_cos_pe(inp['coord_data'], 16)
+        m1, m2, outs, jx = [], [], [], []
+        for k, net in enumerate(O.NETS):
+            W = KM.net_weights(st, net, meta, inp['forecast_h'])
+            out, jxi, S = KM.phase_a(W, pe, dpe, pe6, inp['coord_data'][:, k], 'fp32')
+            m1.append(S['m1'] > 0), m2.append(S['m2'] > 0), outs.append(out), jx.append(jxi)
+        out_n = torch.stack(outs, 1)
+        scale = torch.tensor([1.0 / GEO.dx / (GEO.lon - 1), 1.0 / GEO.dy / (GEO.lat - 1), 1.0 / GEO.pred_t_span])
+        clip, delta = _clip_and_delta(out_n, torch.stack(jx, 1) * scale)
+    return torch.stack(m1), torch.stack(m2), clip, delta
+
+
+def _clip_and_delta(out_n, jac_n):
+    """Which points sit inside the clip bounds (P, T, q, rho) and have the vapour switch on (interface_physics.py:165-168), from
+    normalised fields [N, 6] and their Jacobian [N, 6, 3]."""
+    std, mean = torch.tensor(O.OBS_STD), torch.tensor(O.OBS_MEAN)
+    val = out_n.cpu() * std + mean
+    clip = torch.ones_like(val, dtype=torch.bool)
+    for k in range(2, 6):
+        clip[:, k] = (val[:, k] >= O.CLIP_LO[k]) & (val[:, k] <= O.CLIP_HI[k])
+        val[:, k] = val[:, k].clamp(O.CLIP_LO[k], O.CLIP_HI[k])
+    J = jac_n.cpu() * (std * clip)[:, :, None]
+    u, v, p, T, q = val[:, 0], val[:, 1], val[:, 2], val[:, 3], val[:, 4]
+    omega = J[:, 2, 2] + u * J[:, 2, 0] + v * J[:, 2, 1]
+    tc = T - 273.15
+    e_s = 6.112 * torch.exp(17.67 * tc / (tc + 243.5)) * 100
+    q_s = torch.clamp(0.622 * e_s / (p - 0.378 * e_s), min=1e-6)
+    return clip, (omega < 0) & (q >= q_s)
+
+
+@pytest.mark.parametrize('n', [5197, 1037])
+def test_kink_flips_are_listed_and_every_other_point_is_tight(n):
+    """the tolerances for batches of hundreds of points allowed isolated Jacobian rows / gradient elements beyond the bound
+    'because of ReLU kinks' without identifying them.  Here the kernel's own mask bits (point_path.relu_masks: the words dpn_fwd saves),
+    the clip masks and the vapour switch are compared with the oracle's, the points where ANY of them differs are listed, and
+      (i)  their number is bounded (<= 1 % of the points; measured 0.6 %: 32 of 5 197, each point carries 6 x 512 ReLU bits);
+      (ii) with those points removed from BOTH sides, every loss term is within 1e-4, every Jacobian row within 2e-4 of the field's
+           largest entry, every fields value within 5e-5 and every gradient ELEMENT within 1e-3 of its tensor's maximum -- no outlier
+           allowance, no L2 fallback."""
+    import deepphysinet_amd as dpn
+    from deepphysinet_amd.point_path import relu_masks
+    tol = TOL['bf16x2']
+    inp = synthetic_inputs(n, tag='inter')
+    m = _model('bf16x2')
+    g = _gpu(inp)
+    cfg = m.point_config()
+    with torch.no_grad():
+        heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
+        m1, m2 = relu_masks(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
+        out_n, jac_n = dpn.pde_fields_and_jacobian(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
+    clip, delta = _clip_and_delta(out_n, jac_n)
+    o1, o2, oclip, odelta = _oracle_masks(inp)
+    flip_relu = ((m1.cpu() != o1) | (m2.cpu() != o2)).any(dim=2).any(dim=0)          # [N]
+    flip_clip = (clip != oclip).any(dim=1)
+    flip_delta = delta != odelta
+    flipped = flip_relu | flip_clip | flip_delta
+    nf = int(flipped.sum())
+    print('n = %d: %d points differ in a ReLU bit, %d in a clip mask, %d in the vapour switch: %s' % (
+        n, int(flip_relu.sum()), int(flip_clip.sum()), int(flip_delta.sum()), torch.nonzero(flipped).flatten().tolist()[:20]))
+    assert nf <= max(3, n // 100), nf
+    # the masks themselves: everything else identical, and the bit counts plausible (about half of the units are on)
+    assert 0.2 < float(m1.float().mean()) < 0.8 and 0.2 < float(m2.float().mean()) < 0.8
+    keep = ~flipped
+    sub = {k: (v[keep] if v.shape[0] == n else v) for k, v in inp.items()}
+    ref = _oracle(sub)
+    gs = _gpu(sub)
+    with torch.no_grad():
+        out_k, jac_k = dpn.pde_fields_and_jacobian(cfg, gs['x'], gs['y'], gs['t'], gs['coord_data'], heads, evec, statics)
+    assert float((out_k.cpu() - ref['fields']).abs().max() / ref['fields'].abs().max()) < tol['field']
+    for k in range(6):
+        r = ref['jac_n'][:, k]
+        assert float((jac_k.cpu()[:, k] - r).abs().max()) < tol['jac'] * float(r.abs().max()), k
+    m.physics_net.zero_grad(set_to_none=True)
+    terms = m.pde_loss_terms(gs['x'], gs['y'], gs['t'], gs['f'], gs['field_data'], gs['coord_data'], gs['forecast_h'])
+    terms.sum().backward()
+    mine = terms.detach().cpu().numpy()
+    assert np.all(np.abs(mine - ref['parts']) <= tol['loss'] * np.abs(ref['parts'])), (mine, ref['parts'])
+    worst = 0.0
+    for name, p in m.physics_net.named_parameters():
+        if name.endswith('key_projection.bias'):
+            continue
+        r = ref['grads'][name]
+        err = float((p.grad.cpu() - r).abs().max() / (r.abs().max() + 1e-30))
+        worst = max(worst, err)
+        assert err < tol['grad'], (name, err)
+    print('after removing them: worst gradient element %.2e of its tensor maximum' % worst)
+
+
+def test_variable_net_standalone_forward_matches_oracle():
+    """VariableNet.forward with the reference's own signature (model/variable_net.py:49: meta_out, coord [N,192] encoded, coord_data,
+    ref_data [N,1], fore_h) on one net at a time -- the surface a caller holding a single VariableNet uses -- against the oracle's
+    restatement of the same lines, values and the gradient of a weight."""
+    n = 300
+    inp = synthetic_inputs(n, tag='inter')
+    m = _model('bf16x2')
+    g = _gpu(inp)
+    st = O.make_state()
+    with torch.no_grad():
+        meta_ref = O.meta_net_forward(st, inp['field_data'], inp['forecast_h'])
+        coord_ref = O.encoding_coord(inp['x'], inp['y'], inp['t'], GEO)
+    meta = m.physics_net.meta_net(g['field_data'], g['forecast_h'])
+    coord = m.encoding_coord(g['x'], g['y'], g['t'], m.pred_t_span)
+    for k, name in ((0, 'U_net'), (4, 'q_net')):
+        net = getattr(m.physics_net, name)
+        ref_data = g['coord_data'][:, k:k + 1] * 0.5 + 0.25                  # NOT the column the fused path would add
+        out = net(meta, coord, g['coord_data'], ref_data, g['forecast_h'])
+        with torch.no_grad():
+            want = O.variable_net_forward(st, name, meta_ref, coord_ref, inp['coord_data'], ref_data.cpu(), inp['forecast_h'])
+        assert out.shape == (n, 1)
+        assert float((out.detach().cpu() - want).abs().max() / want.abs().max()) < TOL['bf16x2']['field'], name
+    net.zero_grad(set_to_none=True)
+    out.sum().backward()
+    assert net.out_fc.weight.grad is not None and bool(torch.isfinite(net.out_fc.weight.grad).all())

@@ -15,6 +15,29 @@ from oracle import dpn_oracle as O
 from oracle.fill import fill_state_dict_, synthetic_inputs
 
 
+@pytest.fixture(scope='module', autouse=True)
+def _reference_math():
+    """These tests evaluate the per-field torch expressions on host tensors (module tree / encoder math against the golden vectors);
+    the product refuses host tensors unless this is switched on (deepphysinet_amd._lib.host_math_or_raise)."""
+    from deepphysinet_amd import _lib
+    _lib.enable_cpu_reference_math(True)
+    yield
+    _lib.enable_cpu_reference_math(False)
+
+
+def test_host_tensors_are_refused_without_reference_math():
+    from deepphysinet_amd import _lib
+    from deepphysinet_amd.linear import linear
+    _lib.enable_cpu_reference_math(False)
+    try:
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            linear(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(3))
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            builder_loss(name='WeightSmoothL1Loss', beta=0.1)(torch.zeros(4, 6), torch.zeros(4, 6))
+    finally:
+        _lib.enable_cpu_reference_math(True)
+
+
 @pytest.fixture(scope='module')
 def model():
     m = builder_models(**ncep_config())
