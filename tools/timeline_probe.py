@@ -55,7 +55,7 @@ def main():
     lib.dpn_debug_set_timeline.argtypes = [ctypes.c_void_p]
     cfg = m.point_config()
     nblk = (n + 127) // 128
-    nw = 4 if os.environ.get('DPN_FWD4') == '1' else 8          # waves per workgroup of the kernel dpn_fwd dispatches to
+    nw = 8 if os.environ.get('DPN_FWD2') else 4                  # waves per workgroup (8: the shelved eight-wave kernel, experiment builds with -DDPN_EXPERIMENT_FWD2)
     tl = torch.zeros((nblk, 6, 8, 64), dtype=torch.int32, device=dev)
     with torch.no_grad():
         heads, evec, statics = m.physics_net.field_weights(b['field_data'], b['forecast_h'])
