@@ -17,14 +17,14 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, 'deepphysinet_amd', 'libdpn_hip_timeline.so')
 
 
-def build():
+def build(extra=()):
     from deepphysinet_amd import build as B
     obj = os.path.join(B.HERE, 'csrc', '_obj')
     os.makedirs(obj, exist_ok=True)
     objs = []
     for src, flags, name in B.UNITS:
         o = os.path.join(obj, 'tl_' + name)
-        cmd = ['hipcc', *B.COMMON, *flags, '-DDPN_TIMELINE', '-I' + os.path.join(ROOT, 'include'), '-c', src, '-o', o]
+        cmd = ['hipcc', *B.COMMON, *flags, '-DDPN_TIMELINE', *extra, '-I' + os.path.join(ROOT, 'include'), '-c', src, '-o', o]
         subprocess.run(cmd, check=True)
         objs.append(o)
     subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB], check=True)
@@ -36,7 +36,7 @@ STAGES = [('L1', 0, 8, 12), ('L2', 8, 16, 16), ('Wd', 16, 24, 12), ('fc1', 24, 3
 
 def main():
     if '--build' in sys.argv:
-        return build()
+        return build([a for a in sys.argv[1:] if a.startswith('-D')])       # e.g. --build -DDPN_DMA_INTERLEAVE
     os.environ['DPN_LIB'] = LIB
     import numpy as np
     import torch
