@@ -105,6 +105,7 @@ EXPORTS = {
     'dpn_clip_adam_flat': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                    c_float, c_float, c_void_p, c_void_p]),
     'dpn_clip_adam_flat_dev': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_gemm_fp8': (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dpn_selftest': (c_int, [c_void_p, c_void_p]),
 }
 

@@ -9,7 +9,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, 'csrc', 'dpn_kernels.hip'), os.path.join(HERE, 'csrc', 'dpn_encoder.hip'),
-        os.path.join(HERE, 'csrc', 'dpn_sampler.hip')]
+        os.path.join(HERE, 'csrc', 'dpn_sampler.hip'), os.path.join(HERE, 'csrc', 'dpn_fp8.hip')]
 DEPS = SRCS + [os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h')]
 LIB = os.path.join(HERE, 'libdpn_hip.so')
 
@@ -27,7 +27,8 @@ def needs_build() -> bool:
 UNITS = [(SRCS[0], ['-DDPN_TU=1', '-mllvm', '-amdgpu-mfma-vgpr-form'], 'dpn_point.o'),
          (SRCS[0], ['-DDPN_TU=2'], 'dpn_rest.o'),
          (SRCS[1], [], 'dpn_encoder.o'),
-         (SRCS[2], [], 'dpn_sampler.o')]
+         (SRCS[2], [], 'dpn_sampler.o'),
+         (SRCS[3], [], 'dpn_fp8.o')]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 

@@ -4,6 +4,7 @@ this machine whatever it does, so the schedule minimises the number of launches 
 a batch of them; plus per-op wrappers (attention, add + LayerNorm) for modules that do not fit the fused nodes.
 Host tensors raise unless reference math is switched on (_lib.enable_cpu_reference_math: CPU-side encoder-math tests only)."""
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -152,19 +153,35 @@ class _EncoderLayerFn(torch.autograd.Function):
         assert n == B * Lt
         Fh = wc1.shape[0]
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        # BASELINE configs[4] experiment, off in the product: the six forward GEMMs of the layer on the fp8 matrix cores (csrc/dpn_fp8.hip)
+        fp8 = os.environ.get('DPN_ENCODER_FP8') == '1'
+
+        def gemm8(M, N, K, A, W, bias, C, epi=0, aux_out=None):
+            L.check(lib.dpn_gemm_fp8(M, N, K, _p(A), K, _p(W), K, _p(bias), _p(C), N, epi, _p(aux_out), _s()), 'dpn_gemm_fp8')
         q, k, v = new(n, D), new(n, D), new(n, D)
-        _launch([_problem(n, D, D, [(x, D, w, D)], y, D, 0, 1, bias=b) for w, b, y in ((wq, bq, q), (wk, bk, k), (wv, bv, v))])
+        if fp8:
+            for w, b, y in ((wq, bq, q), (wk, bk, k), (wv, bv, v)):
+                gemm8(n, D, D, x, w, b, y)
+        else:
+            _launch([_problem(n, D, D, [(x, D, w, D)], y, D, 0, 1, bias=b) for w, b, y in ((wq, bq, q), (wk, bk, k), (wv, bv, v))])
         o, P = new(n, D), new(B * 8, 288, 288)
         L.check(lib.dpn_attn_fwd(_p(q), _p(k), _p(v), Lt, B, _p(o), _p(P), _s()), 'dpn_attn_fwd')
         a = new(n, D)
-        _launch([_problem(n, D, D, [(o, D, wo, D)], a, D, 0, 1, bias=bo)])
+        if fp8:
+            gemm8(n, D, D, o, wo, bo, a)
+        else:
+            _launch([_problem(n, D, D, [(o, D, wo, D)], a, D, 0, 1, bias=bo)])
         # (LayerNorm forward folded into the conv1 GEMM -- dpn_sgemm_ln mode 1 -- measured slower than the two launches: 21 vs 13.6 us with four waves, equal with eight)
         x1, xhat1, rstd1 = new(n, D), new(n, D), new(n)
         L.check(lib.dpn_add_ln_fwd(_p(x), _p(a), _p(g1), _p(be1), n, _p(x1), _p(xhat1), _p(rstd1), _s()), 'dpn_add_ln_fwd')
         pre, act = new(n, Fh), new(n, Fh)
-        _launch([_problem(n, Fh, D, [(x1, D, wc1, D)], act, Fh, 0, 1, bias=bc1, epi=L.EPI_GELU, aux_out=pre)])
         y = new(n, D)
-        _launch([_problem(n, D, Fh, [(act, Fh, wc2, Fh)], y, D, 0, 1, bias=bc2)])
+        if fp8:
+            gemm8(n, Fh, D, x1, wc1, bc1, act, L.EPI_GELU, pre)
+            gemm8(n, D, Fh, act, wc2, bc2, y)
+        else:
+            _launch([_problem(n, Fh, D, [(x1, D, wc1, D)], act, Fh, 0, 1, bias=bc1, epi=L.EPI_GELU, aux_out=pre)])
+            _launch([_problem(n, D, Fh, [(act, Fh, wc2, Fh)], y, D, 0, 1, bias=bc2)])
         out, xhat2, rstd2 = new(n, D), new(n, D), new(n)
         L.check(lib.dpn_add_ln_fwd(_p(x1), _p(y), _p(g2), _p(be2), n, _p(out), _p(xhat2), _p(rstd2), _s()), 'dpn_add_ln_fwd')
         ctx.save_for_backward(x, q, k, v, o, P, x1, pre, act, xhat1, rstd1, xhat2, rstd2, wq, wk, wv, wo, wc1, wc2, g1, g2)

@@ -278,6 +278,13 @@ int dpn_clip_adam_flat_dev(int n_tensors, float* const* params, const float* con
                            float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, const float* hyper_dev, float* out_norm_dev,
                            void* stream);
 
+/* BASELINE configs[4] experiment (OFF in the product; DPN_ENCODER_FP8=1 routes the encoder layers' forward GEMMs here): C[M][N] =
+ * epilogue(A[M][K] . W[N][K]^T + bias[N]) on the fp8 matrix cores (OCP e4m3 operands quantised in the kernel with one scale per row of A
+ * and per row of W, fp32 accumulate); K a multiple of 16, lda / ldw multiples of 4; epi = DPN_EPI_NONE or DPN_EPI_GELU (aux_out
+ * receives the pre-activation).  Replaces nothing of the reference by default: its measured parity error is why. */
+int dpn_gemm_fp8(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int epi,
+                 float* aux_out, void* stream);
+
 /* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
 int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);
 

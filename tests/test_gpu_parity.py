@@ -911,3 +911,34 @@ def test_variable_net_standalone_forward_matches_oracle():
     net.zero_grad(set_to_none=True)
     out.sum().backward()
     assert net.out_fc.weight.grad is not None and bool(torch.isfinite(net.out_fc.weight.grad).all())
+
+
+def test_fp8_gemm_experiment_kernel_matches_its_definition():
+    """configs[4] experiment kernel (csrc/dpn_fp8.hip, off in the product): C = s_a s_w q(A / s_a) q(W / s_w)^T + bias with one scale per
+    row and OCP e4m3 operands -- against the same definition written with torch's float8_e4m3fn casts; and its distance from the exact
+    product, which is why the product does not use it (a few percent)."""
+    import ctypes
+    from deepphysinet_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    torch.manual_seed(0)
+    for M, N, K, epi in ((287, 256, 256, 0), (1000, 256, 256, 1), (64, 96, 32, 0)):
+        A = torch.randn(M, K, device=dev) * 1.7
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        bias = torch.randn(N, device=dev) * 0.1
+        C = torch.empty(M, N, device=dev)
+        pre = torch.empty(M, N, device=dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        assert lib.dpn_gemm_fp8(M, N, K, p(A), K, p(W), K, p(bias), p(C), N, epi, p(pre) if epi else None, torch.cuda.current_stream().cuda_stream) == 0
+        sa = A.abs().amax(dim=1, keepdim=True).clamp_min(1e-30) * (1.0 / 448.0)
+        sw = W.abs().amax(dim=1, keepdim=True).clamp_min(1e-30) * (1.0 / 448.0)
+        qa = (A * (1.0 / sa)).to(torch.float8_e4m3fn).float()
+        qw = (W * (1.0 / sw)).to(torch.float8_e4m3fn).float()
+        want = (qa @ qw.t()) * sa * sw.t() + bias
+        exact = A @ W.t() + bias
+        if epi:
+            assert float((pre - want).abs().max() / want.abs().max()) < 2e-3
+            want, exact = torch.nn.functional.gelu(want), torch.nn.functional.gelu(exact)
+        assert float((C - want).abs().max() / want.abs().max()) < 2e-3, (M, N, K)          # same quantised operands, other summation order / rounding ties
+        err = float((C - exact).abs().max() / exact.abs().max())
+        assert 1e-3 < err < 0.2, err                                                       # the fp8 operand rounding itself: percent level
