@@ -141,7 +141,10 @@ def main():
 
     from deepphysinet_amd import distributed as D
     # DPN_BENCH_BACKEND=gloo + DPN_BENCH_ONE_DEVICE=1: exercise the N > 1 code path with every rank on GPU 0 (test boxes have one GPU)
-    rank, world, local = D.init_from_env(os.environ.get('DPN_BENCH_BACKEND'))
+    # DPN_BENCH_RCCL_ONE_RANK=1: a one-rank RCCL group + the N > 1 step shape (segment graphs, bucket all-reduces): the real collective
+    # calls, their interplay with hipGraph capture and replay, on a single-GPU box
+    one_rank_rccl = os.environ.get('DPN_BENCH_RCCL_ONE_RANK') == '1' and args.gpus == 1
+    rank, world, local = D.init_from_env(os.environ.get('DPN_BENCH_BACKEND'), force=one_rank_rccl)
     if os.environ.get('DPN_BENCH_ONE_DEVICE') == '1':
         local = 0
     if not torch.cuda.is_available():
@@ -169,7 +172,7 @@ def main():
         del many
     crit = torch.nn.MSELoss()
     # N > 1 (or DPN_BENCH_SPLIT_STEP=1 on one GPU, to time the same code path): three graph segments with a bucket all-reduce behind each
-    split_step = (world > 1 or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1') and args.leads == 1
+    split_step = (world > 1 or one_rank_rccl or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1') and args.leads == 1
 
     def make_step(m, opt):
         """One GPU: [whole] = zero_grad + place_one_batch + backward + clip + Adam, one callable (one hipGraph).
@@ -202,7 +205,7 @@ def main():
         m, opt = build(prec)
         if world > 1:
             D.broadcast_parameters(m.physics_net)      # DDP's wrap-time broadcast (the seeds already agree; this makes it a fact)
-        sync = D.GradientAllReduce(opt) if world > 1 else None
+        sync = D.GradientAllReduce(opt, single_rank_too=one_rank_rccl) if (world > 1 or one_rank_rccl) else None
         segments, staged = make_step(m, opt)
         n_reduce = len(segments) - 1 if split_step else 0     # segment i completes gradient bucket i; the last segment is the optimiser
 
@@ -227,7 +230,8 @@ def main():
                 graphs, pool = [], None
                 for seg in segments:                  # one capture stream (torch's default) and one memory pool for all segments:
                     g = torch.cuda.CUDAGraph()        # the autograd graph built in segment 0 is walked in segments 1 and 2
-                    with torch.cuda.graph(g, pool=pool):
+                    # thread_local: the process group's watchdog thread queries events while we capture
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local' if sync is not None else 'global'):
                         seg()
                     pool = g.pool()
                     graphs.append(g)
@@ -237,7 +241,7 @@ def main():
                 graphs = None
                 torch.cuda.synchronize()
                 m, opt = build(prec)
-                sync = D.GradientAllReduce(opt) if world > 1 else None
+                sync = D.GradientAllReduce(opt, single_rank_too=one_rank_rccl) if (world > 1 or one_rank_rccl) else None
                 segments, staged = make_step(m, opt)
         if graphs is None:
             fn = eager
@@ -416,7 +420,7 @@ def main():
                                    'shared_jacobian_variant': {'value': v2, 'seconds_per_pass': secs2,
                                                                'note': 'same oracle, the 18 distinct derivatives taken once (SURVEY 8d variant ii)'}}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or one_rank_rccl:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

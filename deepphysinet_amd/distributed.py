@@ -17,13 +17,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, force=False):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank).
+    force: create the process group even for one rank (a single-GPU box can then run the real RCCL calls of the N > 1 path)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # this pool's driver only supports dmabuf IPC (RCCL needs it)
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -50,15 +52,16 @@ def _all_reduce_mean(flat, world, group, async_op):
 
 
 class GradientAllReduce:
-    def __init__(self, optimizer=None, bucket_mb=32.0, group=None):
+    def __init__(self, optimizer=None, bucket_mb=32.0, group=None, single_rank_too=False):
         self.opt = optimizer
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
         self.group = group
         self._work = []
         self._checked = False
+        self.single_rank_too = single_rank_too        # run the collectives even in a one-rank group (exercises RCCL on a single-GPU box)
 
     def active(self):
-        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.single_rank_too)
 
     # ---- flat path (the optimiser owns the gradient buffer) ------------------------------------------------------------
     def _check_layout(self):

@@ -262,6 +262,25 @@ def test_bench_starts_its_own_ranks():
     assert out['value'] > 0 and np.isfinite(out['ms_per_step'])
 
 
+def test_bench_step_with_rccl_collectives_on_one_rank():
+    """The N > 1 step shape (three segment graphs, an in-place bucket all-reduce behind each, the optimiser graph) with the REAL backend
+    ('nccl' = RCCL) in a one-rank group: the collective calls, ReduceOp.AVG, and their interplay with hipGraph capture / replay and the
+    process group's watchdog thread -- everything of `bench.py --gpus N` a one-GPU box can run.  The loss equals the one-graph step's."""
+    env = dict(os.environ, DPN_BENCH_RCCL_ONE_RANK='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'DPN_BENCH_BACKEND', 'DPN_BENCH_ONE_DEVICE'):
+        env.pop(k, None)
+    outs = []
+    for e in (env, {k: v for k, v in env.items() if k != 'DPN_BENCH_RCCL_ONE_RANK'}):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--points', '4096',
+                            '--no-cpu-baseline', '--no-alt'], env=e, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]))
+    assert outs[0]['config']['step_segments'] == 4 and outs[1]['config']['step_segments'] == 1
+    for k, b in outs[1]['pde_losses'].items():                            # after the same seven optimiser steps
+        a = outs[0]['pde_losses'][k]
+        assert np.isfinite(a) and abs(a - b) <= 1e-5 * abs(b), (k, a, b)
+
+
 def test_run_train_interface_drives_steps_and_resumes(tmp_path):
     """The reference's train.py calls run_train_interface(checkpoint_path=..., log_path=...) (train.py:47): three steps through the loop
     (data loss only, then PDE losses on), an epoch-end checkpoint + schedule step, and a resume from physics_latest.pth."""
