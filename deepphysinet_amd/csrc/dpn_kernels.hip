@@ -24,6 +24,7 @@
 // No kernel in this file uses atomics: every reduction is fixed-order, the whole step is bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/dpn_hip.h"
@@ -84,12 +85,11 @@ DEV void frag_set2(Frag<NS>& f, const int p, float a, float b) {      // element
     if constexpr (NS == 2) f.w[1][p] = pack2(a - bf_lo(hi), b - bf_hi(hi));
 }
 
-// max(x, 0) as ONE v_max_f32: fmaxf() makes hipcc canonicalise its operand first (an extra v_max x,x per element on MFMA results)
-DEV float relu1(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
+// (max(x, 0) used to be ONE inline-asm v_max_f32 here -- fmaxf() makes hipcc canonicalise its operand first, an extra v_max x,x per
+//  element.  Inline asm is invisible to the compiler's hazard recogniser: when the scheduler made that v_max the FIRST reader of an MFMA
+//  result, no wait states were inserted and it read the accumulator before the matrix core had written it (3 % errors in the hi+lo mode,
+//  depending on unrelated code around it).  The ReLU is now a select on the compare that builds the mask bit; tools/mfma_hazard_check.py
+//  scans the generated assembly for any inline-asm reader of a fresh MFMA result.)
 
 DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
@@ -239,6 +239,14 @@ DEV void dma16_nt(const char* gsrc_lane, char* lds_wave_base) {       // read-on
 DEV void dma4(const char* gsrc_lane, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 4, 0, 0);
+}
+// v_writelane with the lane as an inline constant (one SGPR operand per VALU instruction on gfx9: the word takes it).  `pos` is a
+// compile-time constant after unrolling: the switch folds to one instruction.
+DEV void writelane_at(u32& v, const u32 word, const int pos) {
+    switch (pos) {
+        case 0: asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(word)); break; case 1: asm volatile("v_writelane_b32 %0, %1, 1" : "+v"(v) : "s"(word)); break; case 2: asm volatile("v_writelane_b32 %0, %1, 2" : "+v"(v) : "s"(word)); break; case 3: asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(v) : "s"(word)); break; case 4: asm volatile("v_writelane_b32 %0, %1, 4" : "+v"(v) : "s"(word)); break; case 5: asm volatile("v_writelane_b32 %0, %1, 5" : "+v"(v) : "s"(word)); break; case 6: asm volatile("v_writelane_b32 %0, %1, 6" : "+v"(v) : "s"(word)); break; case 7: asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(v) : "s"(word)); break; case 8: asm volatile("v_writelane_b32 %0, %1, 8" : "+v"(v) : "s"(word)); break; case 9: asm volatile("v_writelane_b32 %0, %1, 9" : "+v"(v) : "s"(word)); break; case 10: asm volatile("v_writelane_b32 %0, %1, 10" : "+v"(v) : "s"(word)); break; case 11: asm volatile("v_writelane_b32 %0, %1, 11" : "+v"(v) : "s"(word)); break; case 12: asm volatile("v_writelane_b32 %0, %1, 12" : "+v"(v) : "s"(word)); break; case 13: asm volatile("v_writelane_b32 %0, %1, 13" : "+v"(v) : "s"(word)); break; case 14: asm volatile("v_writelane_b32 %0, %1, 14" : "+v"(v) : "s"(word)); break; case 15: asm volatile("v_writelane_b32 %0, %1, 15" : "+v"(v) : "s"(word)); break; case 16: asm volatile("v_writelane_b32 %0, %1, 16" : "+v"(v) : "s"(word)); break; case 17: asm volatile("v_writelane_b32 %0, %1, 17" : "+v"(v) : "s"(word)); break; case 18: asm volatile("v_writelane_b32 %0, %1, 18" : "+v"(v) : "s"(word)); break; case 19: asm volatile("v_writelane_b32 %0, %1, 19" : "+v"(v) : "s"(word)); break; case 20: asm volatile("v_writelane_b32 %0, %1, 20" : "+v"(v) : "s"(word)); break; case 21: asm volatile("v_writelane_b32 %0, %1, 21" : "+v"(v) : "s"(word)); break; case 22: asm volatile("v_writelane_b32 %0, %1, 22" : "+v"(v) : "s"(word)); break; case 23: asm volatile("v_writelane_b32 %0, %1, 23" : "+v"(v) : "s"(word)); break; case 24: asm volatile("v_writelane_b32 %0, %1, 24" : "+v"(v) : "s"(word)); break; case 25: asm volatile("v_writelane_b32 %0, %1, 25" : "+v"(v) : "s"(word)); break; case 26: asm volatile("v_writelane_b32 %0, %1, 26" : "+v"(v) : "s"(word)); break; case 27: asm volatile("v_writelane_b32 %0, %1, 27" : "+v"(v) : "s"(word)); break; case 28: asm volatile("v_writelane_b32 %0, %1, 28" : "+v"(v) : "s"(word)); break; case 29: asm volatile("v_writelane_b32 %0, %1, 29" : "+v"(v) : "s"(word)); break; case 30: asm volatile("v_writelane_b32 %0, %1, 30" : "+v"(v) : "s"(word)); break; case 31: asm volatile("v_writelane_b32 %0, %1, 31" : "+v"(v) : "s"(word)); break; case 32: asm volatile("v_writelane_b32 %0, %1, 32" : "+v"(v) : "s"(word)); break; case 33: asm volatile("v_writelane_b32 %0, %1, 33" : "+v"(v) : "s"(word)); break; case 34: asm volatile("v_writelane_b32 %0, %1, 34" : "+v"(v) : "s"(word)); break; case 35: asm volatile("v_writelane_b32 %0, %1, 35" : "+v"(v) : "s"(word)); break; case 36: asm volatile("v_writelane_b32 %0, %1, 36" : "+v"(v) : "s"(word)); break; case 37: asm volatile("v_writelane_b32 %0, %1, 37" : "+v"(v) : "s"(word)); break; case 38: asm volatile("v_writelane_b32 %0, %1, 38" : "+v"(v) : "s"(word)); break; case 39: asm volatile("v_writelane_b32 %0, %1, 39" : "+v"(v) : "s"(word)); break; case 40: asm volatile("v_writelane_b32 %0, %1, 40" : "+v"(v) : "s"(word)); break; case 41: asm volatile("v_writelane_b32 %0, %1, 41" : "+v"(v) : "s"(word)); break; case 42: asm volatile("v_writelane_b32 %0, %1, 42" : "+v"(v) : "s"(word)); break; case 43: asm volatile("v_writelane_b32 %0, %1, 43" : "+v"(v) : "s"(word)); break; case 44: asm volatile("v_writelane_b32 %0, %1, 44" : "+v"(v) : "s"(word)); break; case 45: asm volatile("v_writelane_b32 %0, %1, 45" : "+v"(v) : "s"(word)); break; case 46: asm volatile("v_writelane_b32 %0, %1, 46" : "+v"(v) : "s"(word)); break; case 47: asm volatile("v_writelane_b32 %0, %1, 47" : "+v"(v) : "s"(word)); break; case 48: asm volatile("v_writelane_b32 %0, %1, 48" : "+v"(v) : "s"(word)); break; case 49: asm volatile("v_writelane_b32 %0, %1, 49" : "+v"(v) : "s"(word)); break; case 50: asm volatile("v_writelane_b32 %0, %1, 50" : "+v"(v) : "s"(word)); break; case 51: asm volatile("v_writelane_b32 %0, %1, 51" : "+v"(v) : "s"(word)); break; case 52: asm volatile("v_writelane_b32 %0, %1, 52" : "+v"(v) : "s"(word)); break; case 53: asm volatile("v_writelane_b32 %0, %1, 53" : "+v"(v) : "s"(word)); break; case 54: asm volatile("v_writelane_b32 %0, %1, 54" : "+v"(v) : "s"(word)); break; case 55: asm volatile("v_writelane_b32 %0, %1, 55" : "+v"(v) : "s"(word)); break; case 56: asm volatile("v_writelane_b32 %0, %1, 56" : "+v"(v) : "s"(word)); break; case 57: asm volatile("v_writelane_b32 %0, %1, 57" : "+v"(v) : "s"(word)); break; case 58: asm volatile("v_writelane_b32 %0, %1, 58" : "+v"(v) : "s"(word)); break; case 59: asm volatile("v_writelane_b32 %0, %1, 59" : "+v"(v) : "s"(word)); break; case 60: asm volatile("v_writelane_b32 %0, %1, 60" : "+v"(v) : "s"(word)); break; case 61: asm volatile("v_writelane_b32 %0, %1, 61" : "+v"(v) : "s"(word)); break; case 62: asm volatile("v_writelane_b32 %0, %1, 62" : "+v"(v) : "s"(word)); break; case 63: asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(v) : "s"(word)); break;
+        default: break;
+    }
 }
 template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -535,7 +543,7 @@ DEV void store_tile_k(const KMat& m, int net, int64_t tile32, int ct, const Lane
 // saved-state / operand addressing ---------------------------------------------------------------------------
 struct SavedView {       // written by dpn_fwd
     KMat V, T1;          // [6][NS] x 256 columns
-    KMat M2;             // [6][1]  x 256 columns, relu-2 mask as bf16 0/1
+    u32* m2t;            // [6][tiles32][256] relu-2 mask, one word per row of the K layout (slot order), bit p = point p of the tile
     uint4* m1;           // [6][tiles32][64] lane-format bits of relu mask 1
 };
 DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
@@ -545,11 +553,11 @@ DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
     const int64_t tiles32 = n_pad / 32;
     s.V = KMat{b, tiles32, 8};
     s.T1 = KMat{b + mat, tiles32, 8};
-    s.M2 = KMat{b + 2 * mat, tiles32, 8};
-    s.m1 = reinterpret_cast<uint4*>(b + 2 * mat + (int64_t)kNets * n_pad * 512);
+    s.m2t = reinterpret_cast<u32*>(b + 2 * mat);
+    s.m1 = reinterpret_cast<uint4*>(b + 2 * mat + (int64_t)kNets * n_pad * 32);
     return s;
 }
-static int64_t saved_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 512 + (int64_t)kNets * n_pad * 32; }
+static int64_t saved_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 32 + (int64_t)kNets * n_pad * 32; }
 
 struct OperandView {     // written by dpn_bwd_points
     KMat Z1, Z;          // [6][NS] x 256
@@ -646,6 +654,9 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 
     f32x16 acc[8];
     u32 m1w[4] = {0u, 0u, 0u, 0u};
+    u32 m2w = 0u;          // relu-2 mask words of two 32-channel tiles: lane 32 (T & 1) + row of the K layout, bit p = point p
+    // padding points carry zero bits (both halves of the wave hold the same 32 points); readfirstlane: wave-uniform for the compiler too
+    const u32 m2valid = (u32)__builtin_amdgcn_readfirstlane((int)(partial ? (u32)__builtin_amdgcn_ballot_w64(L.valid) : ~0u));
     Frag<NS> actA[16], actB[16];
 
     // ---------------- L1: pre1 = w1 . pe + b1 ; h1 = relu -> actA ; relu mask -> m1w
@@ -653,8 +664,9 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const float p0 = acc[T][r], p1 = acc[T][r + 1];
-            m1w[T >> 1] |= ((p0 > 0.f) ? (1u << (16 * (T & 1) + r)) : 0u) | ((p1 > 0.f) ? (2u << (16 * (T & 1) + r)) : 0u);
-            frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, relu1(p0), relu1(p1));
+            const bool on0 = p0 > 0.f, on1 = p1 > 0.f;
+            m1w[T >> 1] |= (on0 ? (1u << (16 * (T & 1) + r)) : 0u) | (on1 ? (2u << (16 * (T & 1) + r)) : 0u);
+            frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, on0 ? p0 : 0.f, on1 ? p1 : 0.f);
         }
         // pin the mask word HERE: left alone, the scheduler postpones the compares to the first use of m1w (after fc1) and keeps the
         // tile's 16 pre-activations alive until then -- in AGPRs for bf16, in SCRATCH for the hi+lo mode, whose reloads drain the DMA ring
@@ -717,7 +729,6 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     const float const0 = lds_read_f32(lds_vec + kNumVecs * 256 * 4);
     float adot = 0.f;
     auto epi3 = [&](const int T) __attribute__((always_inline)) {
-        Frag<1> mk0, mk1;
         Vec16 uv;
         lds_read_vec16(uv, vec_addr(lds_vec, kVecU, h, T));
 #pragma unroll
@@ -732,16 +743,23 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
                 adot = fmaf(p0, t0, adot);                                           // relu(p) * u == p * (m2 * u): no separate max
                 adot = fmaf(p1, t1, adot);
                 frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, t0, t1);
-                const u32 mw = (on0 ? 0x3F80u : 0u) | (on1 ? 0x3F800000u : 0u);
-                if (r < 8) mk0.w[0][(r & 7) >> 1] = mw; else mk1.w[0][(r & 7) >> 1] = mw;
+                {   // (unconditional: a branch here would cut the epilogue into blocks the scheduler cannot fold under the MFMAs)
+                    // the compare's lane mask IS the saved word: its low half = channel 32 T + drow32(r, 0) over the tile's 32 points,
+                    // its high half = channel 32 T + drow32(r, 1); the channel's row of the K layout is 32 T + 16 (r >> 3) + 8 h + (r & 7)
+                    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(on0), b1 = __builtin_amdgcn_ballot_w64(on1);
+                    const int base = 32 * (T & 1) + 16 * (r >> 3) + (r & 7);
+                    writelane_at(m2w, (u32)b0 & m2valid, base);
+                    writelane_at(m2w, (u32)(b0 >> 32) & m2valid, base + 8);
+                    writelane_at(m2w, (u32)b1 & m2valid, base + 1);
+                    writelane_at(m2w, (u32)(b1 >> 32) & m2valid, base + 9);
+                }
             }
         }
-        // pin t2 and the mask words in VGPRs HERE: left alone, the scheduler keeps the 128 compare results as lane masks in SGPRs
-        // (spilling them through v_writelane / v_readlane) and materialises every select in one 1000-instruction block after the GEMM
+        // pin t2 in VGPRs HERE: left alone, the scheduler keeps the 128 compare results as lane masks in SGPRs (spilling them through
+        // v_writelane / v_readlane) and materialises every select in one 1000-instruction block after the GEMM
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) asm volatile("" : "+v"(actA[2 * T].w[s2]), "+v"(actA[2 * T + 1].w[s2]));
-        asm volatile("" : "+v"(mk0.w[0]), "+v"(mk1.w[0]));
-        if (save) store_tile_k<1, 1>(sv.M2, net, tile32, T, L, mk0, mk1, partial);
+        if (save && (T & 1)) sv.m2t[((int64_t)net * (a.n_pad / 32) + tile32) * 256 + 32 * (T - 1) + L.lane] = m2w;   // 256 B per two tiles
     };
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
@@ -1122,12 +1140,12 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 #if DPN_HAS_REST
 // ------------------------------------------------------------------------------------------------ backward, stage 2
 // Points-reduction GEMMs  D[so][si] = sum_pt X[pt][so] * Y[pt][si]  for the four products of a net:
-//   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q = Z^T 1
+//   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q = Z^T 1      (M2: the relu-2 mask, saved as bit words, expanded in registers)
 //   P1: dw2  = V^T  Z1   (256x256)  + gcvec = V^T g, sum g
 //   P2: dWd  = V^T  G6   (256x192)
 //   P3: dw1  = T1^T Z0   (256x192)  + db1 = T1^T g
-// grid = (k_splits, 4 products, 6 nets); each workgroup owns the whole output of its product for its range of 32-point
-// tiles.  Operands are already MFMA fragments in global memory (K-layout): every wave loads its A/B fragments straight
+// grid = (sum of the four products' split counts, 6 nets); each workgroup owns the whole output of its product for its range of
+// 32-point tiles (the products move different numbers of bytes per tile, so they are cut into different numbers of ranges: SplitPlan).  Operands are already MFMA fragments in global memory (K-layout): every wave loads its A/B fragments straight
 // into registers, one 16-byte load per fragment, no LDS, no barrier; the next k-step's loads are in flight under the MFMAs.
 constexpr int kPartFloats = 65536 * 2 + 49152 * 2 + 5 * 256;       // per (split, net)
 DPN_HD int part_off(int prod) { return prod == 0 ? 0 : prod == 1 ? 65536 : prod == 2 ? 131072 : 180224; }
@@ -1135,11 +1153,19 @@ constexpr int kPartVec = 229376;                                    // mvec, q, 
 
 struct WgradArgs {
     int64_t n, n_pad;
-    int k_splits;
+    int splits[4];          // point ranges per product (SplitPlan)
     void* saved;
     void* operands;
     float* partials;
+#ifdef DPN_WGRAD_PHASES
+    unsigned* phases;       // experiment build: [net][workgroup][8 waves][8]: cycles in wait / barrier / issue / compute, tiles
+#endif
 };
+#ifdef DPN_WGRAD_PHASES
+#define DPN_WG_CLOCK(V) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); V = (u32)t_; } while (0)
+#else
+#define DPN_WG_CLOCK(V) do { } while (0)
+#endif
 
 
 // one workgroup = 8 waves (2 x 4): wave (wm, wn) owns rows 128wm.. and columns 64wn.. of the product.  The X and Y fragments
@@ -1153,11 +1179,13 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     constexpr int RING = (NS == 1) ? 4 : 2;
     constexpr int PER_TILE = NS * 4 + 1;                               // DMA instructions per wave per tile
     __shared__ __attribute__((aligned(16))) char lds[RING * kSlot];
-    const int prod = blockIdx.y, net = blockIdx.z;
+    int prod = 0, split = blockIdx.x;                                   // workgroup -> (product, point range): uniform scalar walk
+    while (prod < 3 && split >= a.splits[prod]) { split -= a.splits[prod]; ++prod; }
+    const int net = blockIdx.y;
     const int ncol = prod < 2 ? 256 : 192, nct = ncol / 32;
     const int64_t tiles = a.n_pad / 32;
-    const int64_t per = (tiles + a.k_splits - 1) / a.k_splits;
-    const int64_t t0 = (int64_t)blockIdx.x * per;
+    const int64_t per = (tiles + a.splits[prod] - 1) / a.splits[prod];
+    const int64_t t0 = (int64_t)split * per;
     int64_t t1 = t0 + per < tiles ? t0 + per : tiles;
     if (t1 < t0) t1 = t0;
 
@@ -1167,7 +1195,7 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     const bool active = wn * 2 < nct;                                   // 192-column products leave the wn = 3 waves idle
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
-    const char* xb = (prod == 0) ? sv.M2.base : (prod == 3) ? sv.T1.base : sv.V.base;           // 8 column tiles
+    const char* xb = (prod == 3) ? sv.T1.base : sv.V.base;                                      // 8 column tiles (product 0: the mask words)
     const char* yb = (prod == 0) ? ov.Z.base : (prod == 1) ? ov.Z1.base : (prod == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
     const int nsx = (prod == 0) ? 1 : NS;                               // the 0/1 mask has no lo part
     const float* gnet = ov.gnet + (int64_t)net * a.n_pad;
@@ -1175,6 +1203,9 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
 
     // every wave issues PER_TILE DMA instructions per tile: piece q = wave + 8*j of the (X s=0.., Y s=0..) image, + its own g copy.
     // Pieces beyond the image (192-column Y, mask without lo part) re-read a valid piece into a dummy LDS area (uniform count).
+    // (Letting only the four waves with wm == tile & 1 issue a tile -- twice the pieces each, in the shadow of their SIMD partners'
+    //  MFMAs -- was measured: the issue phase shrinks from 1 900 to 1 100 cycles per tile and the barrier wait grows by as much,
+    //  360 us against 364 us in the hi+lo mode: at 4.8 TB/s the kernel sits on the HBM stream, not on its issue slots.  Not kept.)
     auto issue = [&](int64_t tile, int slot) __attribute__((always_inline)) {
         char* sl = lds + slot * kSlot;
 #pragma unroll
@@ -1187,6 +1218,8 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                 const int sx = s2 < nsx ? s2 : 0;
                 src = xb + (((int64_t)net * nsx + sx) * tiles + tile) * xbytes + r * 1024;
                 dst = sl + s2 * 16384 + r * 1024;
+                // product 0: 1 KB of mask words per tile -- piece 0 is real, the other X pieces re-read it into the rest of the X area
+                if (prod == 0) src = reinterpret_cast<const char*>(sv.m2t) + ((int64_t)net * tiles + tile) * 1024;
             } else {
                 const int ry = (r - 16) * 1024 < ybytes ? (r - 16) : 0;
                 src = yb + (((int64_t)net * NS + s2) * tiles + tile) * ybytes + ry * 1024;
@@ -1225,6 +1258,13 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                 for (int n2 = 0; n2 < 2; ++n2) rd128(fba[b][s2][n2], buf + NS * 16384 + s2 * 16384 + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
             }
         };
+        // product 0: the X operand is the relu-2 mask, saved as one word per row (bit p = point p of the tile, 1 KB per tile instead of a
+        // 16-KB bf16 image): the lane's four rows' words are read FIRST (older than every counted read below) and expanded to 0 / 1
+        // fragments after the wait; the X reads below then fetch unused bytes
+        // (read for every product, four words: a branch here would leave the registers with two definitions, one of them pending)
+        u32 mw[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) asm volatile("ds_read_b32 %0, %1" : "=v"(mw[m]) : "v"(buf + (32 * (wm * 4 + m) + i) * 4) : "memory");
         if constexpr (NS == 1) { issue_reads(0, 0); issue_reads(1, 1); }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1247,6 +1287,19 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
                              "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
                              "+v"(fb[1][0]), "+v"(fb[1][1]) :: "memory");
+            }
+            asm volatile("" : "+v"(mw[0]), "+v"(mw[1]), "+v"(mw[2]), "+v"(mw[3]));          // behind the wait (volatile asm keeps its order)
+            if (prod == 0) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    // fragment element e = point drow32(8 kk + e, h) = 16 kk + 4 h + {0, 1, 2, 3, 8, 9, 10, 11}[e]
+                    const int x = (int)(mw[m] >> (16 * kk + 4 * h));
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int o = (p & 1) * 2 + (p >> 1) * 8;
+                        fa[0][m][p] = ((u32)__builtin_amdgcn_sbfe(x, o, 1) & 0x3F80u) | ((u32)__builtin_amdgcn_sbfe(x, o + 1, 1) & 0x3F800000u);
+                    }
+                }
             }
             const float gp[8] = {__uint_as_float(gq0[0]), __uint_as_float(gq0[1]), __uint_as_float(gq0[2]), __uint_as_float(gq0[3]),
                                  __uint_as_float(gq1[0]), __uint_as_float(gq1[1]), __uint_as_float(gq1[2]), __uint_as_float(gq1[3])};
@@ -1295,20 +1348,37 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < RING - 1; ++r) issue(t0 + r < t1 ? t0 + r : tl, r);
     int slot = 0;
+#ifdef DPN_WGRAD_PHASES
+    u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, ph_wait = 0, ph_bar = 0, ph_issue = 0, ph_comp = 0;
+#endif
     for (int64_t tile = t0; tile < t1; ++tile) {
+        DPN_WG_CLOCK(c0);
         wait_vmcnt<(RING - 2) * PER_TILE>();                             // this wave's pieces of `tile` have landed
+        DPN_WG_CLOCK(c1);
         __builtin_amdgcn_s_barrier();                                    // ... and everybody else's; and compute(tile-1) is finished everywhere
+        DPN_WG_CLOCK(c2);
         {
             const int64_t nt = tile + RING - 1;
             issue(nt < t1 ? nt : tl, (slot + RING - 1) % RING);          // refill the slot that compute(tile-1) just released
         }
+        DPN_WG_CLOCK(c3);
         if (active) compute(slot);
+        DPN_WG_CLOCK(c4);
+#ifdef DPN_WGRAD_PHASES
+        ph_wait += c1 - c0; ph_bar += c2 - c1; ph_issue += c3 - c2; ph_comp += c4 - c3;
+#endif
         slot = (slot + 1) % RING;
     }
+#ifdef DPN_WGRAD_PHASES
+    if (a.phases && lane == 0) {
+        unsigned* o = a.phases + (((int64_t)net * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        o[0] = ph_wait; o[1] = ph_bar; o[2] = ph_issue; o[3] = ph_comp; o[4] = (unsigned)(t1 - t0); o[5] = prod;
+    }
+#endif
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     // ---- write this split's partial sums: natural [row slot][col] order
-    float* part = a.partials + ((int64_t)blockIdx.x * kNets + net) * kPartFloats;
+    float* part = a.partials + ((int64_t)split * kNets + net) * kPartFloats;
     float* out = part + part_off(prod);
     if (active) {
 #pragma unroll
@@ -1352,7 +1422,7 @@ struct FinishArgs {
     const char* packed;
     const float* partials;
     float* scratch_r;       // [6][256] r vector (lives in the partials buffer tail)
-    int k_splits, ns;
+    int splits[4], ns;      // point ranges per product, as dpn_wgrad_kernel cut them
     int64_t n;
 };
 
@@ -1371,24 +1441,25 @@ DEV int slot_of_pe6(int orig) {
     return 16 * ks + 8 * h + 2 * p + fn;
 }
 
-// NQ sums over the k_splits partial buffers, ALL their loads in flight at once (a loop of load -> wait -> add, which is what hipcc
-// makes of the obvious code, costs one HBM round trip per split and per sum: 40 in a row per thread).  Splits beyond k_splits re-read
-// the last one and are not added; the additions keep the split order, so the result does not depend on how the loads are grouped.
-constexpr int kMaxSplits = 10;                  // choose_splits() never returns more
+// NQ sums over the partial buffers of the point ranges (ks[q] of them for sum q: the count of the product that wrote it), ALL their
+// loads in flight at once (a loop of load -> wait -> add, which is what hipcc makes of the obvious code, costs one HBM round trip per
+// range and per sum: 40 in a row per thread).  Ranges beyond ks[q] re-read the last one and are not added; the additions keep the
+// range order, so the result does not depend on how the loads are grouped.
+constexpr int kMaxSplits = 12;                  // choose_plan() never returns more for one product
 template <int NQ>
-DEV void part_sums(const float* partials, int k_splits, int net, const int (&off)[NQ], float (&out)[NQ]) {
+DEV void part_sums(const float* partials, const int (&ks)[NQ], int net, const int (&off)[NQ], float (&out)[NQ]) {
     float v[kMaxSplits][NQ];
 #pragma unroll
     for (int k = 0; k < kMaxSplits; ++k) {
-        const float* base = partials + ((int64_t)min(k, k_splits - 1) * kNets + net) * kPartFloats;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) v[k][q] = __builtin_nontemporal_load(base + off[q]);   // read once
+        for (int q = 0; q < NQ; ++q)
+            v[k][q] = __builtin_nontemporal_load(partials + ((int64_t)min(k, ks[q] - 1) * kNets + net) * kPartFloats + off[q]);   // read once
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < kMaxSplits; ++k) t += (k < k_splits) ? v[k][q] : 0.f;
+        for (int k = 0; k < kMaxSplits; ++k) t += (k < ks[q]) ? v[k][q] : 0.f;
         out[q] = t;
     }
 }
@@ -1407,12 +1478,14 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
     // thread 0 also owns the row's three vector entries: fetched with everything else, not after the reduction
     float rowv[3] = {0.f, 0.f, 0.f};
     if (i == 0) {
-        const int offv[3] = {kPartVec + 0 * 256 + so, kPartVec + 2 * 256 + so, kPartVec + 3 * 256 + so};
-        part_sums<3>(a.partials, a.k_splits, net, offv, rowv);
+        const int offv[3] = {kPartVec + 0 * 256 + so, kPartVec + 2 * 256 + so, kPartVec + 3 * 256 + so};     // written by products 0, 1, 3
+        const int ksv[3] = {a.splits[0], a.splits[1], a.splits[3]};
+        part_sums<3>(a.partials, ksv, net, offv, rowv);
     }
     const int off2[2] = {part_off(0) + so * 256 + i, part_off(1) + so * 256 + si};      // Z's columns are in natural order (SWAP output)
     float g2[2];
-    part_sums<2>(a.partials, a.k_splits, net, off2, g2);
+    const int ks2[2] = {a.splits[0], a.splits[1]};
+    part_sums<2>(a.partials, ks2, net, off2, g2);
     const float Goi = g2[0];
     Gd.W1[o * 256 + i] = uo * Goi;
     red[i] = P.W1[o * 256 + i] * Goi;
@@ -1420,7 +1493,8 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
     if (i < kPe) {
         const int offp[2] = {part_off(2) + so * 192 + slot_of_pe6(i), part_off(3) + so * 192 + slot_of_pe3(i)};
         float gp[2];
-        part_sums<2>(a.partials, a.k_splits, net, offp, gp);
+        const int ksp[2] = {a.splits[2], a.splits[3]};
+        part_sums<2>(a.partials, ksp, net, offp, gp);
         Gd.Wd[o * kPe + i] = gp[0];
         Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[1];
     }
@@ -1448,8 +1522,9 @@ __global__ __launch_bounds__(256) void dpn_finish_fc2_kernel(FinishArgs a) {
     __shared__ float red[256];
     float sq[2] = {0.f, 0.f};
     if (o == 0) {
-        const int offv[2] = {kPartVec + 4 * 256, kPartVec + 1 * 256 + op};
-        part_sums<2>(a.partials, a.k_splits, net, offv, sq);
+        const int offv[2] = {kPartVec + 4 * 256, kPartVec + 1 * 256 + op};       // sum g: product 1; q: product 0
+        const int ksv[2] = {a.splits[1], a.splits[0]};
+        part_sums<2>(a.partials, ksv, net, offv, sq);
     }
     const float r = a.scratch_r[net * 256 + o];
     const float wop = P.wo[op];
@@ -2044,14 +2119,28 @@ __global__ void dpn_selftest_kernel(float* out) {
 // ------------------------------------------------------------------------------------------------ C ABI
 static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 #if DPN_HAS_REST
-static inline int choose_splits(int64_t n_pad) {
-    // 24 workgroups (4 products x 6 nets) per split and one 8-wave workgroup per CU (LDS ring): 10 splits = 240 workgroups is
-    // the largest single round on 256 CUs.  Measured at 37 265 points: 10 -> 19.3 M points/s, 11 -> 18.1 M (tail round),
-    // 21 -> 18.7 M (two rounds, twice the partials for dpn_finish_rows to reduce).
+// Point ranges per product.  One 8-wave workgroup per CU (the LDS ring fills it) and a kernel time that falls as 1 / workgroups up to
+// one round (measured, hi+lo mode, 37 265 points: 120 workgroups 671 us, 192 452 us, 240 396 us, 288 562 us -- the tail round), so
+// the plan fills one round of the 256 CUs: 42 workgroups per net, the two extra ranges going to the products that measured slowest
+// (dw2 = V^T Z1 and dw1 = T1^T Z0 in the hi+lo mode).  A cut in proportion to the bytes per tile (9 / 12 / 10 / 11) measured WORSE
+// than uniform: the time of a workgroup follows its number of tiles, not its bytes.  Uniform 10 x 4: 377 us, this plan 364 us
+// (hi+lo); 170 us against 168 us (single bf16) -- tools/wgrad_overlap_probe.py.
+struct SplitPlan { int s[4]; int most; };
+static inline SplitPlan choose_plan(int64_t n_pad, int ns) {
     int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
-    if (c > kMaxSplits) c = kMaxSplits;         // dpn_finish_* keep one load per split in flight
-    return (int)c;
+    SplitPlan p;
+    if (c >= 10) p = (ns == 2) ? SplitPlan{{10, 11, 10, 11}, 11} : SplitPlan{{11, 11, 10, 10}, 11};
+    else p = SplitPlan{{(int)c, (int)c, (int)c, (int)c}, (int)c};
+#ifdef DPN_EXPERIMENT_SPLITS                     // timing experiments only: DPN_WGRAD_PLAN="9,12,10,11"
+    if (const char* e = getenv("DPN_WGRAD_PLAN")) {
+        if (sscanf(e, "%d,%d,%d,%d", &p.s[0], &p.s[1], &p.s[2], &p.s[3]) == 4) {
+            p.most = 1;
+            for (int k = 0; k < 4; ++k) { if (p.s[k] < 1) p.s[k] = 1; if (p.s[k] > kMaxSplits) p.s[k] = kMaxSplits; if (p.s[k] > p.most) p.most = p.s[k]; }
+        }
+    }
+#endif
+    return p;
 }
 #endif  // DPN_HAS_REST
 static inline int ck(hipError_t e) { return (int)e; }
@@ -2068,7 +2157,7 @@ int dpn_sizes(int64_t n, int prec, DpnSizes* out) {
     out->packed = (int64_t)kNets * pack_bytes_per_net(prec);
     out->saved = saved_bytes(n_pad, prec);
     out->operands = operand_bytes(n_pad, prec);
-    out->k_splits = choose_splits(n_pad);
+    out->k_splits = choose_plan(n_pad, prec).most;
     out->partials = ((int64_t)out->k_splits * kNets * kPartFloats + kNets * 256) * 4;
     return 0;
 }
@@ -2161,13 +2250,21 @@ int dpn_bwd_points(const float* x, const float* y, const float* t, const float* 
 
 #endif  // DPN_HAS_POINT
 #if DPN_HAS_REST
+#ifdef DPN_WGRAD_PHASES
+static unsigned* g_wgrad_phases = nullptr;
+int dpn_debug_set_wgrad_phases(void* buf) { g_wgrad_phases = reinterpret_cast<unsigned*>(buf); return 0; }   // experiment build only, not in dpn_hip.h
+#endif
 int dpn_wgrad(int64_t n, int prec, const float* g_out, const void* saved, const void* operands, void* partials, void* stream) {
     if (!g_out || !saved || !operands || !partials || n <= 0 || (prec != 1 && prec != 2)) return -1;
-    WgradArgs a{n, pad_points(n), choose_splits(pad_points(n)), const_cast<void*>(saved), const_cast<void*>(operands),
+    const SplitPlan plan = choose_plan(pad_points(n), prec);
+    WgradArgs a{n, pad_points(n), {plan.s[0], plan.s[1], plan.s[2], plan.s[3]}, const_cast<void*>(saved), const_cast<void*>(operands),
                 reinterpret_cast<float*>(partials)};
+#ifdef DPN_WGRAD_PHASES
+    a.phases = g_wgrad_phases;
+#endif
     (void)g_out;   // the per-net cotangents were staged into `operands` by dpn_bwd_points
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid(a.k_splits, 4, kNets);
+    const dim3 grid(plan.s[0] + plan.s[1] + plan.s[2] + plan.s[3], kNets);
     if (prec == 1) hipLaunchKernelGGL(dpn_wgrad_kernel<1>, grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL(dpn_wgrad_kernel<2>, grid, dim3(512), 0, s, a);
     return ck(hipGetLastError());
@@ -2180,10 +2277,11 @@ int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_
     for (int k = 0; k < kNets; ++k) { a.net[k] = nets[k]; a.grad[k] = grads[k]; }
     a.packed = reinterpret_cast<const char*>(packed);
     a.partials = reinterpret_cast<const float*>(partials);
-    a.k_splits = choose_splits(pad_points(n));
+    const SplitPlan plan = choose_plan(pad_points(n), prec);
+    for (int k = 0; k < 4; ++k) a.splits[k] = plan.s[k];
     a.ns = prec;
     a.n = n;
-    a.scratch_r = const_cast<float*>(a.partials) + (int64_t)a.k_splits * kNets * kPartFloats;   // [6][256], tail of the partials buffer
+    a.scratch_r = const_cast<float*>(a.partials) + (int64_t)plan.most * kNets * kPartFloats;   // [6][256], tail of the partials buffer
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
     hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);

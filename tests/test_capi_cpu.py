@@ -139,8 +139,29 @@ def test_inline_asm_lds_reads_are_waited_for_before_any_use(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'lds_hazard_check.py'), asm, *kernels], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         assert r.stdout.count(' 0 hazards') == 2 * len(kernels), r.stdout
+        # ... and no inline-asm instruction is the first toucher of a fresh MFMA result (the hazard recogniser cannot see inside inline asm)
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'mfma_hazard_check.py'), asm, *kernels], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert r.stdout.count(' 0 of them touch') == 2 * len(kernels), r.stdout
         assert 's_swappc_b64' not in open(asm).read(), 'a helper was not inlined: the kernels must not make calls'
         checked += 1
+
+
+def test_mfma_hazard_checker_flags_inline_asm_on_a_fresh_accumulator(tmp_path):
+    """The second checker: an inline-asm instruction naming a register an MFMA wrote fewer than 12 wait states earlier is reported
+    (the inline-asm v_max_f32 ReLU of round 1 read accumulators before the matrix core had written them whenever the scheduler put it
+    first); the same instruction behind an s_nop 11, or a compiler-visible instruction in its place, passes."""
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'mfma_hazard_check.py')
+    body = ('_Z3badv:\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[34:37], v[182:185], v[2:17]\n%s'
+            '\t;;#ASMSTART\n\tv_max_f32 v0, 0, v2\n\t;;#ASMEND\n\ts_endpgm\n.Lfunc_end0:\n')
+    for filler, want in (('', 1), ('\ts_nop 11\n', 0), ('\ts_nop 3\n\tv_mov_b32_e32 v40, v41\n', 1)):
+        f = tmp_path / 'k.s'
+        f.write_text(body % filler)
+        r = subprocess.run([sys.executable, tool, str(f), 'bad'], capture_output=True, text=True)
+        assert r.returncode == want and (' %d of them touch' % want) in r.stdout, r.stdout
+    f.write_text('_Z3badv:\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[34:37], v[182:185], v[2:17]\n\tv_max_f32 v0, 0, v2\n\ts_endpgm\n.Lfunc_end0:\n')
+    r = subprocess.run([sys.executable, tool, str(f), 'bad'], capture_output=True, text=True)
+    assert r.returncode == 0                   # a visible instruction is the compiler's to protect
 
 
 def test_hazard_checker_flags_a_read_before_its_wait(tmp_path):
@@ -148,7 +169,9 @@ def test_hazard_checker_flags_a_read_before_its_wait(tmp_path):
     (lgkmcnt(N) leaves the N youngest outstanding) is modelled, and a clean stream passes."""
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'lds_hazard_check.py')
     bad = tmp_path / 'bad.s'
-    bad.write_text('_Z3badv:\n\tds_read_b128 v[0:3], v9\n\tds_read_b128 v[4:7], v9 offset:16\n\ts_waitcnt lgkmcnt(1)\n'
+    # (the compiler's own LDS operations -- the ds_bpermute outside the asm markers -- take a counter slot but are not tracked by register)
+    bad.write_text('_Z3badv:\n\t;;#ASMSTART\n\tds_read_b128 v[0:3], v9\n\tds_read_b128 v[4:7], v9 offset:16\n\t;;#ASMEND\n'
+                   '\tds_bpermute_b32 v12, v10, v11\n\tv_mov_b32_e32 v12, 0\n\ts_waitcnt lgkmcnt(2)\n'
                    '\tv_add_f32_e32 v8, v0, v1\n\tv_accvgpr_write_b32 a0, v5\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v8, v6\n\ts_endpgm\n.Lfunc_end0:\n')
     r = subprocess.run([sys.executable, tool, str(bad), 'bad'], capture_output=True, text=True)
     assert r.returncode == 1 and ' 1 hazards' in r.stdout and 'v_accvgpr_write_b32 a0, v5' in r.stdout, r.stdout

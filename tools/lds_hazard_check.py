@@ -15,7 +15,12 @@ that names a register whose ds_read has not been waited for.
     (DPN_TU=2 without the -mllvm flag for dpn_wgrad_kernel; tests/test_capi_cpu.py runs both)
 
 Control flow is ignored (the scan is linear), which is exact for the unrolled
-pipelines of these kernels: no ds_read is pending across a backward branch.
+pipelines of these kernels: no inline-asm ds_read is pending across a branch.
+Only the reads inside ;;#ASMSTART ... ;;#ASMEND are tracked by register: an LDS
+operation the compiler emitted itself (ds_bpermute of a shuffle, a visible
+ds_read) takes a slot of the counter, and its destination is the compiler's to
+wait for -- in the branchy epilogues a linear scan would pair such a read with
+code of another path.
 """
 import re
 import sys
@@ -41,7 +46,12 @@ def check(lines, name):
     hazards = 0
     n_reads = 0
     max_pending = 0
+    in_asm = False
     for no, raw in lines:
+        if ';;#ASMSTART' in raw:
+            in_asm = True
+        elif ';;#ASMEND' in raw:
+            in_asm = False
         ins = raw.split(';')[0].strip()
         if not ins or ins.endswith(':') or ins.startswith('.'):
             continue
@@ -61,10 +71,10 @@ def check(lines, name):
                 pending = []         # raw immediate: treat as a full wait only if the lgkm field is 0 (not emitted by this code base)
         elif LGKM.match(op):
             dst = set()
-            if op.startswith('ds_read') or op.startswith('ds_bpermute') or op.startswith('ds_permute') or op.startswith('ds_swizzle'):
+            if in_asm and op.startswith('ds_read'):
                 first = ins[len(op):].split(',')[0]
                 dst = regs_of(first)
-                n_reads += op.startswith('ds_read')
+                n_reads += 1
             pending.append(dst)
             max_pending = max(max_pending, len(pending))
     print(f'{name}: {n_reads} ds_read, at most {max_pending} LGKM operations in flight (the counter holds 15: issue stalls beyond), {hazards} hazards')
