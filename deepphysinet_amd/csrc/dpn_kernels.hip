@@ -240,14 +240,6 @@ DEV void dma4(const char* gsrc_lane, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc_lane),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 4, 0, 0);
 }
-// v_writelane with the lane as an inline constant (one SGPR operand per VALU instruction on gfx9: the word takes it).  `pos` is a
-// compile-time constant after unrolling: the switch folds to one instruction.
-DEV void writelane_at(u32& v, const u32 word, const int pos) {
-    switch (pos) {
-        case 0: asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(word)); break; case 1: asm volatile("v_writelane_b32 %0, %1, 1" : "+v"(v) : "s"(word)); break; case 2: asm volatile("v_writelane_b32 %0, %1, 2" : "+v"(v) : "s"(word)); break; case 3: asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(v) : "s"(word)); break; case 4: asm volatile("v_writelane_b32 %0, %1, 4" : "+v"(v) : "s"(word)); break; case 5: asm volatile("v_writelane_b32 %0, %1, 5" : "+v"(v) : "s"(word)); break; case 6: asm volatile("v_writelane_b32 %0, %1, 6" : "+v"(v) : "s"(word)); break; case 7: asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(v) : "s"(word)); break; case 8: asm volatile("v_writelane_b32 %0, %1, 8" : "+v"(v) : "s"(word)); break; case 9: asm volatile("v_writelane_b32 %0, %1, 9" : "+v"(v) : "s"(word)); break; case 10: asm volatile("v_writelane_b32 %0, %1, 10" : "+v"(v) : "s"(word)); break; case 11: asm volatile("v_writelane_b32 %0, %1, 11" : "+v"(v) : "s"(word)); break; case 12: asm volatile("v_writelane_b32 %0, %1, 12" : "+v"(v) : "s"(word)); break; case 13: asm volatile("v_writelane_b32 %0, %1, 13" : "+v"(v) : "s"(word)); break; case 14: asm volatile("v_writelane_b32 %0, %1, 14" : "+v"(v) : "s"(word)); break; case 15: asm volatile("v_writelane_b32 %0, %1, 15" : "+v"(v) : "s"(word)); break; case 16: asm volatile("v_writelane_b32 %0, %1, 16" : "+v"(v) : "s"(word)); break; case 17: asm volatile("v_writelane_b32 %0, %1, 17" : "+v"(v) : "s"(word)); break; case 18: asm volatile("v_writelane_b32 %0, %1, 18" : "+v"(v) : "s"(word)); break; case 19: asm volatile("v_writelane_b32 %0, %1, 19" : "+v"(v) : "s"(word)); break; case 20: asm volatile("v_writelane_b32 %0, %1, 20" : "+v"(v) : "s"(word)); break; case 21: asm volatile("v_writelane_b32 %0, %1, 21" : "+v"(v) : "s"(word)); break; case 22: asm volatile("v_writelane_b32 %0, %1, 22" : "+v"(v) : "s"(word)); break; case 23: asm volatile("v_writelane_b32 %0, %1, 23" : "+v"(v) : "s"(word)); break; case 24: asm volatile("v_writelane_b32 %0, %1, 24" : "+v"(v) : "s"(word)); break; case 25: asm volatile("v_writelane_b32 %0, %1, 25" : "+v"(v) : "s"(word)); break; case 26: asm volatile("v_writelane_b32 %0, %1, 26" : "+v"(v) : "s"(word)); break; case 27: asm volatile("v_writelane_b32 %0, %1, 27" : "+v"(v) : "s"(word)); break; case 28: asm volatile("v_writelane_b32 %0, %1, 28" : "+v"(v) : "s"(word)); break; case 29: asm volatile("v_writelane_b32 %0, %1, 29" : "+v"(v) : "s"(word)); break; case 30: asm volatile("v_writelane_b32 %0, %1, 30" : "+v"(v) : "s"(word)); break; case 31: asm volatile("v_writelane_b32 %0, %1, 31" : "+v"(v) : "s"(word)); break; case 32: asm volatile("v_writelane_b32 %0, %1, 32" : "+v"(v) : "s"(word)); break; case 33: asm volatile("v_writelane_b32 %0, %1, 33" : "+v"(v) : "s"(word)); break; case 34: asm volatile("v_writelane_b32 %0, %1, 34" : "+v"(v) : "s"(word)); break; case 35: asm volatile("v_writelane_b32 %0, %1, 35" : "+v"(v) : "s"(word)); break; case 36: asm volatile("v_writelane_b32 %0, %1, 36" : "+v"(v) : "s"(word)); break; case 37: asm volatile("v_writelane_b32 %0, %1, 37" : "+v"(v) : "s"(word)); break; case 38: asm volatile("v_writelane_b32 %0, %1, 38" : "+v"(v) : "s"(word)); break; case 39: asm volatile("v_writelane_b32 %0, %1, 39" : "+v"(v) : "s"(word)); break; case 40: asm volatile("v_writelane_b32 %0, %1, 40" : "+v"(v) : "s"(word)); break; case 41: asm volatile("v_writelane_b32 %0, %1, 41" : "+v"(v) : "s"(word)); break; case 42: asm volatile("v_writelane_b32 %0, %1, 42" : "+v"(v) : "s"(word)); break; case 43: asm volatile("v_writelane_b32 %0, %1, 43" : "+v"(v) : "s"(word)); break; case 44: asm volatile("v_writelane_b32 %0, %1, 44" : "+v"(v) : "s"(word)); break; case 45: asm volatile("v_writelane_b32 %0, %1, 45" : "+v"(v) : "s"(word)); break; case 46: asm volatile("v_writelane_b32 %0, %1, 46" : "+v"(v) : "s"(word)); break; case 47: asm volatile("v_writelane_b32 %0, %1, 47" : "+v"(v) : "s"(word)); break; case 48: asm volatile("v_writelane_b32 %0, %1, 48" : "+v"(v) : "s"(word)); break; case 49: asm volatile("v_writelane_b32 %0, %1, 49" : "+v"(v) : "s"(word)); break; case 50: asm volatile("v_writelane_b32 %0, %1, 50" : "+v"(v) : "s"(word)); break; case 51: asm volatile("v_writelane_b32 %0, %1, 51" : "+v"(v) : "s"(word)); break; case 52: asm volatile("v_writelane_b32 %0, %1, 52" : "+v"(v) : "s"(word)); break; case 53: asm volatile("v_writelane_b32 %0, %1, 53" : "+v"(v) : "s"(word)); break; case 54: asm volatile("v_writelane_b32 %0, %1, 54" : "+v"(v) : "s"(word)); break; case 55: asm volatile("v_writelane_b32 %0, %1, 55" : "+v"(v) : "s"(word)); break; case 56: asm volatile("v_writelane_b32 %0, %1, 56" : "+v"(v) : "s"(word)); break; case 57: asm volatile("v_writelane_b32 %0, %1, 57" : "+v"(v) : "s"(word)); break; case 58: asm volatile("v_writelane_b32 %0, %1, 58" : "+v"(v) : "s"(word)); break; case 59: asm volatile("v_writelane_b32 %0, %1, 59" : "+v"(v) : "s"(word)); break; case 60: asm volatile("v_writelane_b32 %0, %1, 60" : "+v"(v) : "s"(word)); break; case 61: asm volatile("v_writelane_b32 %0, %1, 61" : "+v"(v) : "s"(word)); break; case 62: asm volatile("v_writelane_b32 %0, %1, 62" : "+v"(v) : "s"(word)); break; case 63: asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(v) : "s"(word)); break;
-        default: break;
-    }
-}
 template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 DEV void wait_vmcnt_n(const int n) {        // n is a compile-time constant after unrolling: the switch folds to one s_waitcnt
@@ -543,7 +535,7 @@ DEV void store_tile_k(const KMat& m, int net, int64_t tile32, int ct, const Lane
 // saved-state / operand addressing ---------------------------------------------------------------------------
 struct SavedView {       // written by dpn_fwd
     KMat V, T1;          // [6][NS] x 256 columns
-    u32* m2t;            // [6][tiles32][256] relu-2 mask, one word per row of the K layout (slot order), bit p = point p of the tile
+    KMat M2;             // [6][1]  x 256 columns, relu-2 mask as bf16 0/1
     uint4* m1;           // [6][tiles32][64] lane-format bits of relu mask 1
 };
 DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
@@ -553,11 +545,11 @@ DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
     const int64_t tiles32 = n_pad / 32;
     s.V = KMat{b, tiles32, 8};
     s.T1 = KMat{b + mat, tiles32, 8};
-    s.m2t = reinterpret_cast<u32*>(b + 2 * mat);
-    s.m1 = reinterpret_cast<uint4*>(b + 2 * mat + (int64_t)kNets * n_pad * 32);
+    s.M2 = KMat{b + 2 * mat, tiles32, 8};
+    s.m1 = reinterpret_cast<uint4*>(b + 2 * mat + (int64_t)kNets * n_pad * 512);
     return s;
 }
-static int64_t saved_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 32 + (int64_t)kNets * n_pad * 32; }
+static int64_t saved_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 512 + (int64_t)kNets * n_pad * 32; }
 
 struct OperandView {     // written by dpn_bwd_points
     KMat Z1, Z;          // [6][NS] x 256
@@ -654,9 +646,6 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 
     f32x16 acc[8];
     u32 m1w[4] = {0u, 0u, 0u, 0u};
-    u32 m2w = 0u;          // relu-2 mask words of two 32-channel tiles: lane 32 (T & 1) + row of the K layout, bit p = point p
-    // padding points carry zero bits (both halves of the wave hold the same 32 points); readfirstlane: wave-uniform for the compiler too
-    const u32 m2valid = (u32)__builtin_amdgcn_readfirstlane((int)(partial ? (u32)__builtin_amdgcn_ballot_w64(L.valid) : ~0u));
     Frag<NS> actA[16], actB[16];
 
     // ---------------- L1: pre1 = w1 . pe + b1 ; h1 = relu -> actA ; relu mask -> m1w
@@ -729,6 +718,7 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     const float const0 = lds_read_f32(lds_vec + kNumVecs * 256 * 4);
     float adot = 0.f;
     auto epi3 = [&](const int T) __attribute__((always_inline)) {
+        Frag<1> mk0, mk1;
         Vec16 uv;
         lds_read_vec16(uv, vec_addr(lds_vec, kVecU, h, T));
 #pragma unroll
@@ -743,23 +733,20 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
                 adot = fmaf(p0, t0, adot);                                           // relu(p) * u == p * (m2 * u): no separate max
                 adot = fmaf(p1, t1, adot);
                 frag_set2<NS>(actA[2 * T + (r >> 3)], (r & 7) >> 1, t0, t1);
-                {   // (unconditional: a branch here would cut the epilogue into blocks the scheduler cannot fold under the MFMAs)
-                    // the compare's lane mask IS the saved word: its low half = channel 32 T + drow32(r, 0) over the tile's 32 points,
-                    // its high half = channel 32 T + drow32(r, 1); the channel's row of the K layout is 32 T + 16 (r >> 3) + 8 h + (r & 7)
-                    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(on0), b1 = __builtin_amdgcn_ballot_w64(on1);
-                    const int base = 32 * (T & 1) + 16 * (r >> 3) + (r & 7);
-                    writelane_at(m2w, (u32)b0 & m2valid, base);
-                    writelane_at(m2w, (u32)(b0 >> 32) & m2valid, base + 8);
-                    writelane_at(m2w, (u32)b1 & m2valid, base + 1);
-                    writelane_at(m2w, (u32)(b1 >> 32) & m2valid, base + 9);
-                }
+                const u32 mw = (on0 ? 0x3F80u : 0u) | (on1 ? 0x3F800000u : 0u);
+                if (r < 8) mk0.w[0][(r & 7) >> 1] = mw; else mk1.w[0][(r & 7) >> 1] = mw;
             }
         }
-        // pin t2 in VGPRs HERE: left alone, the scheduler keeps the 128 compare results as lane masks in SGPRs (spilling them through
-        // v_writelane / v_readlane) and materialises every select in one 1000-instruction block after the GEMM
+        // pin t2 and the mask words in VGPRs HERE: left alone, the scheduler keeps the 128 compare results as lane masks in SGPRs
+        // (spilling them through v_writelane / v_readlane) and materialises every select in one 1000-instruction block after the GEMM
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) asm volatile("" : "+v"(actA[2 * T].w[s2]), "+v"(actA[2 * T + 1].w[s2]));
-        if (save && (T & 1)) sv.m2t[((int64_t)net * (a.n_pad / 32) + tile32) * 256 + 32 * (T - 1) + L.lane] = m2w;   // 256 B per two tiles
+        asm volatile("" : "+v"(mk0.w[0]), "+v"(mk1.w[0]));
+        // (Saving the mask as bit words instead -- the compares' lane masks ARE the transposed words, 1 KB per tile and net instead of
+        //  16 KB, v_writelane into one VGPR -- and expanding them to 0 / 1 fragments in dpn_wgrad_kernel was built and measured: this
+        //  kernel unchanged, dpn_wgrad_kernel +4.5 % (the expansion sits in front of the MFMAs of its product's workgroups), step +1.1 %
+        //  hi+lo and +3.2 % single bf16 on the same box.  Not kept: tools/experiments/m2_bit_masks.patch.)
+        if (save) store_tile_k<1, 1>(sv.M2, net, tile32, T, L, mk0, mk1, partial);
     };
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
@@ -1140,7 +1127,7 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 #if DPN_HAS_REST
 // ------------------------------------------------------------------------------------------------ backward, stage 2
 // Points-reduction GEMMs  D[so][si] = sum_pt X[pt][so] * Y[pt][si]  for the four products of a net:
-//   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q = Z^T 1      (M2: the relu-2 mask, saved as bit words, expanded in registers)
+//   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q = Z^T 1
 //   P1: dw2  = V^T  Z1   (256x256)  + gcvec = V^T g, sum g
 //   P2: dWd  = V^T  G6   (256x192)
 //   P3: dw1  = T1^T Z0   (256x192)  + db1 = T1^T g
@@ -1195,7 +1182,7 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     const bool active = wn * 2 < nct;                                   // 192-column products leave the wn = 3 waves idle
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
-    const char* xb = (prod == 3) ? sv.T1.base : sv.V.base;                                      // 8 column tiles (product 0: the mask words)
+    const char* xb = (prod == 0) ? sv.M2.base : (prod == 3) ? sv.T1.base : sv.V.base;           // 8 column tiles
     const char* yb = (prod == 0) ? ov.Z.base : (prod == 1) ? ov.Z1.base : (prod == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
     const int nsx = (prod == 0) ? 1 : NS;                               // the 0/1 mask has no lo part
     const float* gnet = ov.gnet + (int64_t)net * a.n_pad;
@@ -1218,8 +1205,6 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                 const int sx = s2 < nsx ? s2 : 0;
                 src = xb + (((int64_t)net * nsx + sx) * tiles + tile) * xbytes + r * 1024;
                 dst = sl + s2 * 16384 + r * 1024;
-                // product 0: 1 KB of mask words per tile -- piece 0 is real, the other X pieces re-read it into the rest of the X area
-                if (prod == 0) src = reinterpret_cast<const char*>(sv.m2t) + ((int64_t)net * tiles + tile) * 1024;
             } else {
                 const int ry = (r - 16) * 1024 < ybytes ? (r - 16) : 0;
                 src = yb + (((int64_t)net * NS + s2) * tiles + tile) * ybytes + ry * 1024;
@@ -1258,13 +1243,6 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                 for (int n2 = 0; n2 < 2; ++n2) rd128(fba[b][s2][n2], buf + NS * 16384 + s2 * 16384 + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
             }
         };
-        // product 0: the X operand is the relu-2 mask, saved as one word per row (bit p = point p of the tile, 1 KB per tile instead of a
-        // 16-KB bf16 image): the lane's four rows' words are read FIRST (older than every counted read below) and expanded to 0 / 1
-        // fragments after the wait; the X reads below then fetch unused bytes
-        // (read for every product, four words: a branch here would leave the registers with two definitions, one of them pending)
-        u32 mw[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) asm volatile("ds_read_b32 %0, %1" : "=v"(mw[m]) : "v"(buf + (32 * (wm * 4 + m) + i) * 4) : "memory");
         if constexpr (NS == 1) { issue_reads(0, 0); issue_reads(1, 1); }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1287,19 +1265,6 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
                              "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
                              "+v"(fb[1][0]), "+v"(fb[1][1]) :: "memory");
-            }
-            asm volatile("" : "+v"(mw[0]), "+v"(mw[1]), "+v"(mw[2]), "+v"(mw[3]));          // behind the wait (volatile asm keeps its order)
-            if (prod == 0) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    // fragment element e = point drow32(8 kk + e, h) = 16 kk + 4 h + {0, 1, 2, 3, 8, 9, 10, 11}[e]
-                    const int x = (int)(mw[m] >> (16 * kk + 4 * h));
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const int o = (p & 1) * 2 + (p >> 1) * 8;
-                        fa[0][m][p] = ((u32)__builtin_amdgcn_sbfe(x, o, 1) & 0x3F80u) | ((u32)__builtin_amdgcn_sbfe(x, o + 1, 1) & 0x3F800000u);
-                    }
-                }
             }
             const float gp[8] = {__uint_as_float(gq0[0]), __uint_as_float(gq0[1]), __uint_as_float(gq0[2]), __uint_as_float(gq0[3]),
                                  __uint_as_float(gq1[0]), __uint_as_float(gq1[1]), __uint_as_float(gq1[2]), __uint_as_float(gq1[3])};

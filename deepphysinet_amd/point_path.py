@@ -488,21 +488,23 @@ def relu_masks(cfg: PointConfig, x, y, t, coord_data, heads, evec, statics):
         tiles = n_pad // 32
         mat = 6 * ns * n_pad * 512
         raw = ws.saved
-        # M2: [6][tiles][256] words: word 32 ct + jj = row jj of column tile ct of the K layout = channel chain_ch(2 ct + (jj >> 4),
-        # (jj >> 3) & 1, jj & 7); bit p = point p of the tile
-        m2_words = raw[2 * mat:2 * mat + 6 * n_pad * 32].view(torch.int32).view(6, tiles, 256)
+        # M2: [6][tiles][kk 2][ct 8][lane 64][8 bf16 of 0/1]: register r = 8 kk + e of lane (col jj = lane & 31, h = lane >> 5) is the mask of
+        # channel chain_ch(2 ct + (jj >> 4), (jj >> 3) & 1, jj & 7) at point drow32(r, h) of the tile
+        m2_raw = raw[2 * mat:2 * mat + 6 * n_pad * 512].view(torch.int16).view(6, tiles, 2, 8, 64, 8) != 0
         lane = torch.arange(64, device=dev)
         jj, hh = lane & 31, lane >> 5
-        row = torch.arange(256, device=dev)
-        rj = row & 31
-        chan = 16 * (2 * (row >> 5) + (rj >> 4)) + 8 * ((rj & 7) >> 2) + 4 * ((rj >> 3) & 1) + (rj & 3)      # [row] -> channel
-        pbit = torch.arange(32, device=dev)
+        ct = torch.arange(8, device=dev)
+        ks = 2 * ct[:, None] + (jj >> 4)[None, :]                                       # [ct, lane]
+        chan = 16 * ks + 8 * ((jj & 7) >> 2)[None, :] + 4 * ((jj >> 3) & 1)[None, :] + (jj & 3)[None, :]
         r = torch.arange(16, device=dev)
-        bits2 = ((m2_words[:, :, None, :] >> pbit[None, None, :, None]) & 1).bool()         # [net, tile, point, row]
+        prow = (r & 3)[:, None] + 8 * (r >> 2)[:, None] + 4 * hh[None, :]              # [r, lane] point row inside the tile
         m2 = torch.zeros((6, tiles, 32, 256), dtype=torch.bool, device=dev)
-        m2[:, :, :, chan] = bits2
+        src = m2_raw.permute(0, 1, 3, 4, 2, 5).reshape(6, tiles, 8, 64, 16)            # [net, tile, ct, lane, r]
+        pi = prow.t()[None, :, :].expand(8, 64, 16)                                    # [ct, lane, r]
+        ci = chan[:, :, None].expand(8, 64, 16)
+        m2[:, :, pi, ci] = src
         # m1: uint4 per (net, tile, lane): bit 16 (T & 1) + r of word T >> 1 = mask of channel 32 T + drow32(r, h) at point lane & 31
-        m1_raw = raw[2 * mat + 6 * n_pad * 32:2 * mat + 6 * n_pad * 32 + 6 * n_pad * 32].view(torch.int32).view(6, tiles, 64, 4)
+        m1_raw = raw[2 * mat + 6 * n_pad * 512:2 * mat + 6 * n_pad * 512 + 6 * n_pad * 32].view(torch.int32).view(6, tiles, 64, 4)
         T = torch.arange(8, device=dev)
         words = m1_raw[:, :, :, T >> 1]                                                # [net, tile, lane, T]
         bits = (words[..., None] >> (16 * (T & 1)[:, None] + r[None, :])) & 1           # [net, tile, lane, T, r]
