@@ -1274,7 +1274,11 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                if (wn == 0 && prod != 2) {                              // row-side vector: sum_pt X[pt][row] * g[pt]
+                if (wn == (nct == 8 ? m : m % 3) && prod != 2) {         // row-side vector: sum_pt X[pt][row] * g[pt]; the four waves that
+                                                                         // hold this row tile's fragments take one tile each (all on
+                                                                         // the wn = 0 waves it made them the workgroup's critical path:
+                                                                         // +700 cycles per tile, everybody else waiting at the barrier);
+                                                                         // 192-column products: the wn = 3 waves sit idle, three share
                     float d = 0.f;
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2) {
@@ -1294,9 +1298,10 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                     acc[m][n2] = mfma(as_bf(fa[0][m]), as_bf(fb[0][n2]), acc[m][n2]);
                 }
             }
-            if (prod == 0 && wm == 0) {                                  // column-side vector: q = sum_pt Z[pt][col]
+            if (prod == 0) {                                             // column-side vector: q = sum_pt Z[pt][col], one column tile per wm
 #pragma unroll
                 for (int n2 = 0; n2 < 2; ++n2) {
+                    if (wm != n2) continue;
                     float d = 0.f;
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2)
@@ -1360,7 +1365,7 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const float v = vecA[m] + __shfl_xor(vecA[m], 32);
-        if (wn == 0 && h == 0) {
+        if (wn == (nct == 8 ? m : m % 3) && h == 0) {
             const int rr = wm * 128 + 32 * m + i;
             if (prod == 0) part[kPartVec + 0 * 256 + rr] = v;          // mvec
             if (prod == 1) part[kPartVec + 2 * 256 + rr] = v;          // gcvec
@@ -1371,11 +1376,11 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
         const float gs = gsum + __shfl_xor(gsum, 32);                  // lanes 0 and 32 hold the two halves
         if (lane == 0) part[kPartVec + 4 * 256] = gs;
     }
-    if (prod == 0 && wm == 0) {
+    if (prod == 0) {
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
             const float v = vecB[n2] + __shfl_xor(vecB[n2], 32);
-            if (h == 0) part[kPartVec + 1 * 256 + wn * 64 + 32 * n2 + i] = v;   // q = colsum(Z)
+            if (wm == n2 && h == 0) part[kPartVec + 1 * 256 + wn * 64 + 32 * n2 + i] = v;   // q = colsum(Z)
         }
     }
 }

@@ -70,6 +70,12 @@ def check(lines, name):
             elif 'lgkmcnt' not in ins and re.fullmatch(r's_waitcnt\s+(0x[0-9a-f]+|\d+)', ins):
                 pending = []         # raw immediate: treat as a full wait only if the lgkm field is 0 (not emitted by this code base)
         elif LGKM.match(op):
+            if op.startswith('s_load') or op.startswith('s_buffer_load'):
+                # scalar loads share the counter and return OUT of order: a counted lgkmcnt(N) wait behind one is no longer a statement
+                # about the LDS reads in front of it
+                if any(pending):
+                    hazards += 1
+                    print(f'{name}: line {no}: `{ins}` is issued with inline-asm LDS reads outstanding (counted waits assume in-order returns)')
             dst = set()
             if in_asm and op.startswith('ds_read'):
                 first = ins[len(op):].split(',')[0]

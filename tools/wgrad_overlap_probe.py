@@ -138,7 +138,9 @@ def main():
         forked()
     print('     one graph with the two as parallel branches: %.1f us' % timed(g.replay))
     # and the backward chain only beside wgrad: what the step would do
-    h, e = enc_fwd()
+    with torch.cuda.stream(sA):                       # the backward pass runs on the stream of its forward
+        h, e = enc_fwd()
+    torch.cuda.synchronize()
 
     def forked_bwd():
         sB.wait_stream(torch.cuda.current_stream())
