@@ -255,6 +255,10 @@ template <int NS>
 struct Pipe {
     static constexpr int kRing = 4;
     static constexpr int kSlotBytes = 16 * 1024 * NS;
+#ifdef DPN_FWD_PHASES
+    u32 ph[6] = {0, 0, 0, 0, 0, 0}, pc0 = 0;      // experiment build: cycles in vmcnt wait / barrier / DMA issue / reads + MFMAs / last block / epilogue
+#define DPN_PH_CLOCK(V) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); V = (u32)t_; } while (0)
+#endif
     const char* g;       // global address of the next chunk to issue (wave-uniform)
     char* lds;
     int end;             // number of chunks this kernel may touch (54 forward, 24 backward)
@@ -264,7 +268,13 @@ struct Pipe {
         g = reinterpret_cast<const char*>(gsrc); lds = lds_base; end = end_chunks;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); lane = threadIdx.x & 63;
     }
+#ifdef DPN_ABL_HALFDMA                        // ablation (wrong results): half of each chunk is fetched -- is the step time the DMA's?
+    DEV static int dmas(int nk) { return nk * NS / 8; }
+#elif defined(DPN_ABL_QUARTERDMA)
+    DEV static int dmas(int nk) { return nk * NS / 16; }
+#else
     DEV static int dmas(int nk) { return nk * NS / 4; }                 // DMA instructions per wave for a chunk of nk k-steps
+#endif
     DEV void issue(const int c) {                                       // chunk c -> slot c % 4
         const int n = dmas(stream_nk(c, end));
         char* slot = lds + (c & (kRing - 1)) * kSlotBytes;
@@ -291,11 +301,26 @@ struct Pipe {
     //  fc1 chunk in the hi+lo mode.  Not kept.)
     DEV void acquire(const int c) {                                     // after this, every wave may read chunk c from LDS
         __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from stretching live ranges across pipeline steps
+#ifdef DPN_FWD_PHASES
+        u32 c0, c1, c2, c3;
+        DPN_PH_CLOCK(c0);
+        if (pc0) ph[5] += c0 - pc0;             // since the end of the previous chunk's multiply: its epilogue
+#endif
         wait_vmcnt_n(dmas(stream_nk(c + 1, end)) + dmas(stream_nk(c + 2, end)));
+#ifdef DPN_FWD_PHASES
+        DPN_PH_CLOCK(c1);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // compiler-level ordering only: no s_waitcnt is emitted
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef DPN_FWD_PHASES
+        DPN_PH_CLOCK(c2);
+#endif
         issue(c + 3);
+#ifdef DPN_FWD_PHASES
+        DPN_PH_CLOCK(c3);
+        ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; pc0 = c3;
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     DEV unsigned buf(const int c) const {                               // LDS byte address of slot c % 4
@@ -598,6 +623,11 @@ struct FwdArgs {
 #define DPN_STAMP(I) do { } while (0)
 #endif
 
+#ifdef DPN_FWD_PHASES
+#define DPN_PH_AFTER_MMA do { u32 c4_; DPN_PH_CLOCK(c4_); pipe.ph[3] += c4_ - pipe.pc0; pipe.pc0 = c4_; } while (0)
+#else
+#define DPN_PH_AFTER_MMA do { } while (0)
+#endif
 // One pipeline step on chunk C: make it readable (and put chunk C+3 in flight), multiply it, and run the epilogue of the
 // PREVIOUS tile in the shadow of these MFMAs (it only touches that tile's accumulator).
 #define DPN_STEP(C, NK, SWAP, ACT, ACC, EPI_PREV)                                    \
@@ -605,6 +635,7 @@ struct FwdArgs {
         DPN_STAMP(2 + (C));                                                          \
         pipe.acquire(C);                                                             \
         mma_chunk<NS, (NK), (SWAP)>(pipe.buf(C), (ACT), (ACC));                      \
+        DPN_PH_AFTER_MMA;                                                            \
         EPI_PREV;                                                                    \
     } while (0)
 
@@ -826,6 +857,9 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     pipe.drain();
 #ifdef DPN_TIMELINE
     DPN_STAMP(62);
+#ifdef DPN_FWD_PHASES
+    if (L.lane >= 56 && L.lane < 62) tl = pipe.ph[L.lane - 56];         // slots 56..61: the phase sums of this wave
+#endif
     if (a.timeline) a.timeline[(((int64_t)blockIdx.x * kNets + net) * 8 + wave) * 64 + L.lane] = tl;
 #endif
 #pragma unroll

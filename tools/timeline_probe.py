@@ -74,6 +74,12 @@ def main():
         print('kernel + pack (instrumented): %.1f us' % (e0.elapsed_time(e1) * 1e3))
     lib.dpn_debug_set_timeline(None)
     T = tl.cpu().numpy().astype(np.int64)[:, :, :nw] & 0xFFFFFFFF
+    if os.environ.get('DPN_FWD_PHASES'):                   # build with -DDPN_FWD_PHASES: slots 56..61 hold phase sums over the 54 steps
+        P = T[..., 56:62].astype(np.float64)
+        names = ('vmcnt wait', 'barrier', 'DMA issue', 'reads + MFMAs', '(unused)', 'epilogue')
+        print('%s: cycles per wave over the 54 pipeline steps, by phase: %s | sum %.0f' %
+              (prec, '  '.join('%s %.0f' % (nm, P[..., k].mean()) for k, nm in enumerate(names) if k != 4), P.sum(-1).mean()))
+        print('   per step: %s' % '  '.join('%s %.0f' % (nm, P[..., k].mean() / 54) for k, nm in enumerate(names) if k != 4))
     d = (T[..., 1:] - T[..., :-1]) & 0xFFFFFFFF            # wrap-safe deltas, [blk, net, wave, 63]
     total = (T[..., 62] - T[..., 0]) & 0xFFFFFFFF
     print('%s: waves %d, cycles per wave entry -> exit: mean %.0f  min %d  max %d' % (prec, total.size, total.mean(), total.min(), total.max()))
