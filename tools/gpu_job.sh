@@ -1,13 +1,14 @@
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
-for p in bf16x2 bf16; do
-for v in full HALFDMA QUARTERDMA; do
-  L=$PWD/deepphysinet_amd/libdpn_hip_abl_$v.so; [ $v = full ] && L=$PWD/deepphysinet_amd/libdpn_hip_timeline.so
-  cp $L /tmp/lib_probe.so
-  echo "== $p $v"; python - <<PY 2>&1 | grep -v amdgpu.ids | grep "kernel + pack\|cycles per wave\|^L2 \|^fc1 \|^v \|^L1 " | cut -c1-150
-import os, sys, runpy, shutil
-sys.argv = ['tools/timeline_probe.py', '$p']
-import importlib.util
-src = open('tools/timeline_probe.py').read().replace("LIB = os.path.join(ROOT, 'deepphysinet_amd', 'libdpn_hip_timeline.so')", "LIB = '/tmp/lib_probe.so'")
-exec(compile(src, 'tools/timeline_probe.py', 'exec'))
+mkdir -p gpurun_out/r2j
+timeout 1500 python -u -m pytest tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -n 2
+for i in 1 2; do
+for v in prev new; do
+  if [ $v = prev ]; then export DPN_LIB=$PWD/deepphysinet_amd/libdpn_hip_prev.so; else unset DPN_LIB; fi
+  python -u bench.py --no-cpu-baseline > gpurun_out/r2j/ab_$v.json 2>/dev/null
+  python - <<PY
+import json
+d = json.load(open('gpurun_out/r2j/ab_$v.json'))
+o = d['other_precision_mode']
+print('$v', 'x2: ms %.4f fwd %.1f wgrad %.1f bwd %.1f frac %.3f | bf16: ms %.4f fwd %.1f frac %.3f' % (d['ms_per_step'], d['roofline']['kernel_ms'] * 1e3, d['roofline_hbm_kernel']['kernel_ms'] * 1e3, d['roofline_hbm_kernel']['bwd_points_kernel_ms'] * 1e3, d['roofline']['frac'], o['ms_per_step'], o['roofline']['kernel_ms'] * 1e3, o['roofline']['frac']))
 PY
 done; done
