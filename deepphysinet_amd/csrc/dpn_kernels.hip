@@ -1165,9 +1165,10 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 //   P1: dw2  = V^T  Z1   (256x256)  + gcvec = V^T g, sum g
 //   P2: dWd  = V^T  G6   (256x192)
 //   P3: dw1  = T1^T Z0   (256x192)  + db1 = T1^T g
-// grid = (sum of the four products' split counts, 6 nets); each workgroup owns the whole output of its product for its range of
-// 32-point tiles (the products move different numbers of bytes per tile, so they are cut into different numbers of ranges: SplitPlan).  Operands are already MFMA fragments in global memory (K-layout): every wave loads its A/B fragments straight
-// into registers, one 16-byte load per fragment, no LDS, no barrier; the next k-step's loads are in flight under the MFMAs.
+// grid = (sum of the four products' point-range counts, 6 nets): each workgroup owns the whole output of its product for its range of
+// 32-point tiles (SplitPlan below says how many ranges each product is cut into) and writes one partial sum per range;
+// dpn_finish_* add the ranges in a fixed order.  Operands are already MFMA fragments in global memory (K-layout, written by
+// dpn_fwd / dpn_bwd_points), so a tile travels global -> LDS as a plain byte image.
 constexpr int kPartFloats = 65536 * 2 + 49152 * 2 + 5 * 256;       // per (split, net)
 DPN_HD int part_off(int prod) { return prod == 0 ? 0 : prod == 1 ? 65536 : prod == 2 ? 131072 : 180224; }
 constexpr int kPartVec = 229376;                                    // mvec, q, gcvec, db1, [sum g]
