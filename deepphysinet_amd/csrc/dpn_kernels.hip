@@ -875,6 +875,9 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #if DPN_HAS_POINT && defined(DPN_EXPERIMENT_FWD2)
 #include "../../tools/experiments/dpn_fwd2_eight_waves.h"       // shelved eight-wave variant (measured slower; see its header and DESIGN.md)
 #endif
+#if DPN_HAS_POINT
+#include "dpn_fwd_tiles.h"                                       // tile-split forward kernel (the hi+lo mode's default)
+#endif
 
 #if DPN_HAS_REST
 // g_pe[n][c] = sum_k g_out[n][k] * gpe[n][k][c]: the cotangent of caller-encoded coordinates (PhysicsNet.forward backward w.r.t. coord_x)
@@ -2202,6 +2205,17 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
         return ck(hipGetLastError());
     }
 #endif
+    // hi+lo mode: the tile-split kernel (dpn_fwd_tiles.h; 64 points per workgroup, two workgroups per CU).  Caller-encoded coordinates
+    // and the single-bf16 mode stay on the ring kernel (one bf16 product per fragment pair cannot pay for the doubled weight stream).
+    // DPN_FWD_KERNEL=ring|tiles overrides (A/B measurements, bitwise comparison of the two kernels in the tests).
+    const char* force = getenv("DPN_FWD_KERNEL");          // read per call: the tests switch kernels inside one process
+    const bool tiles = force ? (force[0] == 't') : (prec == 2);
+    if (tiles && !pe_in) {
+        const dim3 grid64((unsigned)(a.n_pad / 64), kNets);
+        if (prec == 1) hipLaunchKernelGGL(dpn_fwd_tiles_kernel<1>, grid64, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(dpn_fwd_tiles_kernel<2>, grid64, dim3(256), 0, s, a);
+        return ck(hipGetLastError());
+    }
     if (prec == 1) hipLaunchKernelGGL(dpn_fwd_kernel<1>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(dpn_fwd_kernel<2>, grid, dim3(256), 0, s, a);
     return ck(hipGetLastError());
