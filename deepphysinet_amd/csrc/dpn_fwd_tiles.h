@@ -40,8 +40,21 @@ DEV void barrier_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Ablation builds (tools/variant_build.py; wrong results on purpose, timing only): TS_ABL_NOMFMA keeps the operands alive and drops the
+// products, TS_ABL_NOSINCOS replaces the feature evaluation by one multiply, TS_ABL_NOALOAD multiplies with whatever is in the registers.
+#ifdef TS_ABL_NOSINCOS
+template <int NS> DEV void ts_sincos(float th, float& s, float& c) { s = th; c = th * 0.5f; }
+#else
+template <int NS> DEV void ts_sincos(float th, float& s, float& c) { sincos_t<NS>(th, s, c); }
+#endif
+
 template <int NS>
 DEV void mma3(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16& acc) {        // same product order as mma_block (not SWAP)
+#ifdef TS_ABL_NOMFMA
+    if constexpr (NS == 2) asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+    else asm volatile("" ::"v"(a[0]), "v"(b[0]));
+    return;
+#endif
     if constexpr (NS == 2) {
         acc = mfma(as_bf(a[0]), as_bf(b[1]), acc);
         acc = mfma(as_bf(a[1]), as_bf(b[0]), acc);
@@ -50,36 +63,101 @@ DEV void mma3(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16& acc) {        
 }
 
 // acc[t][p] += W[tile t][k] * X[k][column tile p] over NK k-steps.  wg: this wave's first tile chunk in the packed stream (wave-uniform;
-// the second tile's chunk follows it), xl: LDS X + lane * 16.  A fragments two k-steps ahead, B fragments one.
+// the second tile's chunk follows it), xl: LDS X + lane * 16.  A fragments kPF - 1 k-steps ahead, B fragments one.
+// The first kPF - 1 k-steps' A fragments are loaded by gemm_head, which the kernel calls BEFORE the previous layer's epilogue: the
+// weight stream of a layer then starts under that epilogue (packing, saved-state stores, the two barriers) instead of cold behind it --
+// and in front of its stores: vmcnt retires in order, a load issued behind the saved-state stores would wait for them as well.
+#ifndef TS_PF
+#define TS_PF 4
+#endif
+// Issue priority between the two waves of a SIMD (they belong to different workgroups): 0 = none, 1 = s_setprio 1 around every k-step's
+// MFMAs, 2 = s_setprio 1 everywhere EXCEPT the multiply loops (the feature / epilogue / store phases are a workgroup's serial chain; a
+// multiplying wave needs one issue slot in eight)
+#ifndef TS_PRIO
+#define TS_PRIO 2
+#endif
+constexpr int kPF = TS_PF;
+template <int NS, int NT> struct Head { u32x4 a[kPF - 1][NT][NS]; };
+
+// Weight fragments come through a buffer descriptor (SGPR base, the lane's 16-byte slot as the only VGPR offset, fragment index as scalar /
+// immediate offset): no 64-bit address arithmetic between the MFMAs.  tools/microbench/l2_stream2.hip, this loop shape at 3 MFMAs per
+// loaded KB: global_load with VGPR addresses 48 % of the bf16 peak, buffer_load 65 %, s_setprio 1 around the MFMAs 62 %.
 template <int NS, int NK, int NT>
-DEV void gemm(const char* wg, const char* xl, const int lane, f32x16 (&acc)[2][2]) {
-    const u32x4* ag = reinterpret_cast<const u32x4*>(wg) + lane;
-    u32x4 A[3][NT][NS];
+struct WSrc {
+    __amdgpu_buffer_rsrc_t rs;
+    int voff;
+    int so[NT];                                  // running scalar offsets of the next k-step, one per tile (SALU adds; kept opaque so that
+                                                 // the unrolled loop does not turn them into a hundred constants in as many SGPRs)
+    DEV void init(const char* wg, const int lane, const int ks0) {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wg), 0, NT * NK * NS * 1024, 0x00020000);
+        voff = lane * 16;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { so[t] = (t * NK + ks0) * NS * 1024; asm volatile("" : "+s"(so[t])); }
+    }
+    DEV void next(u32x4 (&dst)[NT][NS]) {        // fragments of the next k-step
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#ifdef TS_ABL_NOALOAD
+                asm volatile("" : "=v"(dst[t][s]));
+#else
+                dst[t][s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + s * 1024, so[t], 0));
+#endif
+            }
+            so[t] += NS * 1024;
+            asm volatile("" : "+s"(so[t]));
+        }
+    }
+};
+template <int NS, int NK, int NT>
+DEV void gemm_head(const char* wg, const int lane, Head<NS, NT>& H) {
+    WSrc<NS, NK, NT> src;
+    src.init(wg, lane, 0);
+#pragma unroll
+    for (int k = 0; k < kPF - 1; ++k) src.next(H.a[k]);
+}
+template <int NS, int NK, int NT>
+DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>& H, f32x16 (&acc)[2][2]) {
+    static_assert(NK >= kPF, "k-steps per chunk");
+    WSrc<NS, NK, NT> src;
+    src.init(wg, lane, kPF - 1);
+    u32x4 A[kPF][NT][NS];
     u32x4 B[2][2][NS];
-    auto loadA = [&](const int ks, const int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) A[slot][t][s] = ag[((t * NK + ks) * NS + s) * 64];
-    };
     auto loadB = [&](const int ks, const int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int s = 0; s < NS; ++s) B[slot][p][s] = *reinterpret_cast<const u32x4*>(xl + ((ks * 2 + p) * NS + s) * 1024);
     };
-    loadA(0, 0);
-    loadA(1, 1);
-    loadB(0, 0);
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-        if (ks + 2 < NK) loadA(ks + 2, (ks + 2) % 3);
-        if (ks + 1 < NK) loadB(ks + 1, (ks + 1) & 1);
+    for (int k = 0; k < kPF - 1; ++k)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) mma3<NS>(A[ks % 3][t], B[ks & 1][p], acc[t][p]);
+            for (int s = 0; s < NS; ++s) A[k][t][s] = H.a[k][t][s];
+    loadB(0, 0);
+#if TS_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);            // multiply phases at low priority, everything else (the serial chain of a workgroup) at high
+#endif
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        if (ks + kPF - 1 < NK) src.next(A[(ks + kPF - 1) % kPF]);
+        if (ks + 1 < NK) loadB(ks + 1, (ks + 1) & 1);
+#if TS_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);        // the multiplying wave wins issue arbitration against its SIMD partner's loads / packing
+#endif
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) mma3<NS>(A[ks % kPF][t], B[ks & 1][p], acc[t][p]);
+#if TS_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
+#if TS_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
 }
 
 template <int NS>
@@ -123,7 +201,103 @@ DEV void save_tile_k(const KMat& m, const int net, const int64_t tile32, const i
         store_d_as_k(m, net, NSTORE, s, tile32, ct, lane, d);
     }
 }
+
+// ---- positional features, evaluated once per point (not once per point and net) by dpn_features_kernel and stored behind the saved state:
+// per 64-point workgroup tile  [pe3 image 24 NS KB | pe6 image 24 NS KB | dpe table 48 KB]
+//   pe3 / pe6 image : the LDS X image of the features' B fragments, [k-step 12][column tile 2][hi | lo][64 lanes][16 B] -- the forward kernel
+//                     copies it 16 bytes per thread and step, linearly
+//   dpe table       : d pe3 / d xi in the accumulator layout of the gpe tiles, [coordinate 3][tile 2][column tile 2][64 lanes][16 floats]:
+//                     element 2 rp = freq * cos, 2 rp + 1 = -freq * sin of the lane's angle rp (what the Jacobian contraction multiplies by)
+template <int NS> constexpr int feat_pe_bytes() { return 12 * 2 * NS * 1024; }
+template <int NS> constexpr int feat_tile_bytes() { return 2 * feat_pe_bytes<NS>() + 3 * 2 * 2 * 64 * 64; }
+
+// the coordinate features of k-step ks (0..11) for the lane's point: one B fragment (hi [+ lo])
+template <int NS>
+DEV void pe3_frag(Frag<NS>& f, const FwdArgs& a, const int ks, const int h, const int64_t pc) {
+    const int c = ks >> 2;
+    const float* src = (c == 0) ? a.x : (c == 1) ? a.y : a.t;
+    const float d1 = (c == 0) ? a.geo.dx : (c == 1) ? a.geo.dy : a.geo.pred_t_span;
+    const float d2 = (c == 0) ? a.geo.lon_m1 : (c == 1) ? a.geo.lat_m1 : 1.0f;   // x / dx / (lon-1): two fp32 divisions (interface_physics.py:324-326); t: one
+    const float xi = src[pc] / d1 / d2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s, co;
+        ts_sincos<NS>(xi * a.freqs[8 * (ks & 3) + 4 * h + q], s, co);
+        frag_set2<NS>(f, q, s, co);
+    }
+}
+// the data features (SineCosPE(6,16) of coord_data, variable_net.py:73) of k-step ks (0..11)
+template <int NS>
+DEV void pe6_frag(Frag<NS>& f, const FwdArgs& a, const int ks, const int h, const int64_t pc) {
+    const float v = a.coord_data[pc * 6 + (ks >> 1)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s, co;
+        ts_sincos<NS>(v * a.freqs[32 + 8 * (ks & 1) + 4 * h + q], s, co);
+        frag_set2<NS>(f, q, 1.0f * s, 1.0f * co);
+    }
+}
+// d pe3 / d xi_c for the 16 accumulator registers of gpe tile 2c + t (register pair rp = one angle: k-step 2T + (rp >> 2) of the coordinate PE)
+template <int NS>
+DEV void dpe_tile(float (&d)[16], const FwdArgs& a, const int c, const int t, const int h, const int64_t pc) {
+    const float* src = (c == 0) ? a.x : (c == 1) ? a.y : a.t;
+    const float d1 = (c == 0) ? a.geo.dx : (c == 1) ? a.geo.dy : a.geo.pred_t_span;
+    const float d2 = (c == 0) ? a.geo.lon_m1 : (c == 1) ? a.geo.lat_m1 : 1.0f;
+    const float xi = src[pc] / d1 / d2;
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) {
+        const int r = 2 * rp;
+        const float fr = a.freqs[8 * ((2 * t + (r >> 3)) & 3) + 4 * h + ((r & 7) >> 1)];
+        float s, co;
+        ts_sincos<NS>(xi * fr, s, co);
+        d[r] = fr * co;
+        d[r + 1] = -fr * s;
+    }
+}
 }  // namespace ts
+
+template <int NS>
+__global__ __launch_bounds__(256) void dpn_features_kernel(FwdArgs a, char* feat) {
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int64_t tile0 = (int64_t)blockIdx.x * 2;
+    char* ft = feat + (int64_t)blockIdx.x * ts::feat_tile_bytes<NS>();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int64_t pt = (tile0 + p) * 32 + j;
+        const int64_t pc = pt < a.n ? pt : (a.n - 1);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const int ks = 3 * w + kk;
+            Frag<NS> f3, f6;
+            ts::pe3_frag<NS>(f3, a, ks, h, pc);
+            ts::pe6_frag<NS>(f6, a, ks, h, pc);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                *reinterpret_cast<u32x4*>(ft + ((ks * 2 + p) * NS + s) * 1024 + lane * 16) = f3.w[s];
+                *reinterpret_cast<u32x4*>(ft + ts::feat_pe_bytes<NS>() + ((ks * 2 + p) * NS + s) * 1024 + lane * 16) = f6.w[s];
+            }
+        }
+        if (w < 3) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float d[16];
+                ts::dpe_tile<NS>(d, a, w, t, h, pc);
+                f32x4* o = reinterpret_cast<f32x4*>(ft + 2 * ts::feat_pe_bytes<NS>() + (((w * 2 + t) * 2 + p) * 64 + lane) * 64);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = f32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+            }
+        }
+    }
+}
+
+// Experiment build (-DDPN_TIMELINE -DTS_TIMELINE, tools/tiles_timeline.py): lane 0 of every wave writes the shader clock at the phase
+// boundaries below to a.timeline[workgroup][wave][stamp]
+#if defined(TS_TIMELINE) && defined(DPN_TIMELINE)
+#define TS_STAMP(I) do { if (a.timeline && lane == 0) a.timeline[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 48 + (I)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#else
+#define TS_STAMP(I) do { } while (0)
+#endif
 
 template <int NS>
 __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
@@ -133,12 +307,21 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const char* pk = a.packed + (long)net * pack_bytes_per_net(NS);
+#if TS_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    TS_STAMP(0);
     float* vec = reinterpret_cast<float*>(lds + C::kVecOff);
     float* red = reinterpret_cast<float*>(lds + C::kRedOff);
     char* xl = lds + lane * 16;
-    {   // permuted fp32 vectors of this net -> LDS (published by the first barrier)
-        const float* gv = reinterpret_cast<const float*>(pk + (long)kPackKB * 1024 * NS);
-        for (int i = threadIdx.x; i < ts::kVecFloats; i += 256) vec[i] = gv[i];
+    {   // permuted fp32 vectors of this net -> LDS (published by the first barrier): 385 x 16 bytes, both loads of a thread in flight
+        const u32x4* gv = reinterpret_cast<const u32x4*>(pk + (long)kPackKB * 1024 * NS);
+        static_assert(ts::kVecFloats % 4 == 0 && ts::kVecFloats / 4 <= 512, "vector block");
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
+        const u32x4 v0 = gv[i0];
+        const u32x4 v1 = gv[i1 < ts::kVecFloats / 4 ? i1 : i0];
+        reinterpret_cast<u32x4*>(vec)[i0] = v0;
+        if (i1 < ts::kVecFloats / 4) reinterpret_cast<u32x4*>(vec)[i1] = v1;
     }
     const int64_t tile0 = (int64_t)blockIdx.x * 2;                  // first of this workgroup's two 32-point column tiles
     int64_t pc[2];
@@ -153,6 +336,9 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     const ts::Ident I = ts::make_ident(j, h);
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     const bool save = a.saved != nullptr;
+    // features of this workgroup's 64 points, evaluated once per point by dpn_features_kernel (stored behind the saved state); without a
+    // saved-state buffer (inference, fields-only calls) they are evaluated here
+    const char* ft = save ? reinterpret_cast<const char*>(a.saved) + saved_state_bytes(a.n_pad, NS) + (int64_t)blockIdx.x * ts::feat_tile_bytes<NS>() : nullptr;
     const int64_t tiles32 = a.n_pad / 32;
     auto chunk = [&](const int kb) __attribute__((always_inline)) { return pk + (long)kb * 1024 * NS; };
 
@@ -174,36 +360,35 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         }
     };
 
-    // ---------------- coordinate features pe3 -> X (k-steps 0..11): this thread builds k-steps 3w .. 3w+2 of both column tiles
-    {
+    ts::Head<NS, 2> H;
+    ts::gemm_head<NS, 12, 2>(chunk(kS0 + 2 * w * 12), lane, H);
+    // ---------------- coordinate features pe3 -> X (k-steps 0..11)
+    if (ft) {                                // linear copy of the stored image: 16 bytes per thread and step, all loads in flight at once
+        constexpr int kSteps = ts::feat_pe_bytes<NS>() / 4096;
+        u32x4 v[kSteps];
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const int ks = 3 * w + kk, c = ks >> 2;                                   // wave-uniform
-            const float* src = (c == 0) ? a.x : (c == 1) ? a.y : a.t;
-            const float d1 = (c == 0) ? a.geo.dx : (c == 1) ? a.geo.dy : a.geo.pred_t_span;
-            const float d2 = (c == 0) ? a.geo.lon_m1 : (c == 1) ? a.geo.lat_m1 : 1.0f;   // x / dx / (lon-1): two fp32 divisions (interface_physics.py:324-326); t: one
-            float fr[4];
+        for (int i = 0; i < kSteps; ++i) v[i] = reinterpret_cast<const u32x4*>(ft)[threadIdx.x + 256 * i];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fr[q] = a.freqs[8 * (ks & 3) + 4 * h + q];
+        for (int i = 0; i < kSteps; ++i) reinterpret_cast<u32x4*>(lds)[threadIdx.x + 256 * i] = v[i];
+    } else {                                 // this thread builds k-steps 3w .. 3w+2 of both column tiles
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const float xi = src[pc[p]] / d1 / d2;
                 Frag<NS> f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float s, co;
-                    sincos_t<NS>(xi * fr[q], s, co);
-                    frag_set2<NS>(f, q, s, co);
-                }
-                ts::x_store<NS>(xl, ks, p, f);
+                ts::pe3_frag<NS>(f, a, 3 * w + kk, h, pc[p]);
+                ts::x_store<NS>(xl, 3 * w + kk, p, f);
             }
-        }
     }
+    TS_STAMP(1);
     ts::barrier_lds();
     // ---------------- L1: pre1 = w1 . pe + b1 ; h1 = relu -> X ; relu mask bits -> m1w
     u32 m1w[2] = {0u, 0u};
     init_all(kVecB1, 1.0f);
-    ts::gemm<NS, 12, 2>(chunk(kS0 + 2 * w * 12), xl, lane, acc);
+    TS_STAMP(2);
+    ts::gemm<NS, 12, 2>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
+    TS_STAMP(3);
+    ts::gemm_head<NS, 16, 2>(chunk(kS1 + 2 * w * 16), lane, H);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -215,36 +400,42 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
                 m1w[p] |= (on0 ? (1u << (16 * t + r)) : 0u) | (on1 ? (2u << (16 * t + r)) : 0u);
                 frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, on0 ? p0 : 0.f, on1 ? p1 : 0.f);
             }
+    // make the mask words opaque HERE: left alone, the compiler proves (m1w >> k) & 1 == the k-th compare and keeps all 64 compare results
+    // alive (as lane masks in SGPRs, spilled through v_writelane, and in scratch) until the y layer's epilogue instead of the two words
+    asm volatile("" : "+v"(m1w[0]), "+v"(m1w[1]));
     if (save) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)          // word w of the lane's uint4 = tiles 2w (low half), 2w+1 (high half): the ring kernel's m1w[T >> 1]
             reinterpret_cast<u32*>(sv.m1 + ((int64_t)net * tiles32 + tile0 + p) * 64 + lane)[w] = m1w[p];
     }
+    TS_STAMP(4);
     ts::barrier_lds();                       // everybody is done reading pe3
     x_store_all();
+    TS_STAMP(5);
     ts::barrier_lds();
     // ---------------- L2: c = w2 . h1 + Wd . pe6 + (b2 + bd + e) -> X ; cdot = wo . c
     init_all(kVecCvec, 1.0f);
-    ts::gemm<NS, 16, 2>(chunk(kS1 + 2 * w * 16), xl, lane, acc);
-    {   // data features pe6 (SineCosPE(6,16) of coord_data): k-steps 3w .. 3w+2 of both column tiles, built while the accumulators wait
+    TS_STAMP(6);
+    ts::gemm<NS, 16, 2>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
+    TS_STAMP(7);
+    ts::gemm_head<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), lane, H);
+    if (ft) {   // data features pe6: copy of the stored image
+        constexpr int kSteps = ts::feat_pe_bytes<NS>() / 4096;
+        u32x4 v[kSteps];
+#pragma unroll
+        for (int i = 0; i < kSteps; ++i) v[i] = reinterpret_cast<const u32x4*>(ft + ts::feat_pe_bytes<NS>())[threadIdx.x + 256 * i];
+    TS_STAMP(8);
+        ts::barrier_lds();                   // everybody is done reading h1
+#pragma unroll
+        for (int i = 0; i < kSteps; ++i) reinterpret_cast<u32x4*>(lds)[threadIdx.x + 256 * i] = v[i];
+    TS_STAMP(9);
+        ts::barrier_lds();
+    } else {    // data features pe6 (SineCosPE(6,16) of coord_data): k-steps 3w .. 3w+2 of both column tiles, built while the accumulators wait
         Frag<NS> f6[3][2];
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const int ks = 3 * w + kk;
-            float fr[4];
+        for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fr[q] = a.freqs[32 + 8 * (ks & 1) + 4 * h + q];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const float v = a.coord_data[pc[p] * 6 + (ks >> 1)];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float s, co;
-                    sincos_t<NS>(v * fr[q], s, co);
-                    frag_set2<NS>(f6[kk][p], q, 1.0f * s, 1.0f * co);
-                }
-            }
-        }
+            for (int p = 0; p < 2; ++p) ts::pe6_frag<NS>(f6[kk][p], a, 3 * w + kk, h, pc[p]);
         ts::barrier_lds();                   // everybody is done reading h1
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk)
@@ -252,7 +443,10 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
             for (int p = 0; p < 2; ++p) ts::x_store<NS>(xl, 3 * w + kk, p, f6[kk][p]);
         ts::barrier_lds();
     }
-    ts::gemm<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, acc);
+    TS_STAMP(10);
+    ts::gemm<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc);
+    TS_STAMP(11);
+    ts::gemm_head<NS, 16, 2>(chunk(kS2 + 2 * w * 16), lane, H);
     float cdot[2] = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -269,12 +463,17 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
             for (int r = 0; r < 16; r += 2) frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, acc[t][p][r], acc[t][p][r + 1]);
         }
     }
+    TS_STAMP(12);
     ts::barrier_lds();
     x_store_all();
+    TS_STAMP(13);
     ts::barrier_lds();
     // ---------------- fc1: pre2 = W1 . c + bf1 ; out = u . relu(pre2) + 2 wo . c + const ; t2 = m2 (.) u -> X ; M2 -> saved
     init_all(kVecBf1, 1.0f);
-    ts::gemm<NS, 16, 2>(chunk(kS2 + 2 * w * 16), xl, lane, acc);
+    TS_STAMP(14);
+    ts::gemm<NS, 16, 2>(chunk(kS2 + 2 * w * 16), xl, lane, H, acc);
+    TS_STAMP(15);
+    if (save || a.jac_n) ts::gemm_head<NS, 16, 2>(chunk(kS3 + 2 * w * 16), lane, H);
     float adot[2] = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -308,8 +507,10 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         o += __shfl_xor(o, 32);
         if (h == 0) red[w * 64 + p * 32 + j] = o;
     }
+    TS_STAMP(16);
     ts::barrier_lds();
     x_store_all();
+    TS_STAMP(17);
     ts::barrier_lds();
     if (w == 0) {                            // lane (j, h) finishes point j of column tile h: the four waves' shares in a fixed order
         const int64_t pt = (tile0 + h) * 32 + j;
@@ -322,7 +523,10 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     if (!save && !a.jac_n) return;
     // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> X (+ saved V)
     init_all(kVecWo, 2.0f);
-    ts::gemm<NS, 16, 2>(chunk(kS3 + 2 * w * 16), xl, lane, acc);
+    TS_STAMP(18);
+    ts::gemm<NS, 16, 2>(chunk(kS3 + 2 * w * 16), xl, lane, H, acc);
+    TS_STAMP(19);
+    ts::gemm_head<NS, 16, 2>(chunk(kS4 + 2 * w * 16), lane, H);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -331,13 +535,18 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
             for (int r = 0; r < 16; r += 2) frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, acc[t][p][r], acc[t][p][r + 1]);
             if (save) ts::save_tile_k<NS, NS>(sv.V, net, tile0 + p, 2 * w + t, lane, I, zero_rows[p], F[t][p][0], F[t][p][1]);
         }
+    TS_STAMP(20);
     ts::barrier_lds();
     x_store_all();
+    TS_STAMP(21);
     ts::barrier_lds();
     // ---------------- y = w2^T v ; t1 = m1 (.) y -> X (+ saved T1)
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc[t][0] = (f32x16)0.f; acc[t][1] = (f32x16)0.f; }
-    ts::gemm<NS, 16, 2>(chunk(kS4 + 2 * w * 16), xl, lane, acc);
+    TS_STAMP(22);
+    ts::gemm<NS, 16, 2>(chunk(kS4 + 2 * w * 16), xl, lane, H, acc);
+    TS_STAMP(23);
+    if (a.jac_n && w < 3) ts::gemm_head<NS, 16, 2>(chunk(kS5 + 2 * w * 16), lane, H);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -350,34 +559,36 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
             if (save) ts::save_tile_k<NS, NS>(sv.T1, net, tile0 + p, 2 * w + t, lane, I, zero_rows[p], F[t][p][0], F[t][p][1]);
         }
     if (!a.jac_n) return;
+    TS_STAMP(24);
     ts::barrier_lds();
     x_store_all();
+    TS_STAMP(25);
     ts::barrier_lds();
     // ---------------- gpe = w1^T t1 (6 tiles: waves 0..2; both tiles of wave w belong to coordinate c = w), contracted with d(pe)/d(xi)
     if (w >= 3) return;
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc[t][0] = (f32x16)0.f; acc[t][1] = (f32x16)0.f; }
-    ts::gemm<NS, 16, 2>(chunk(kS5 + 2 * w * 16), xl, lane, acc);
+    TS_STAMP(26);
+    ts::gemm<NS, 16, 2>(chunk(kS5 + 2 * w * 16), xl, lane, H, acc);
+    TS_STAMP(27);
     {
         const int c = w;
-        const float* src = (c == 0) ? a.x : (c == 1) ? a.y : a.t;
-        const float d1 = (c == 0) ? a.geo.dx : (c == 1) ? a.geo.dy : a.geo.pred_t_span;
-        const float d2 = (c == 0) ? a.geo.lon_m1 : (c == 1) ? a.geo.lat_m1 : 1.0f;
         float jc[2] = {0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const float xi = src[pc[p]] / d1 / d2;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
+                float d[16];
+                if (ft) {
+                    const f32x4* tab = reinterpret_cast<const f32x4*>(ft + 2 * ts::feat_pe_bytes<NS>() + (((c * 2 + t) * 2 + p) * 64 + lane) * 64);
 #pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {            // register pair (sin, cos) of one angle: k-step 2T + (r >> 3) of the coordinate PE
-                    const int r = 2 * rp;
-                    const float fr = a.freqs[8 * ((2 * t + (r >> 3)) & 3) + 4 * h + ((r & 7) >> 1)];
-                    float s, co;
-                    sincos_t<NS>(xi * fr, s, co);
-                    jc[p] = fmaf(acc[t][p][r], fr * co, jc[p]);
-                    jc[p] = fmaf(acc[t][p][r + 1], -fr * s, jc[p]);
+                    for (int q = 0; q < 4; ++q) { const f32x4 x = tab[q]; d[4 * q] = x[0]; d[4 * q + 1] = x[1]; d[4 * q + 2] = x[2]; d[4 * q + 3] = x[3]; }
+                } else {
+                    ts::dpe_tile<NS>(d, a, c, t, h, pc[p]);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) jc[p] = fmaf(acc[t][p][r], d[r], jc[p]);
+            }
             jc[p] += __shfl_xor(jc[p], 32);
         }
         // lane (j, h) stores point j of column tile h; chain rule through x / dx / (lon - 1), in the reference's backward order
@@ -389,4 +600,5 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
             a.jac_n[(pt * 6 + net) * 3 + c] = mine / g1 / g2;
         }
     }
+    TS_STAMP(28);
 }

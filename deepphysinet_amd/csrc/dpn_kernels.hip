@@ -574,7 +574,11 @@ DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
     s.m1 = reinterpret_cast<uint4*>(b + 2 * mat + (int64_t)kNets * n_pad * 512);
     return s;
 }
-static int64_t saved_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 512 + (int64_t)kNets * n_pad * 32; }
+DPN_HD int64_t saved_state_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 512 + (int64_t)kNets * n_pad * 32; }
+// the saved state is followed by the positional features of the tile-split forward kernel (dpn_fwd_tiles.h: per 64 points the pe3 and pe6
+// fragment images and the d pe3 / d xi table, evaluated once per point instead of once per point and net)
+DPN_HD int64_t feature_bytes(int64_t n_pad, int ns) { return (n_pad / 64) * (int64_t)(2 * 12 * 2 * ns * 1024 + 3 * 2 * 2 * 64 * 64); }
+static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_pad, ns) + feature_bytes(n_pad, ns); }
 
 struct OperandView {     // written by dpn_bwd_points
     KMat Z1, Z;          // [6][NS] x 256
@@ -2212,6 +2216,11 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
     const bool tiles = force ? (force[0] == 't') : (prec == 2);
     if (tiles && !pe_in) {
         const dim3 grid64((unsigned)(a.n_pad / 64), kNets);
+        if (saved) {                                   // positional features once per point (read by the six nets' workgroups)
+            char* feat = reinterpret_cast<char*>(saved) + saved_state_bytes(a.n_pad, prec);
+            if (prec == 1) hipLaunchKernelGGL(dpn_features_kernel<1>, dim3(grid64.x), dim3(256), 0, s, a, feat);
+            else hipLaunchKernelGGL(dpn_features_kernel<2>, dim3(grid64.x), dim3(256), 0, s, a, feat);
+        }
         if (prec == 1) hipLaunchKernelGGL(dpn_fwd_tiles_kernel<1>, grid64, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(dpn_fwd_tiles_kernel<2>, grid64, dim3(256), 0, s, a);
         return ck(hipGetLastError());
