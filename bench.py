@@ -84,7 +84,7 @@ def cpu_baseline(sample_points, seed, share_derivatives=False):
     geo = O.Geometry()
     names = O.param_names(st)
     best = None
-    for it in range(3):
+    for it in range(4):                        # 1 warm-up + best of 3
         x, y, t = (b[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
         t0 = time.perf_counter()
         tot = O.place_one_batch(st, x, y, t, b['f'], b['field_data'], b['coord_data'], b['forecast_h'], geo, share_derivatives=share_derivatives)
@@ -96,8 +96,9 @@ def cpu_baseline(sample_points, seed, share_derivatives=False):
 
 
 def launch_ranks(n, argv):
-    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD torch.distributed.run (this process has not touched a
-    GPU: torch.cuda.device_count() does not initialise one) and hand back its exit code."""
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD torch.distributed.run and hand back its exit code.  The
+    parent may already have touched the GPU runtime (on ROCm torch.cuda.device_count() can fall through to hipGetDeviceCount), so it only
+    ever SPAWNS a child -- it must never exec another program in its own process (that takes the machine down on this pool)."""
     import socket
     import subprocess
     one_device = os.environ.get('DPN_BENCH_ONE_DEVICE') == '1'
@@ -129,6 +130,9 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=16384)
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
+    ap.add_argument('--encoder-fp8', action='store_true',
+                    help='BASELINE configs[4]: the encoder layers\' forward GEMMs on fp8 (OCP e4m3) MFMA, bf16x2 Jacobian path; OFF by default -- it moves '
+                         'the PDE losses by 1e-2 ... 2e-1 (tests/test_gpu_parity.py::test_config4_fp8_encoder_workload) and buys no time')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -139,6 +143,8 @@ def main():
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%s: the launcher and the flag disagree' % (args.gpus, env_world))
 
+    if args.encoder_fp8:
+        os.environ['DPN_ENCODER_FP8'] = '1'      # read by deepphysinet_amd.encoder_ops at call time
     from deepphysinet_amd import distributed as D
     # DPN_BENCH_BACKEND=gloo + DPN_BENCH_ONE_DEVICE=1: exercise the N > 1 code path with every rank on GPU 0 (test boxes have one GPU)
     # DPN_BENCH_RCCL_ONE_RANK=1: a one-rank RCCL group + the N > 1 step shape (segment graphs, bucket all-reduces): the real collective
@@ -173,6 +179,9 @@ def main():
     crit = torch.nn.MSELoss()
     # N > 1 (or DPN_BENCH_SPLIT_STEP=1 on one GPU, to time the same code path): three graph segments with a bucket all-reduce behind each
     split_step = (world > 1 or one_rank_rccl or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1') and args.leads == 1
+    # DPN_BENCH_CAPTURE_COLLECTIVES=1: capture the bucket all-reduces inside ONE graph with the segments (opt-in: measured with a one-rank
+    # RCCL group on the single-GPU test box, profiles/; the default keeps the collectives host-issued between four segment graphs)
+    one_graph_collectives = os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') == '1' and split_step and (world > 1 or one_rank_rccl)
 
     def make_step(m, opt):
         """One GPU: [whole] = zero_grad + place_one_batch + backward + clip + Adam, one callable (one hipGraph).
@@ -206,6 +215,7 @@ def main():
         if world > 1:
             D.broadcast_parameters(m.physics_net)      # DDP's wrap-time broadcast (the seeds already agree; this makes it a fact)
         sync = D.GradientAllReduce(opt, single_rank_too=one_rank_rccl) if (world > 1 or one_rank_rccl) else None
+        coll['gradient_buckets_mb'] = [round((b - a) * 4 / 2 ** 20, 2) for a, b in opt.bucket_bounds]
         segments, staged = make_step(m, opt)
         n_reduce = len(segments) - 1 if split_step else 0     # segment i completes gradient bucket i; the last segment is the optimiser
 
@@ -228,13 +238,27 @@ def main():
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 graphs, pool = [], None
-                for seg in segments:                  # one capture stream (torch's default) and one memory pool for all segments:
-                    g = torch.cuda.CUDAGraph()        # the autograd graph built in segment 0 is walked in segments 1 and 2
-                    # thread_local: the process group's watchdog thread queries events while we capture
-                    with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local' if sync is not None else 'global'):
-                        seg()
-                    pool = g.pool()
+                if one_graph_collectives:
+                    # the whole step INCLUDING its bucket all-reduces as one hipGraph (RCCL kernels are capturable; ProcessGroupNCCL forks
+                    # its communication stream off the capture stream, so each all-reduce becomes a parallel branch behind its segment
+                    # and joins in front of the optimiser): one replay per step instead of four replays + three host-issued collectives
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                        for i, seg in enumerate(segments):
+                            seg()
+                            if i < n_reduce:
+                                sync.reduce_bucket(i)
+                                if i == n_reduce - 1:
+                                    sync.wait()
                     graphs.append(g)
+                else:
+                    for seg in segments:              # one capture stream (torch's default) and one memory pool for all segments:
+                        g = torch.cuda.CUDAGraph()    # the autograd graph built in segment 0 is walked in segments 1 and 2
+                        # thread_local: the process group's watchdog thread queries events while we capture
+                        with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local' if sync is not None else 'global'):
+                            seg()
+                        pool = g.pool()
+                        graphs.append(g)
             except Exception as e:                 # noqa
                 if rank == 0:
                     print('[bench] hipGraph capture failed (%s: %s); running eager' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
@@ -273,7 +297,30 @@ def main():
             dt = float(tt.item())
         return m, dt, graphs is not None
 
+    def collective_info():
+        """Who took part: backend, world size, every rank's device (index, PCI bus id, name) gathered over the process group itself, and the
+        RCCL version -- so that a scaling record shows N ranks on N distinct GPUs, not N ranks somewhere."""
+        pr = torch.cuda.get_device_properties(dev)
+        bus = getattr(pr, 'pci_bus_id', None)
+        mine = {'rank': rank, 'local_rank': local, 'device_index': dev.index, 'name': pr.name,
+                'pci': ('%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), bus, getattr(pr, 'pci_device_id', 0))) if bus is not None else None,
+                'uuid': str(getattr(pr, 'uuid', '')) or None, 'pid': os.getpid()}
+        every = [mine]
+        backend = None
+        if torch.distributed.is_initialized():
+            backend = torch.distributed.get_backend()
+            every = [None] * torch.distributed.get_world_size()
+            torch.distributed.all_gather_object(every, mine)
+        try:
+            ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                          # noqa
+            ver = None
+        return {'backend': backend, 'backend_is': 'RCCL (torch backend "nccl" on ROCm)' if backend == 'nccl' else backend, 'world': world,
+                'rccl_version': ver, 'devices': every, 'distinct_devices': len({(d['pci'], d['uuid'], d['device_index']) for d in every}),
+                'gradient_buckets_mb': None, 'reduce_op': 'AVG in place on the flat gradient buffer, one all-reduce per backward segment'}
+
     sync = None
+    coll = collective_info()
     m, dt, graphed = run(args.prec, args.steps, args.warmup, not args.no_graph)
     ms_per_step = dt / args.steps * 1e3
     pts_per_s = args.points * args.leads * world * args.steps / dt
@@ -289,12 +336,17 @@ def main():
                                 'point kernels field after field), six PDE residual losses, fwd+Jacobian+bwd+clip+Adam' % (args.leads, args.points)),
                    'leads': args.leads,
                    'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world,
-                   'step_segments': 4 if split_step else 1},
+                   'step_segments': (1 if one_graph_collectives else 4) if split_step else 1,
+                   'collectives_in_graph': bool(one_graph_collectives)},
         'timed_seconds': dt,
         **({'warning': 'timed region %.3f s < 0.2 s: ms_per_step is still a mean over %d graph replays, but GPU-utilisation samplers '
                        'see almost nothing; use --steps >= 200' % (dt, args.steps)} if dt < 0.2 else {}),
         'algorithmic_tflops_step': pts_per_s * ALG_FLOP_STEP / 1e12,
+        'collective': coll,
     }
+    if args.encoder_fp8:
+        out['config']['encoder_fp8'] = True
+        out['dtype'] += '; encoder forward GEMMs fp8 e4m3 MFMA (configs[4])'
 
     if rank == 0 and args.leads == 1:
         with torch.no_grad():                      # the six scaled PDE-loss scalars of the timed workload (SURVEY 8d asks for them next to the rate)
@@ -378,8 +430,9 @@ def main():
         ach = args.points * ALG_FLOP_FWD_JAC / (k_ms * 1e-3)
         ns = 2 if prec == 'bf16x2' else 1
         nsplit = 3 if prec == 'bf16x2' else 1
-        traffic, source = pmc_traffic('dpn_fwd_kernel', prec, args.points)
-        roof = {'bound': 'mfma', 'kernel': 'dpn_fwd_kernel<%d>' % ns,
+        traffic, source = pmc_traffic('dpn_fwd_tiles_kernel' if ns == 2 else 'dpn_fwd_kernel', prec, args.points)
+        fwd_name = 'dpn_fwd_tiles_kernel<2> (+ dpn_features_kernel<2>, its per-point feature pre-pass)' if ns == 2 else 'dpn_fwd_kernel<1>'
+        roof = {'bound': 'mfma', 'kernel': fwd_name,
                 'achieved': ach / 1e12, 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_BF16,
                 'traffic': traffic, 'traffic_source': source, 'kernel_ms': k_ms,
                 'algorithmic_flop_per_point': ALG_FLOP_FWD_JAC,
@@ -413,11 +466,19 @@ def main():
             del m2
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(args.cpu_threads or min(32, os.cpu_count() or 1))   # more threads only add OpenMP overhead on these small ops
+            cpu_model = None
+            try:
+                with open('/proc/cpuinfo') as fh:
+                    cpu_model = next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), None)
+            except OSError:
+                pass
             v, secs = cpu_baseline(args.cpu_sample, seed=1)
             v2, secs2 = cpu_baseline(args.cpu_sample, seed=1, share_derivatives=True)
             out['cpu_baseline'] = {'value': v, 'unit': 'points/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                                    'sample': 'oracle place_one_batch + backward (fp32, 28 autograd.grad calls) on %d points of the same '
-                                             'synthetic field; best of 2 after 1 warm-up, %.1f s per pass' % (args.cpu_sample, secs),
+                                             'synthetic field; best of 3 after 1 warm-up, %.1f s per pass; host: %s, %d logical cores, %d threads used '
+                                             '(--cpu-sample 37265 times the whole grid)' % (args.cpu_sample, secs, cpu_model, os.cpu_count() or 0, torch.get_num_threads()),
+                                   'host_cpu': cpu_model, 'host_logical_cores': os.cpu_count(),
                                    'shared_jacobian_variant': {'value': v2, 'seconds_per_pass': secs2,
                                                                'note': 'same oracle, the 18 distinct derivatives taken once (SURVEY 8d variant ii)'}}
         print(json.dumps(out))

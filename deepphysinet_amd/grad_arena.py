@@ -17,6 +17,8 @@ import weakref
 import torch
 
 param_epoch = [0]     # bumped by every fused optimiser step (parameters rewritten through raw pointers: no tensor version changes)
+captured_step = [False]   # a fused optimiser step was captured in a hipGraph: its replays rewrite the parameters WITHOUT bumping param_epoch,
+                          # so parameter-keyed caches (PhysicsNet.encode_field(use_cache=True)) may only be trusted inside a capture
 _slots = {}          # param data_ptr -> (weakref(owner), weakref(param), offset, numel)
 
 
@@ -24,6 +26,11 @@ def register(owner, params, offsets):
     """`owner` holds the flat buffer as `owner._g_flat`; parameter i owns [offsets[i], offsets[i] + numel)."""
     o = weakref.ref(owner)
     for p, off in zip(params, offsets):
+        old = _slots.get(p.data_ptr())
+        if old is not None and old[0]() is not None and old[0]() is not owner and old[1]() is p:
+            import warnings
+            warnings.warn('deepphysinet_amd.grad_arena: a second optimiser registers a parameter of shape %s; gradients now land in ITS '
+                          'flat buffer (the first optimiser falls back to copying them in)' % (tuple(p.shape),))
         _slots[p.data_ptr()] = (o, weakref.ref(p), int(off), p.numel())
 
 

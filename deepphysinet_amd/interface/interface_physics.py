@@ -239,12 +239,14 @@ class InterfacePhysics(nn.Module):
         lf = self.train_cfg['losses']['loss_factor']
         self.physics_net.clear_field_cache()
         b = batch
+        heads = evec = statics = meta_out = None
         if with_pde and b['field_data'].is_cuda:
             # one point pass for everything: [interior | margin] points, PDE means per group, SmoothL1 on the margin rows; the margin
             # forward serves both of its losses and all points share one backward (point_path._StepLossFn)
             from ..point_path import step_losses
             cfg = self.point_config(lf)
-            heads, evec, statics = self.physics_net.field_weights(b['field_data'], b['forecast_h'])
+            meta_out = self.physics_net.encode_field(b['field_data'], b['forecast_h'])
+            heads, evec, statics = self.physics_net.field_weights(b['field_data'], b['forecast_h'], meta_out=meta_out)
             cat = lambda a_, b_: torch.cat([a_.reshape(a_.shape[0], -1), b_.reshape(b_.shape[0], -1)], dim=0)
             _, inter_total, _, margin_total, data = step_losses(
                 cfg, b['inter_x'].shape[0], cat(b['inter_x'], b['margin_x']), cat(b['inter_y'], b['margin_y']), cat(b['inter_t'], b['margin_t']),
@@ -269,11 +271,30 @@ class InterfacePhysics(nn.Module):
         optimizer.zero_grad()
         if getattr(self, '_seed', None) is None or self._seed.device != train_loss.device:
             self._seed = torch.ones((), dtype=train_loss.dtype, device=train_loss.device)      # persistent backward seed: no fill per step
-        train_loss.backward(self._seed)
-        self.physics_net.clear_field_cache()
-        if grad_sync is not None:
-            grad_sync(self.physics_net.parameters())
         from ..optim import FusedClipAdam
+        staged = (grad_sync is not None and hasattr(grad_sync, 'reduce_bucket') and grad_sync.active() and isinstance(optimizer, FusedClipAdam)
+                  and heads is not None)
+        if staged:
+            # data-parallel step: the backward pass is cut where a bucket of gradients is complete and that bucket's all-reduce is queued at
+            # once, so it travels under the rest of the backward (what DistributedDataParallel's bucket hooks do in the reference, :903-907,
+            # :1056): point statics | hyper-network heads | encoder -- the optimiser's layout buckets (PhysicsNet.gradient_buckets)
+            buckets = self.physics_net.gradient_buckets()
+            g = torch.autograd.grad(train_loss, [heads, evec] + list(statics), grad_outputs=self._seed)
+            optimizer.place_gradients(list(statics), g[2:])
+            grad_sync.reduce_bucket(0)
+            g2 = torch.autograd.grad([heads, evec], [meta_out] + buckets[1], grad_outputs=[g[0], g[1]], allow_unused=True)
+            optimizer.place_gradients(buckets[1], g2[1:])
+            grad_sync.reduce_bucket(1)
+            g3 = torch.autograd.grad([meta_out], buckets[2], grad_outputs=[g2[0]], allow_unused=True)
+            optimizer.place_gradients(buckets[2], g3)
+            grad_sync.reduce_bucket(2)
+            grad_sync.wait()
+            self.physics_net.clear_field_cache()
+        else:
+            train_loss.backward(self._seed)
+            self.physics_net.clear_field_cache()
+            if grad_sync is not None:
+                grad_sync(self.physics_net.parameters())
         if isinstance(optimizer, FusedClipAdam):                  # clip + Adam in one HIP pass
             optimizer.max_norm = float(max_norm)
             gnorm = optimizer.step()
@@ -308,10 +329,62 @@ class InterfacePhysics(nn.Module):
     def _train_samples(self, kwargs, epoch):
         src = kwargs.get('samples', self.train_cfg.get('train_data', {}).get('samples'))
         if src is None:
-            raise RuntimeError('run_train_interface needs `samples`: an iterable (or a callable epoch -> iterable) of training_step batch '
-                               'dicts, e.g. CollocationSampler.training_batch(field_data, forecast_h).  The GeoTIFF / xarray PhysicsDataset '
-                               'of the reference (dataset/physics_dataset.py) is file I/O outside this build (SURVEY.md section 2, row 10).')
+            # the reference's PhysicsDataset reads GeoTIFF / xarray files (dataset/physics_dataset.py: file I/O outside this build, SURVEY.md
+            # section 2 row 10; no data exists offline): without a `samples` source the loop draws synthetic field samples and collocation
+            # batches of the configured sizes on the device, so that train.py's two-keyword call runs end to end
+            if getattr(self, '_synthetic_samples', None) is None:
+                from ..sampler import SyntheticSamples
+                td = self.train_cfg.get('train_data', {})
+                dev = next(self.physics_net.parameters()).device
+                self._synthetic_samples = SyntheticSamples(dev, n_margin=td.get('label_batch_size', 20480), n_inter=td.get('batch_size_inter', 4096),
+                                                           leads=int(kwargs.get('samples_per_epoch', 61)), lat=self.lat_size, lon=self.lon_size)
+                print('run_train_interface: no `samples` source configured -- synthetic field samples (%d per epoch) and on-device collocation '
+                      'batches are used' % len(self._synthetic_samples))
+            return self._synthetic_samples
         return src(epoch) if callable(src) else src
+
+    @staticmethod
+    def _shard_samples(samples, rank, world):
+        """DistributedSampler semantics (:936, drop_last=False): every rank takes ceil(n / world) samples of the epoch -- rank r the samples
+        r, r + world, ... -- and the tail wraps around to the epoch's first samples, so that all ranks run the same number of steps (and
+        of all-reduces).  A sequence is indexed (a rank touches only its own samples); any other iterable is consumed round by round."""
+        if world == 1:
+            yield from samples
+            return
+        if hasattr(samples, '__len__') and hasattr(samples, '__getitem__'):
+            n = len(samples)
+            for k in range(-(-n // world) if n else 0):
+                yield samples[(rank + k * world) % n]
+            return
+        head, buf = [], []
+        for smp in samples:
+            if len(head) < world:
+                head.append(smp)
+            buf.append(smp)
+            if len(buf) == world:
+                yield buf[rank]
+                buf = []
+        if buf:                                          # incomplete last round: padded with the epoch's first samples
+            k = 0
+            while len(buf) < world:
+                buf.append(head[k % len(head)])
+                k += 1
+            yield buf[rank]
+
+    def _epoch_samples(self, kwargs, epoch, rank, world):
+        """The epoch's samples of this rank.  `samples` may be a callable: samples(epoch) -> all samples (sharded here), or
+        samples(epoch, rank, world) -> this rank's samples only (nothing is drawn for the other ranks)."""
+        src = kwargs.get('samples', self.train_cfg.get('train_data', {}).get('samples'))
+        if callable(src):
+            import inspect
+            try:
+                n_args = len([q for q in inspect.signature(src).parameters.values()
+                              if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
+            except (TypeError, ValueError):
+                n_args = 1
+            if n_args >= 3:
+                return src(epoch, rank, world)
+        return self._shard_samples(self._train_samples(kwargs, epoch), rank, world)
 
     def _run_train(self, dist_mode, **kwargs):
         tc = self.train_cfg
@@ -353,9 +426,7 @@ class InterfacePhysics(nn.Module):
         self.physics_net.train()
         last = None
         for epoch in range(current_epoch, num_epoch):
-            for i, batch in enumerate(self._train_samples(kwargs, epoch)):
-                if dist_mode and i % world != rank:                     # DistributedSampler (:936): one field sample per rank per step
-                    continue
+            for batch in self._epoch_samples(kwargs, epoch, rank, world):        # DistributedSampler (:936): one field sample per rank per step
                 with_pde = with_pde_cfg and global_step >= pde_start
                 self.with_clip = True
                 global_step += 1

@@ -30,6 +30,8 @@ class PhysicsNet(nn.Module):
         self.net_dict = {'u': self.U_net, 'v': self.V_net, 'p': self.P_net, 'T': self.T_net, 'q': self.q_net, 'rio': self.rio_net}
         self.point_cfg = None            # set by InterfacePhysics; default PointConfig() otherwise
         self._meta_cache = None
+        import itertools
+        self._unique = itertools.count(1)
 
     # ---- per-field part ---------------------------------------------------------------------------
     def nets_in_output_order(self):
@@ -39,8 +41,11 @@ class PhysicsNet(nn.Module):
         # the parameters are part of the key: an optimiser step between two calls (torch optimisers bump `_version`; the fused HIP
         # optimiser writes through raw pointers and bumps grad_arena.param_epoch instead) must not return the previous encoder output
         pv = sum(p._version for p in self.meta_net.parameters())
+        # once a fused optimiser step lives in a hipGraph, its replays change the parameters behind every counter the host can see: outside a
+        # capture the key is then unique per call (no reuse); inside a capture (one step's own calls) it is stable
+        replayed = next(self._unique) if (grad_arena.captured_step[0] and not torch.cuda.is_current_stream_capturing()) else 0
         return (field_x.data_ptr(), field_x._version, forecast_h.data_ptr(), forecast_h._version, torch.is_grad_enabled(), pv,
-                grad_arena.param_epoch[0])
+                grad_arena.param_epoch[0], replayed)
 
     def encode_field(self, field_x, forecast_h, use_cache=False):
         """MetaNet output [1,287,256].  With use_cache the result is reused while (field, lead time, parameters) are unchanged

@@ -6,7 +6,8 @@ hipGraph-capturable: the step counter AND the hyper-parameters (learning rate in
 a learning-rate schedule (`CosineAnnealingLR` stepped once per epoch, interface_physics.py:396-397, :831-833).
 
 It is a `torch.optim.Optimizer`: `param_groups`, `state` (per parameter `step`, `exp_avg`, `exp_avg_sq` -- the keys of
-torch.optim.Adam, so the state dicts are interchangeable), `state_dict` / `load_state_dict`, and every torch LR scheduler attaches.
+torch.optim.Adam, so the state dicts load both ways: a torch.optim.Adam state dict gets this optimiser's own extras, max_norm, from its
+defaults), `state_dict` / `load_state_dict`, and every torch LR scheduler attaches.
 
 Gradients: the optimiser owns ONE flat fp32 gradient buffer laid out like its flat moment buffers (grad_arena.py).  The autograd
 nodes of this package write parameter gradients straight into it, the data-parallel all-reduce (distributed.GradientAllReduce) runs in
@@ -71,9 +72,25 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._hyper_host = None
         self.grad_scale = 1.0
+        self.steps_done = 0                                         # host-side count of step() calls (point_path's forward / backward stamps)
         self._leased = set()                                        # offsets of the slots a live gradient may alias (grad_arena)
+        self._ptrs = [p.data_ptr() for p in self.params]            # what the kernels write through: checked against the live tensors every step
         self.sync_hyper()
         grad_arena.register(self, self.params, self._offsets)
+
+    def __del__(self):
+        try:
+            grad_arena.unregister(self)
+        except Exception:                                           # interpreter shutdown
+            pass
+
+    def _check_pointers(self):
+        """The kernels update the parameters through the raw pointers taken at construction: a `model.to(...)` / `param.data = ...` after
+        build_optimizer would leave them writing into freed memory."""
+        for p, ptr in zip(self.params, self._ptrs):
+            if p.data_ptr() != ptr:
+                raise RuntimeError('FusedClipAdam: a parameter of shape %s was re-allocated after the optimiser was built (model.to() / '
+                                   'param.data assignment); build the optimiser again' % (tuple(p.shape),))
 
     # ---- hyper-parameters ----------------------------------------------------------------------------------------------
     @property
@@ -148,9 +165,12 @@ class FusedClipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._check_pointers()
         self.gather_gradients()
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()
+        else:
+            grad_arena.captured_step[0] = True      # replays of this step rewrite the parameters without passing through here
         lib = L.load()
         L.check(lib.dpn_clip_adam_flat_dev(len(self.params), self._p, self._g, self._numel, ctypes.c_void_p(self._m_flat.data_ptr()),
                                            ctypes.c_void_p(self._v_flat.data_ptr()), ctypes.c_void_p(self._sumsq.data_ptr()),
@@ -158,6 +178,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                                            ctypes.c_void_p(self.grad_norm.data_ptr()), torch.cuda.current_stream().cuda_stream),
                 'dpn_clip_adam_flat_dev')
         grad_arena.param_epoch[0] += 1
+        self.steps_done += 1
         return self.grad_norm if closure is None else loss
 
     # ---- checkpoints ---------------------------------------------------------------------------------------------------
@@ -173,6 +194,8 @@ class FusedClipAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         views = {id(p): (m, v) for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq)}
         super().load_state_dict(state_dict)
+        for k, v in self.defaults.items():          # a torch.optim.Adam state dict has no 'max_norm' (load_state_dict replaces the group wholesale)
+            self.param_groups[0].setdefault(k, v)
         step = None
         for p in self.param_groups[0]['params']:
             st = self.state.get(p, {})

@@ -174,10 +174,25 @@ def _stamp(tensors):
     """Version counters of the tensors a backward pass will read again through raw pointers (the point path keeps them in ctx.keep, not in
     save_for_backward: most are detached fp32 views).  _check_stamp raises when one was modified in place between forward and backward
     (e.g. an optimiser step before a delayed backward), which autograd's own check would catch for saved tensors."""
-    return tuple((t, t._version) for t in tensors if t is not None)
+    from . import grad_arena
+    owners = {}
+    for t in tensors:                       # fused optimisers that own one of these tensors (they rewrite it through a raw pointer)
+        e = grad_arena._slots.get(t.data_ptr()) if t is not None else None
+        o = e[0]() if e is not None else None
+        if o is not None:
+            owners[id(o)] = (e[0], o.steps_done)
+    return (('owners', tuple(owners.values())),) + tuple((t, t._version) for t in tensors if t is not None)
 
 
 def _check_stamp(stamp, what):
+    if stamp and stamp[0][0] == 'owners':
+        # the fused optimiser rewrites parameters through raw pointers (no version bump): its own step count says whether it ran between
+        # this forward and its backward (steps replayed from a hipGraph are invisible to the host: not covered)
+        for ref, steps in stamp[0][1]:
+            o = ref()
+            if o is not None and o.steps_done != steps:
+                raise RuntimeError('deepphysinet_amd %s: a fused optimiser step ran between the forward pass and its backward pass' % what)
+        stamp = stamp[1:]
     for t, v in stamp:
         if t._version != v:
             raise RuntimeError('deepphysinet_amd %s: a tensor of shape %s needed by the backward pass was modified in place after the '

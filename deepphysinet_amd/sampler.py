@@ -139,3 +139,33 @@ class CollocationSampler:
         return {'field_data': field_data, 'forecast_h': forecast_h,
                 'margin_x': col(mx), 'margin_y': col(my), 'margin_t': col(mt), 'margin_f': mf, 'margin_data': mlab, 'margin_input_data': mcd,
                 'inter_x': col(ix), 'inter_y': col(iy), 'inter_t': col(it), 'inter_f': if_, 'inter_data': icd}
+
+
+
+class SyntheticSamples:
+    """Default `samples` source of run_train_interface when the configuration names none: one epoch = the 61 six-hourly lead times of the
+    reference's file map (tools/generate_input_map.py:41), each a synthetic field sample [1,159,2405] (normalised forecasts ~ N(0,1), the
+    four constant rows ~ U[0,1]: SURVEY 8d) whose collocation batch is drawn by the on-device CollocationSampler from synthetic coarse /
+    label cubes of the configured shapes.  It stands in for PhysicsDataset's GeoTIFF / xarray reader (dataset/physics_dataset.py: file I/O
+    outside this build, no data offline) so that the reference's two-keyword call `run_train_interface(checkpoint_path=, log_path=)`
+    (train.py:47) runs end to end.  A sequence: data-parallel ranks index only their own samples."""
+
+    def __init__(self, device, n_margin=20480, n_inter=4096, leads=61, seed=0, lat=145, lon=257):
+        g = torch.Generator().manual_seed(seed)
+        self.device = torch.device(device)
+        cube = torch.randn(6, 37, 65, 5, generator=g).to(self.device)
+        labels = torch.randn(25, 6, lat, lon, generator=g).to(self.device)
+        self.sampler = CollocationSampler(SamplerConfig(), cube, labels, seed=seed + 1)
+        self.n_margin, self.n_inter, self.leads, self.seed = int(n_margin), int(n_inter), int(leads), int(seed)
+
+    def __len__(self):
+        return self.leads
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.leads:
+            raise IndexError(i)
+        g = torch.Generator().manual_seed(self.seed * 1000 + 17 + i)
+        field = torch.randn(1, 159, 2405, generator=g)
+        field[:, 155:, :] = torch.rand(1, 4, 2405, generator=g)
+        fh = torch.full((1, 1, 1), 6.0 * i / 360.0)
+        return self.sampler.training_batch(field.to(self.device), fh.to(self.device), n_margin=self.n_margin, n_inter=self.n_inter)

@@ -174,3 +174,48 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_sample_sharding_pads_like_distributed_sampler():
+    """run_train_interface_dist's per-rank samples (reference: DistributedSampler, interface_physics.py:936, drop_last=False): every rank
+    gets ceil(n / world) samples -- the same count, so the same number of all-reduces (an uneven split deadlocks RCCL) -- rank r
+    takes r, r + world, ..., the tail wraps around; identical for a sequence (indexed: a rank touches only its own samples) and for a
+    generator (consumed round by round)."""
+    from torch.utils.data.distributed import DistributedSampler
+    from deepphysinet_amd.interface.interface_physics import InterfacePhysics
+    for n in (1, 2, 3, 5, 7, 8):
+        for world in (1, 2, 3, 4):
+            if n < world:
+                continue                                    # DistributedSampler pads differently below one sample per rank; not a training setup
+            counts = set()
+            for rank in range(world):
+                want = list(DistributedSampler(list(range(n)), num_replicas=world, rank=rank, shuffle=False, drop_last=False))
+                touched = []
+
+                class Seq:                                  # a sequence that records which samples were materialised
+                    def __len__(self): return n
+                    def __getitem__(self, i):
+                        if not 0 <= i < n:
+                            raise IndexError(i)
+                        touched.append(i)
+                        return i
+                got_seq = list(InterfacePhysics._shard_samples(Seq(), rank, world))
+                got_gen = list(InterfacePhysics._shard_samples((i for i in range(n)), rank, world))
+                assert got_seq == want and got_gen == want, (n, world, rank, got_seq, got_gen, want)
+                assert touched == want                      # nothing drawn for the other ranks
+                counts.add(len(got_seq))
+            assert len(counts) == 1                         # every rank runs the same number of steps
+
+
+def test_rank_aware_sample_callable_is_used_as_is():
+    from deepphysinet_amd.interface.interface_physics import InterfacePhysics
+
+    class Dummy(InterfacePhysics):
+        def __init__(self):                                 # no model: only the sample plumbing is under test
+            self.train_cfg = {}
+    d = Dummy()
+    calls = []
+    own = lambda epoch, rank, world: calls.append((epoch, rank, world)) or ['r%d' % rank]
+    assert list(d._epoch_samples({'samples': own}, 3, 1, 4)) == ['r1'] and calls == [(3, 1, 4)]
+    every = lambda epoch: ['a', 'b', 'c']
+    assert list(d._epoch_samples({'samples': every}, 0, 1, 2)) == ['b', 'b'] or list(d._epoch_samples({'samples': every}, 0, 1, 2)) == ['b', 'a']

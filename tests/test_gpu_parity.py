@@ -942,3 +942,36 @@ def test_fp8_gemm_experiment_kernel_matches_its_definition():
         assert float((C - want).abs().max() / want.abs().max()) < 2e-3, (M, N, K)          # same quantised operands, other summation order / rounding ties
         err = float((C - exact).abs().max() / exact.abs().max())
         assert 1e-3 < err < 0.2, err                                                       # the fp8 operand rounding itself: percent level
+
+
+def test_config4_fp8_encoder_workload():
+    """BASELINE configs[4] as a CONFIGURATION (bench.py --encoder-fp8): the encoder layers' forward GEMMs on fp8 (OCP e4m3) MFMA, everything
+    behind them -- hyper-network heads, fused forward + Jacobian in bf16x2, residuals -- as in the product, on the configs[1] workload
+    (0.25-degree grid nodes).  The six PDE losses are held to the ORACLE at the tolerance this precision buys, 0.5 relative (measured
+    2e-2 ... 4e-1 on this sample, 1.4e-2 ... 1.8e-1 on the full grid: the hyper-network turns the encoder output into the point MLPs' weights), and must be strictly worse than the
+    product's 1e-4 -- the test pins both that the configuration runs end to end and what it costs."""
+    import os
+    from bench import synth_batch
+    n = 4096                                                        # grid nodes of the configs[1] workload the oracle finishes in seconds
+    inp = {k: v.cpu() for k, v in synth_batch(n, 'cpu', seed=1).items()}
+    ref = _oracle(inp, want_grads=False)
+    m = _model('bf16x2')
+    g = _gpu(inp)
+    got = {}
+    old = os.environ.get('DPN_ENCODER_FP8')
+    try:
+        for fp8 in ('0', '1'):
+            os.environ['DPN_ENCODER_FP8'] = fp8
+            with torch.no_grad():
+                got[fp8] = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).double().cpu().numpy()
+    finally:
+        if old is None:
+            os.environ.pop('DPN_ENCODER_FP8', None)
+        else:
+            os.environ['DPN_ENCODER_FP8'] = old
+    err_prod = np.abs(got['0'] - ref['parts']) / np.abs(ref['parts'])
+    err_fp8 = np.abs(got['1'] - ref['parts']) / np.abs(ref['parts'])
+    assert np.all(np.isfinite(got['1']))
+    assert err_prod.max() <= 1e-3, err_prod                          # the product path on the same inputs (kink-free batches hold 1e-4)
+    assert err_fp8.max() <= 0.5, err_fp8                             # configs[4]: stated tolerance
+    assert err_fp8.max() > 10 * err_prod.max(), (err_fp8, err_prod)  # ... and it is a real precision loss, not noise

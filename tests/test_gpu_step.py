@@ -333,3 +333,144 @@ def test_point_path_detects_weights_modified_between_forward_and_backward():
         m.physics_net.U_net.out_fc.weight.mul_(1.5)
     with pytest.raises(RuntimeError, match='modified in place'):
         loss.backward()
+
+
+def test_fused_optimizer_loads_a_torch_adam_state_dict():
+    """the state dicts load BOTH ways.  A torch.optim.Adam state dict has no 'max_norm' (Optimizer.load_state_dict replaces the
+    parameter group wholesale); the fused optimiser refills its own extras from its defaults and continues with Adam's moments."""
+    m = _model(seed=3)
+    g = _gpu(synthetic_inputs(64, tag='inter'))
+    ref = torch.optim.Adam(m.physics_net.parameters(), lr=1e-4, weight_decay=1e-4)
+    ref.zero_grad()
+    _loss(m, g).backward()
+    ref.step()
+    sd = ref.state_dict()
+    opt = m.build_optimizer()
+    opt.load_state_dict(sd)
+    assert opt.max_norm == 2.5e7 and int(opt.step_count.item()) == 1
+    p0 = opt.param_groups[0]['params'][0]
+    assert torch.equal(opt.state[p0]['exp_avg'], ref.state[p0]['exp_avg'])
+    opt.zero_grad()
+    _loss(m, g).backward()
+    opt.step()                                              # no KeyError('max_norm'), second Adam step
+    assert int(opt.step_count.item()) == 2
+
+
+def test_fused_optimizer_refuses_reallocated_parameters_and_delayed_backward():
+    """the kernels write through raw pointers taken at construction -- a parameter re-allocated afterwards raises instead of
+    being updated in freed memory; and a fused step between a forward pass and its backward is detected (the tensors' version counters do
+    not move, the optimiser's own step count does)."""
+    m = _model(seed=4)
+    g = _gpu(synthetic_inputs(64, tag='inter'))
+    opt = m.build_optimizer()
+    loss = _loss(m, g)
+    opt.zero_grad()
+    _loss(m, g).backward()
+    opt.step()
+    with pytest.raises(RuntimeError, match='fused optimiser step ran between'):
+        loss.backward()
+    p = m.physics_net.U_net.out_fc.weight
+    p.data = p.data.clone()
+    opt.zero_grad()
+    _loss(m, g).backward()
+    with pytest.raises(RuntimeError, match='re-allocated'):
+        opt.step()
+
+
+def test_encoder_cache_is_not_trusted_once_a_fused_step_lives_in_a_graph():
+    """replays of a captured optimiser step rewrite the parameters without touching any host-side counter; from the capture on,
+    encode_field(use_cache=True) recomputes outside a capture instead of serving a value from before the replays."""
+    from deepphysinet_amd import grad_arena
+    m = _model(seed=7)
+    g = _gpu(synthetic_inputs(64, tag='inter'))
+    opt = m.build_optimizer(lr=1e-2)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        _loss(m, g).backward()
+        opt.step()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step(); step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    was = grad_arena.captured_step[0]
+    try:
+        with torch.cuda.graph(graph):
+            step()
+        assert grad_arena.captured_step[0]
+        with torch.no_grad():
+            a = m.physics_net.encode_field(g['field_data'], g['forecast_h'], use_cache=True).clone()
+        graph.replay(); graph.replay()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            b = m.physics_net.encode_field(g['field_data'], g['forecast_h'], use_cache=True)
+        assert not torch.equal(a, b)
+    finally:
+        grad_arena.captured_step[0] = was
+
+
+_DIST_STEP_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+import numpy as np, torch
+from deepphysinet_amd import distributed as D
+from deepphysinet_amd.configs import ncep_config
+from deepphysinet_amd.interface import builder_models
+from deepphysinet_amd.sampler import CollocationSampler, SamplerConfig
+from oracle.fill import synthetic_inputs
+rank, world, local = D.init_from_env('nccl', force=True)
+dev = torch.device('cuda:0')
+res = {{}}
+for mode in ('plain', 'staged'):
+    torch.manual_seed(5)
+    m = builder_models(**ncep_config(), precision='bf16x2').to(dev)
+    opt = m.build_optimizer()
+    gen = torch.Generator().manual_seed(0)
+    cube = torch.randn(6, 37, 65, 5, generator=gen).to(dev)
+    labels = torch.randn(25, 6, 145, 257, generator=gen).to(dev)
+    smp = CollocationSampler(SamplerConfig(), cube, labels, seed=11)
+    field = synthetic_inputs(1)['field_data'].to(dev)
+    fh = torch.full((1, 1, 1), 24.0 / 360.0, device=dev)
+    batch = smp.training_batch(field, fh, n_margin=2048, n_inter=512)
+    sync = D.GradientAllReduce(opt, single_rank_too=True) if mode == 'staged' else None
+    loss, parts, gnorm = m.training_step(batch, opt, with_pde=True, grad_sync=sync)
+    torch.cuda.synchronize()
+    res[mode] = (float(loss), float(gnorm), {{k: v.detach().cpu().numpy() for k, v in m.physics_net.state_dict().items()}})
+assert res['plain'][0] == res['staged'][0], (res['plain'][0], res['staged'][0])
+assert abs(res['plain'][1] - res['staged'][1]) <= 1e-6 * abs(res['plain'][1])
+worst = max(float(np.abs(a - res['staged'][2][k]).max()) for k, a in res['plain'][2].items())
+print('DIST_STEP_OK worst parameter difference %.3e' % worst)
+assert worst <= 1e-7, worst
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_data_parallel_training_step_overlaps_buckets_and_matches_the_plain_step(tmp_path):
+    """VERDICT r2 #4: training_step with a gradient reducer cuts its backward at the optimiser's three layout buckets and queues each
+    bucket's all-reduce at once (what bench.py's staged step does); with the real backend (RCCL, a one-rank group: AVG over one rank is the
+    identity) the step must leave the same parameters as the plain backward + optimiser step."""
+    script = tmp_path / 'dist_step.py'
+    script.write_text(_DIST_STEP_SCRIPT.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'DIST_STEP_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_train_py_two_keyword_call_runs_end_to_end(tmp_path):
+    """SURVEY section 2 row 18 / VERDICT r2 J3: `python train.py --checkpoint_path D --log_path L` (the reference's launcher flags,
+    train.py:17-19) builds the interface from the NCEP configuration and calls run_train_interface(checkpoint_path=, log_path=) exactly as
+    the reference does (train.py:47); with no `samples` source configured the loop draws synthetic field samples and on-device collocation
+    batches.  Two steps, then a resume."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    ck = str(tmp_path / 'ck')
+    for want in ('global_step 2', 'global_step 3'):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '--checkpoint_path', ck, '--log_path', str(tmp_path / 'log'),
+                            '--max_steps', want.split()[-1]], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert want in r.stdout, r.stdout[-2000:]
+        # the checkpoint is written at epoch end only; a run cut by --max_steps inside epoch 0 writes it when the epoch loop leaves
+    assert os.path.exists(os.path.join(ck, 'physics_latest.pth'))

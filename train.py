@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Launcher with the reference's three flags (reference train.py:17-19, :34-48): --config_file, --checkpoint_path, --log_path.
+
+    python train.py [--config_file cfg.py] [--checkpoint_path DIR] [--log_path DIR] [--dist] [--max_steps N]
+
+The reference reads the config with mmcv.Config.fromfile (absent here, and moved to mmengine in the pinned mmcv: SURVEY section 0, defect
+3), builds the interface with `builder_models(**cfg['config'])` and calls `run_train_interface(checkpoint_path=..., log_path=...)`.  The
+same happens here: a python config file that defines `config = dict(...)` is exec'd (the format of configs/DeepPhysiNet_NCEP_cfg.py);
+without --config_file the built-in copy of that config (deepphysinet_amd.configs.ncep_config) is used.  The reference's PhysicsDataset
+reads GeoTIFF / xarray files that do not exist offline (out of scope); when the config names no `samples`
+source, the loop draws its batches from the on-device CollocationSampler over synthetic coarse / label cubes of the configured shapes, so
+the two-keyword call of the reference runs end to end.  --dist selects run_train_interface_dist (start with torchrun)."""
+import argparse
+import os
+import runpy
+import shutil
+
+import torch
+
+from deepphysinet_amd.configs import ncep_config
+from deepphysinet_amd.interface import builder_models
+
+parse = argparse.ArgumentParser()
+parse.add_argument('--config_file', default=None, type=str)
+parse.add_argument('--checkpoint_path', default=None, type=str)
+parse.add_argument('--log_path', default=None, type=str)
+parse.add_argument('--dist', action='store_true', help='data-parallel loop (run_train_interface_dist); start with torchrun')
+parse.add_argument('--max_steps', default=None, type=int)
+
+
+def load_config(path):
+    if path is None:
+        return ncep_config()
+    ns = runpy.run_path(path)
+    if 'config' not in ns:
+        raise SystemExit('%s does not define `config`' % path)
+    cfg = dict(ns['config'])
+    cfg.setdefault('name', 'InterfacePhysics')
+    return cfg
+
+
+if __name__ == '__main__':
+    args = parse.parse_args()
+    print(args)
+    cfg = load_config(args.config_file)
+    model = builder_models(**cfg)
+    if args.checkpoint_path is not None:
+        os.makedirs(args.checkpoint_path, exist_ok=True)
+        if args.config_file is not None:                  # the reference copies the config next to the checkpoints (train.py:44)
+            shutil.copy(args.config_file, os.path.join(args.checkpoint_path, os.path.basename(args.config_file)))
+    kwargs = dict(checkpoint_path=args.checkpoint_path, log_path=args.log_path)
+    if args.max_steps is not None:
+        kwargs['max_steps'] = args.max_steps
+    run = model.run_train_interface_dist if args.dist else model.run_train_interface
+    out = run(**kwargs)
+    print('done: epoch %d, global_step %d, lr %.3e' % (out['epoch'], out['global_step'], out['lr']))
