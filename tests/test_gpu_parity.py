@@ -68,6 +68,12 @@ def test_library_is_the_hip_one_and_layout_selftest_passes():
 @pytest.mark.parametrize('n', [5197, 1037, 256, 200, 1])   # 5197: all ten weight-gradient splits, 41 workgroups per net; 1037: nine workgroups, a ragged tail of 13
 def test_fields_jacobian_losses_gradients_vs_oracle(prec, n):
     import deepphysinet_amd as dpn
+    if prec == 'bf16x2' and n >= 200:
+        # parity-grade mode, hundreds of points: no outlier / L2 allowances -- the points whose switch bits differ are identified and removed,
+        # everything else is held to the tight bars (sizes 5197 and 1037 run in test_kink_flips_are_listed_and_every_other_point_is_tight)
+        if n in (5197, 1037):
+            pytest.skip('covered by test_kink_flips_are_listed_and_every_other_point_is_tight[%d]' % n)
+        return _assert_tight_after_removing_flips(n)
     tol = TOL[prec]
     inp = synthetic_inputs(n, tag='inter')
     ref = _oracle(inp)
@@ -85,11 +91,9 @@ def test_fields_jacobian_losses_gradients_vs_oracle(prec, n):
         if n < 200:
             assert float(err.max()) < bound, k
         else:
-            # The Jacobian of a ReLU network is piecewise constant in the hidden signs: with a few hundred points one pre-activation lands
-            # within rounding distance of zero and its sign -- hence that ONE point's Jacobian row -- differs between any two arithmetics
-            # (fp32 autograd vs hi+lo bf16 MFMA; which point it is changes with the summation order of the encoder GEMMs that produce
-            # the hyper-weights; measured: 2 such points among 1037 x 6 nets, tools/jac_diag.py).  So: every point within the bound
-            # except isolated ones -- at most one point per net, or 0.2 % of the points.
+            # plain-bf16 mode only (NOT the parity-grade mode, whose checks above carry no such allowance): operands rounded to 8 bits flip
+            # many ReLU signs, and the Jacobian of a ReLU network is piecewise constant in them; isolated rows beyond the (already loose)
+            # bound are tolerated here -- at most one point per net, or 0.2 % of the points.
             bad_points = int((err > bound).any(dim=1).sum())
             assert bad_points <= max(1, (2 * n + 999) // 1000), (k, bad_points)
             assert float(torch.quantile(err.flatten(), 0.99)) < bound, k
@@ -109,11 +113,8 @@ def test_fields_jacobian_losses_gradients_vs_oracle(prec, n):
         if n < 200:
             assert err < tol['grad'] * (20.0 if n == 1 else 1.0), (name, err)
         else:
-            # Hundreds of points and more: some hidden unit of some point sits within rounding distance of its ReLU kink and its mask bit
-            # differs between the arithmetics (see the Jacobian check above); that moves ONE element of a bias / weight-row gradient by
-            # that point's whole contribution (the fp32 oracle against the fp64 oracle shows the same pattern on the same tensors,
-            # cat_fc1.fc.0.*, at 2e-4 max-norm; tools/grad_diag.py).  So: the bound in the tensor's L2 norm, and 5x the bound on the
-            # single worst element.
+            # plain-bf16 mode only: flipped mask bits move single elements of a bias / weight-row gradient by a point's whole contribution;
+            # the bound holds in the tensor's L2 norm and 5x on the single worst element (the parity-grade mode has no such fallback).
             l2 = float(d.pow(2).mean().sqrt() / (r.pow(2).mean().sqrt() + 1e-30))
             assert l2 < tol['grad'] and err < 5.0 * tol['grad'], (name, l2, err)
 
@@ -152,17 +153,17 @@ def test_grid_node_points_longest_lead_match_reference_golden(golden_dir):
     with torch.no_grad():
         heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
         out_n, jac_n = dpn.pde_fields_and_jacobian(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
-        from deepphysinet_amd.point_path import relu_masks
-        m1, m2 = relu_masks(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
-    # per term: 1e-4, the north-star bar -- unless one of the 200 points carries a ReLU / clip / vapour-switch bit that differs from the
-    # oracle arithmetic's (then that point, named here, moves a term by a few 1e-4 in ANY two fp32-class arithmetics: the reference's own
-    # fp32 run against its fp64 run does the same; test_kink_flips_are_listed_and_every_other_point_is_tight holds the rest to 1e-4)
-    o1, o2, oclip, odelta = _oracle_masks(inp)
-    clip, delta = _clip_and_delta(out_n, jac_n)
-    flipped = ((m1.cpu() != o1) | (m2.cpu() != o2)).any(dim=2).any(dim=0) | (clip != oclip).any(dim=1) | (delta != odelta)
+    # per term: 1e-4, the north-star bar, against the REFERENCE's numbers when no point of the batch carries a switch bit (ReLU / clip /
+    # vapour) that differs from the oracle arithmetic's; otherwise those points are named and removed from both sides, and the terms of
+    # the remaining points are held to 1e-4 against the oracle (which tests/test_oracle_golden.py pins to this very fixture)
+    flipped, _ = _flipped_points(m, inp)
     rel = np.abs(terms - d['parts']) / np.abs(d['parts'])
-    print('F10: points with a differing switch bit:', torch.nonzero(flipped).flatten().tolist(), 'per-term rel. error', rel)
-    assert np.all(rel <= (1e-4 if int(flipped.sum()) == 0 else 1e-3)), (terms, d['parts'], int(flipped.sum()))
+    print('F10: points with a differing switch bit:', torch.nonzero(flipped).flatten().tolist(), 'per-term rel. error (all points)', rel)
+    if int(flipped.sum()) == 0:
+        assert np.all(rel <= 1e-4), (terms, d['parts'])
+    else:
+        mine, ref_parts, idx = _terms_vs_oracle_flip_free(m, inp)
+        assert np.all(np.abs(mine - ref_parts) <= 1e-4 * np.abs(ref_parts)), (idx, mine, ref_parts)
     ref_n = torch.from_numpy(d['fields_norm'])
     assert float((out_n.cpu() - ref_n).abs().max() / ref_n.abs().max()) < TOL['bf16x2']['field']
 
@@ -178,15 +179,29 @@ def test_clip_masks_wide_outputs(golden_dir, with_clip):
     terms = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).detach().cpu().numpy()
     ok = np.isfinite(d['parts'])
     assert np.array_equal(np.isfinite(terms), ok)           # the unclipped vapour term is NaN in the reference as well
-    assert np.all(np.abs(terms[ok] - d['parts'][ok]) <= 2e-4 * np.abs(d['parts'][ok])), (terms, d['parts'])
+    flipped, _ = _flipped_points(m, inp, gain=5.0, with_clip=with_clip)
+    print('F9 (clip %d): points with a differing switch bit: %s' % (with_clip, torch.nonzero(flipped).flatten().tolist()))
+    sub = inp
+    # with the clip: the north-star 1e-4.  Without it the fields are unbounded (rho and q reach zero and below: the reference's own vapour
+    # term is NaN there) and the residuals divide by them -- an ill-conditioned evaluation in ANY arithmetic, not a switch flip: 2e-4 holds
+    # (measured 1.3e-4 on the u-momentum term, whose p_x / rho has rho within 1e-3 of zero at two points)
+    bar = 1e-4 if with_clip else 2e-4
+    if int(flipped.sum()) == 0:
+        assert np.all(np.abs(terms[ok] - d['parts'][ok]) <= bar * np.abs(d['parts'][ok])), (terms, d['parts'])
+    else:                                                     # named points removed from both sides, the rest at the north-star bar
+        assert int(flipped.sum()) <= 3
+        mine, ref_parts, _ = _terms_vs_oracle_flip_free(m, inp, gain=5.0, with_clip=with_clip)
+        assert np.all(np.abs(mine[ok] - ref_parts[ok]) <= bar * np.abs(ref_parts[ok])), (mine, ref_parts)
+        sub = _without(inp, flipped)
     if with_clip:
-        ref = _oracle(inp, gain=5.0, with_clip=True)
+        ref = _oracle(sub, gain=5.0, with_clip=True)
+        gs = _gpu(sub)
         m.physics_net.zero_grad()
-        m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).sum().backward()
+        m.pde_loss_terms(gs['x'], gs['y'], gs['t'], gs['f'], gs['field_data'], gs['coord_data'], gs['forecast_h']).sum().backward()
         for name in ('T_net.out_fc.weight', 'P_net.cat_fc1.fc.0.weight', 'q_net.coord_hidden_fc.weight'):
             r = ref['grads'][name]
             p = dict(m.physics_net.named_parameters())[name]
-            assert float((p.grad.cpu() - r).abs().max() / r.abs().max()) < 2e-3, name
+            assert float((p.grad.cpu() - r).abs().max() / r.abs().max()) < TOL['bf16x2']['grad'], name
 
 
 def test_data_loss_and_reference_forward_surface(golden_dir):
@@ -279,9 +294,14 @@ def test_full_grid_properties(prec):
     x, y, t = (cpu[kk].clone().requires_grad_(True) for kk in ('x', 'y', 't'))
     _, parts, _, _ = O.place_one_batch(st, x, y, t, cpu['f'], cpu['field_data'], cpu['coord_data'], cpu['forecast_h'], GEO, return_parts=True)
     ref = np.array([float(p.detach()) for p in parts])
-    # here the CPU oracle also recomputes the fp32 encoder with a different reduction order; this model amplifies that ~1e-7
-    # difference by ~1e3 (measured: the same HIP step with two K-tilings of the encoder GEMMs differs by up to 1e-4), hence 3x
-    assert np.all(np.abs(terms(slice(0, k)) - ref) <= 3 * TOL[prec]['loss'] * np.abs(ref)), (terms(slice(0, k)), ref)
+    if prec == 'bf16x2':
+        # parity-grade mode: the prefix's points whose switch bits differ from the oracle arithmetic's are named and removed from both sides
+        # (default-init weights put many P / T / q / rho values near a clip bound), the remaining points' six terms are held to 1e-4
+        mine, ref_ff, idx = _terms_vs_oracle_flip_free(m, cpu, st=st)
+        print('full grid, 2048-point prefix: removed points', idx)
+        assert np.all(np.abs(mine - ref_ff) <= TOL[prec]['loss'] * np.abs(ref_ff)), (mine, ref_ff, idx)
+    else:
+        assert np.all(np.abs(terms(slice(0, k)) - ref) <= 3 * TOL[prec]['loss'] * np.abs(ref)), (terms(slice(0, k)), ref)
 
 
 def test_fused_clip_adam_equals_torch():
@@ -354,7 +374,10 @@ def test_config2_forecast_lead_batch_is_a_loop_of_single_fields(golden_dir):
         # prec='bf16x2', reproduces the very same deviations: 2e-3 on `energy` at h = 0 for the first 192 points).  One such
         # point moves a batch mean by O(1/N); everything continuous (fields, losses of the other leads) stays at 1e-5.
         rel = np.abs(terms - ref['parts']) / np.abs(ref['parts'])
-        assert np.all(rel <= 2e-3) and np.median(rel) <= 2e-5, (h, terms, ref['parts'])
+        if not np.all(rel <= 1e-4):                          # name the points that changed sides, hold the rest to the north-star bar
+            mine, ref_ff, idx = _terms_vs_oracle_flip_free(m, b)
+            print('lead %d h: removed points %s' % (h, idx))
+            assert idx and np.all(np.abs(mine - ref_ff) <= 1e-4 * np.abs(ref_ff)), (h, idx, mine, ref_ff)
         import deepphysinet_amd as dpn
         with torch.no_grad():
             heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
@@ -523,7 +546,10 @@ def test_config2_lead_batch_in_one_step_equals_the_loop():
     for b in range(B):
         ref = _oracle(samples[b], want_grads=False)
         rel = np.abs(terms[b].detach().cpu().numpy() - ref['parts']) / np.abs(ref['parts'])
-        assert np.all(rel <= 2e-3) and np.median(rel) <= 5e-5, (b, rel)
+        if not np.all(rel <= 1e-4):                          # name the points that changed sides (single-field path, same point kernels), rest at 1e-4
+            mine, ref_ff, idx = _terms_vs_oracle_flip_free(m, samples[b])
+            print('lead batch field %d: removed points %s' % (b, idx))
+            assert idx and np.all(np.abs(mine - ref_ff) <= 1e-4 * np.abs(ref_ff)), (b, idx, mine, ref_ff)
     # (ii) the loop of single-field steps on the same kernels
     m.physics_net.zero_grad(set_to_none=True)
     total = 0.0
@@ -790,10 +816,10 @@ def test_config2_full_size_61_leads():
 
 
 # ------------------------------------------------------------------------------------------------ kink-aware parity, as a proof
-def _oracle_masks(inp):
+def _oracle_masks(inp, st=None, gain=1.0, with_clip=True):
     """ReLU masks [6, N, 256] x 2, clip mask [N, 6] and the vapour switch delta [N] of the fp32 oracle arithmetic (oracle/kernel_model.py)."""
     from oracle import kernel_model as KM
-    st = O.make_state()
+    st = O.make_state(gain=gain) if st is None else st
     with torch.no_grad():
         meta = O.meta_net_forward(st, inp['field_data'], inp['forecast_h'])
         xi = torch.cat([inp['x'] / GEO.dx / (GEO.lon - 1), inp['y'] / GEO.dy / (GEO.lat - 1), inp['t'] / GEO.pred_t_span], 1)
@@ -806,17 +832,62 @@ def _oracle_masks(inp):
             m1.append(S['m1'] > 0), m2.append(S['m2'] > 0), outs.append(out), jx.append(jxi)
         out_n = torch.stack(outs, 1)
         scale = torch.tensor([1.0 / GEO.dx / (GEO.lon - 1), 1.0 / GEO.dy / (GEO.lat - 1), 1.0 / GEO.pred_t_span])
-        clip, delta = _clip_and_delta(out_n, torch.stack(jx, 1) * scale)
+        clip, delta = _clip_and_delta(out_n, torch.stack(jx, 1) * scale, with_clip)
     return torch.stack(m1), torch.stack(m2), clip, delta
 
 
-def _clip_and_delta(out_n, jac_n):
+def _flipped_points(m, inp, st=None, gain=1.0, with_clip=True):
+    """Points of the batch at which ANY switch of the computation -- one of the 6 x 512 ReLU bits the forward kernel saves, a clip mask of
+    inverse_norm, the condensation switch of the vapour equation -- differs between the HIP arithmetic and the fp32 oracle arithmetic.
+    Two fp32-class arithmetics agree to ~1e-6 except where a pre-activation / bound / switch argument sits within rounding distance of
+    its threshold; those points are IDENTIFIED here (bool [N]) instead of being covered by a blanket tolerance."""
+    import deepphysinet_amd as dpn
+    from deepphysinet_amd.point_path import relu_masks
+    g = _gpu(inp)
+    cfg = m.point_config()
+    with torch.no_grad():
+        heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
+        m1, m2 = relu_masks(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
+        out_n, jac_n = dpn.pde_fields_and_jacobian(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
+    clip, delta = _clip_and_delta(out_n, jac_n, with_clip)
+    o1, o2, oclip, odelta = _oracle_masks(inp, st=st, gain=gain, with_clip=with_clip)
+    flip_relu = ((m1.cpu() != o1) | (m2.cpu() != o2)).any(dim=2).any(dim=0)
+    return flip_relu | (clip != oclip).any(dim=1) | (delta != odelta), (m1, m2)
+
+
+def _without(inp, flipped):
+    n = flipped.shape[0]
+    keep = ~flipped
+    return {k: (v[keep] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n and k not in ('field_data', 'forecast_h')) else v) for k, v in inp.items()}
+
+
+def _terms_vs_oracle_flip_free(m, inp, st=None, gain=1.0, with_clip=True, max_flipped=None):
+    """The six loss terms of the HIP path and of the oracle on the batch WITHOUT its flipped points (named in the output): returns
+    (hip terms, oracle terms, indices of the removed points).  With no flipped point this is the plain full-batch comparison."""
+    flipped, _ = _flipped_points(m, inp, st=st, gain=gain, with_clip=with_clip)
+    idx = torch.nonzero(flipped).flatten().tolist()
+    n = flipped.shape[0]
+    assert len(idx) <= (max(3, n // 100) if max_flipped is None else max_flipped), idx
+    sub = _without(inp, flipped) if idx else inp
+    gs = _gpu(sub)
+    terms = m.pde_loss_terms(gs['x'], gs['y'], gs['t'], gs['f'], gs['field_data'], gs['coord_data'], gs['forecast_h']).detach().double().cpu().numpy()
+    if st is None:
+        ref = _oracle(sub, gain=gain, with_clip=with_clip, want_grads=False)['parts']
+    else:
+        x, y, t = (sub[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
+        _, parts, _, _ = O.place_one_batch(st, x, y, t, sub['f'], sub['field_data'], sub['coord_data'], sub['forecast_h'], GEO, with_clip=with_clip,
+                                           return_parts=True)
+        ref = np.array([float(p.detach()) for p in parts])
+    return terms, ref, idx
+
+
+def _clip_and_delta(out_n, jac_n, with_clip=True):
     """Which points sit inside the clip bounds (P, T, q, rho) and have the vapour switch on (interface_physics.py:165-168), from
     normalised fields [N, 6] and their Jacobian [N, 6, 3]."""
     std, mean = torch.tensor(O.OBS_STD), torch.tensor(O.OBS_MEAN)
     val = out_n.cpu() * std + mean
     clip = torch.ones_like(val, dtype=torch.bool)
-    for k in range(2, 6):
+    for k in range(2, 6 if with_clip else 2):
         clip[:, k] = (val[:, k] >= O.CLIP_LO[k]) & (val[:, k] <= O.CLIP_HI[k])
         val[:, k] = val[:, k].clamp(O.CLIP_LO[k], O.CLIP_HI[k])
     J = jac_n.cpu() * (std * clip)[:, :, None]
@@ -828,43 +899,27 @@ def _clip_and_delta(out_n, jac_n):
     return clip, (omega < 0) & (q >= q_s)
 
 
-@pytest.mark.parametrize('n', [5197, 1037])
-def test_kink_flips_are_listed_and_every_other_point_is_tight(n):
-    """the tolerances for batches of hundreds of points allowed isolated Jacobian rows / gradient elements beyond the bound
-    'because of ReLU kinks' without identifying them.  Here the kernel's own mask bits (point_path.relu_masks: the words dpn_fwd saves),
-    the clip masks and the vapour switch are compared with the oracle's, the points where ANY of them differs are listed, and
-      (i)  their number is bounded (<= 1 % of the points; measured 0.6 %: 32 of 5 197, each point carries 6 x 512 ReLU bits);
-      (ii) with those points removed from BOTH sides, every loss term is within 1e-4, every Jacobian row within 2e-4 of the field's
-           largest entry, every fields value within 5e-5 and every gradient ELEMENT within 1e-3 of its tensor's maximum -- no outlier
-           allowance, no L2 fallback."""
+def _assert_tight_after_removing_flips(n):
+    """The parity statement of the hi+lo mode for a batch of n points: the points where a switch bit differs from the oracle arithmetic's
+    are listed and bounded in number (<= 1 % of the points, at least 3; measured 0.6 %: 32 of 5 197, each point carries 6 x 512 ReLU
+    bits); with them removed from BOTH sides every loss term is within 1e-4, every Jacobian row within 2e-4 of the field's largest entry,
+    every field value within 5e-5 and every gradient ELEMENT within 1e-3 of its tensor's maximum -- no outlier allowance, no L2 fallback."""
     import deepphysinet_amd as dpn
-    from deepphysinet_amd.point_path import relu_masks
     tol = TOL['bf16x2']
     inp = synthetic_inputs(n, tag='inter')
     m = _model('bf16x2')
-    g = _gpu(inp)
-    cfg = m.point_config()
-    with torch.no_grad():
-        heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
-        m1, m2 = relu_masks(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
-        out_n, jac_n = dpn.pde_fields_and_jacobian(cfg, g['x'], g['y'], g['t'], g['coord_data'], heads, evec, statics)
-    clip, delta = _clip_and_delta(out_n, jac_n)
-    o1, o2, oclip, odelta = _oracle_masks(inp)
-    flip_relu = ((m1.cpu() != o1) | (m2.cpu() != o2)).any(dim=2).any(dim=0)          # [N]
-    flip_clip = (clip != oclip).any(dim=1)
-    flip_delta = delta != odelta
-    flipped = flip_relu | flip_clip | flip_delta
+    flipped, (m1, m2) = _flipped_points(m, inp)
     nf = int(flipped.sum())
-    print('n = %d: %d points differ in a ReLU bit, %d in a clip mask, %d in the vapour switch: %s' % (
-        n, int(flip_relu.sum()), int(flip_clip.sum()), int(flip_delta.sum()), torch.nonzero(flipped).flatten().tolist()[:20]))
+    print('n = %d: %d points carry a switch bit that differs from the oracle arithmetic: %s' % (n, nf, torch.nonzero(flipped).flatten().tolist()[:20]))
     assert nf <= max(3, n // 100), nf
     # the masks themselves: everything else identical, and the bit counts plausible (about half of the units are on)
     assert 0.2 < float(m1.float().mean()) < 0.8 and 0.2 < float(m2.float().mean()) < 0.8
-    keep = ~flipped
-    sub = {k: (v[keep] if v.shape[0] == n else v) for k, v in inp.items()}
+    sub = _without(inp, flipped) if nf else inp
     ref = _oracle(sub)
     gs = _gpu(sub)
+    cfg = m.point_config()
     with torch.no_grad():
+        heads, evec, statics = m.physics_net.field_weights(gs['field_data'], gs['forecast_h'])
         out_k, jac_k = dpn.pde_fields_and_jacobian(cfg, gs['x'], gs['y'], gs['t'], gs['coord_data'], heads, evec, statics)
     assert float((out_k.cpu() - ref['fields']).abs().max() / ref['fields'].abs().max()) < tol['field']
     for k in range(6):
@@ -884,6 +939,13 @@ def test_kink_flips_are_listed_and_every_other_point_is_tight(n):
         worst = max(worst, err)
         assert err < tol['grad'], (name, err)
     print('after removing them: worst gradient element %.2e of its tensor maximum' % worst)
+
+
+@pytest.mark.parametrize('n', [5197, 1037])
+def test_kink_flips_are_listed_and_every_other_point_is_tight(n):
+    """tolerances that allow 'isolated outliers because of ReLU kinks' must identify them.  See
+    _assert_tight_after_removing_flips; test_fields_jacobian_losses_gradients_vs_oracle runs the same statement for its other sizes."""
+    _assert_tight_after_removing_flips(n)
 
 
 def test_variable_net_standalone_forward_matches_oracle():
