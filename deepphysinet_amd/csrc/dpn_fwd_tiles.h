@@ -48,18 +48,29 @@ template <int NS> DEV void ts_sincos(float th, float& s, float& c) { s = th; c =
 template <int NS> DEV void ts_sincos(float th, float& s, float& c) { sincos_t<NS>(th, s, c); }
 #endif
 
-template <int NS>
-DEV void mma3(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16& acc) {        // same product order as mma_block (not SWAP)
+// SWAP = false: a = weight fragment (A operand), b = activation fragment (B operand): Out[channel][point], the chained layout.
+// SWAP = true : the activation fragment is the A operand, the weight fragment the B operand: Out[point][channel] -- channel per lane, the
+//               K-operand layout of the weight-gradient GEMMs (dpn_bwd_tiles_kernel's Z).  Product order as mma_block in both cases.
+template <int NS, bool SWAP = false>
+DEV void mma3(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16& acc) {
 #ifdef TS_ABL_NOMFMA
     if constexpr (NS == 2) asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
     else asm volatile("" ::"v"(a[0]), "v"(b[0]));
     return;
 #endif
-    if constexpr (NS == 2) {
-        acc = mfma(as_bf(a[0]), as_bf(b[1]), acc);
-        acc = mfma(as_bf(a[1]), as_bf(b[0]), acc);
+    if constexpr (SWAP) {
+        if constexpr (NS == 2) {
+            acc = mfma(as_bf(b[1]), as_bf(a[0]), acc);
+            acc = mfma(as_bf(b[0]), as_bf(a[1]), acc);
+        }
+        acc = mfma(as_bf(b[0]), as_bf(a[0]), acc);
+    } else {
+        if constexpr (NS == 2) {
+            acc = mfma(as_bf(a[0]), as_bf(b[1]), acc);
+            acc = mfma(as_bf(a[1]), as_bf(b[0]), acc);
+        }
+        acc = mfma(as_bf(a[0]), as_bf(b[0]), acc);
     }
-    acc = mfma(as_bf(a[0]), as_bf(b[0]), acc);
 }
 
 // acc[t][p] += W[tile t][k] * X[k][column tile p] over NK k-steps.  wg: this wave's first tile chunk in the packed stream (wave-uniform;
@@ -117,7 +128,7 @@ DEV void gemm_head(const char* wg, const int lane, Head<NS, NT>& H) {
 #pragma unroll
     for (int k = 0; k < kPF - 1; ++k) src.next(H.a[k]);
 }
-template <int NS, int NK, int NT>
+template <int NS, int NK, int NT, bool SWAP = false>
 DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>& H, f32x16 (&acc)[2][2]) {
     static_assert(NK >= kPF, "k-steps per chunk");
     WSrc<NS, NK, NT> src;
@@ -150,7 +161,7 @@ DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) mma3<NS>(A[ks % kPF][t], B[ks & 1][p], acc[t][p]);
+            for (int p = 0; p < 2; ++p) mma3<NS, SWAP>(A[ks % kPF][t], B[ks & 1][p], acc[t][p]);
 #if TS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -212,8 +223,8 @@ template <int NS> constexpr int feat_pe_bytes() { return 12 * 2 * NS * 1024; }
 template <int NS> constexpr int feat_tile_bytes() { return 2 * feat_pe_bytes<NS>() + 3 * 2 * 2 * 64 * 64; }
 
 // the coordinate features of k-step ks (0..11) for the lane's point: one B fragment (hi [+ lo])
-template <int NS>
-DEV void pe3_frag(Frag<NS>& f, const FwdArgs& a, const int ks, const int h, const int64_t pc) {
+template <int NS, class Args>
+DEV void pe3_frag(Frag<NS>& f, const Args& a, const int ks, const int h, const int64_t pc) {
     const int c = ks >> 2;
     const float* src = (c == 0) ? a.x : (c == 1) ? a.y : a.t;
     const float d1 = (c == 0) ? a.geo.dx : (c == 1) ? a.geo.dy : a.geo.pred_t_span;
@@ -227,19 +238,36 @@ DEV void pe3_frag(Frag<NS>& f, const FwdArgs& a, const int ks, const int h, cons
     }
 }
 // the data features (SineCosPE(6,16) of coord_data, variable_net.py:73) of k-step ks (0..11)
-template <int NS>
-DEV void pe6_frag(Frag<NS>& f, const FwdArgs& a, const int ks, const int h, const int64_t pc) {
+template <int NS, class Args>
+DEV void pe6_frag(Frag<NS>& f, const Args& a, const int ks, const int h, const int64_t pc, const float g = 1.0f) {
     const float v = a.coord_data[pc * 6 + (ks >> 1)];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float s, co;
         ts_sincos<NS>(v * a.freqs[32 + 8 * (ks & 1) + 4 * h + q], s, co);
-        frag_set2<NS>(f, q, 1.0f * s, 1.0f * co);
+        frag_set2<NS>(f, q, g * s, g * co);
+    }
+}
+// backward: Z0 = g * pe + gJ_c * d pe / d xi_c for k-step ks (coordinate c = ks >> 2), build_pe3<BWD> of the ring kernels
+template <int NS, class Args>
+DEV void z0_frag(Frag<NS>& f, const Args& a, const int ks, const int h, const int64_t pc, const float g, const float gjc) {
+    const int c = ks >> 2;
+    const float* src = (c == 0) ? a.x : (c == 1) ? a.y : a.t;
+    const float d1 = (c == 0) ? a.geo.dx : (c == 1) ? a.geo.dy : a.geo.pred_t_span;
+    const float d2 = (c == 0) ? a.geo.lon_m1 : (c == 1) ? a.geo.lat_m1 : 1.0f;
+    const float xi = src[pc] / d1 / d2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float fr = a.freqs[8 * (ks & 3) + 4 * h + q];
+        float s, co;
+        ts_sincos<NS>(xi * fr, s, co);
+        const float gf = gjc * fr;
+        frag_set2<NS>(f, q, fmaf(g, s, gf * co), fmaf(g, co, -gf * s));
     }
 }
 // d pe3 / d xi_c for the 16 accumulator registers of gpe tile 2c + t (register pair rp = one angle: k-step 2T + (rp >> 2) of the coordinate PE)
-template <int NS>
-DEV void dpe_tile(float (&d)[16], const FwdArgs& a, const int c, const int t, const int h, const int64_t pc) {
+template <int NS, class Args>
+DEV void dpe_tile(float (&d)[16], const Args& a, const int c, const int t, const int h, const int64_t pc) {
     const float* src = (c == 0) ? a.x : (c == 1) ? a.y : a.t;
     const float d1 = (c == 0) ? a.geo.dx : (c == 1) ? a.geo.dy : a.geo.pred_t_span;
     const float d2 = (c == 0) ? a.geo.lon_m1 : (c == 1) ? a.geo.lat_m1 : 1.0f;
@@ -601,4 +629,163 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         }
     }
     TS_STAMP(28);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Backward, stage 1 (per-point cotangent streams -> operands of the weight-gradient reductions), tile-split form.  Same arithmetic and same
+// operand layout as dpn_bwd_kernel (bit-identical Z0, Z1, Z, G6, gnet); decomposition as dpn_fwd_tiles_kernel: 64 points per workgroup, wave
+// w owns tiles 2w, 2w+1 of both column tiles, the cotangent fragments are shared through LDS, the weights come L2 -> VGPR.
+//   Z0 = g pe + sum_c gJ_c d pe / d xi_c                      -> X, K-layout rows (operand of dw1 = T1^T Z0)
+//   Z1 = m1 (.) (w1 Z0 + g b1)                                -> X, K-layout rows (operand of dw2 = V^T Z1)
+//   Z  = w2 Z1 + Wd (g pe6) + g (b2 + bd + e), channel per lane (SWAP orientation: the activation fragments are the A operand), stored as is
+//   G6 = g pe6                                                -> X, K-layout rows (operand of dWd = V^T G6)
+template <int NS>
+__global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
+    using C = ts::Cfg<NS>;
+    __shared__ __attribute__((aligned(16))) char lds[C::kLdsBytes];
+    const int net = blockIdx.y;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const char* pk = a.packed + (long)net * pack_bytes_per_net(NS);
+#if TS_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    float* vec = reinterpret_cast<float*>(lds + C::kVecOff);
+    char* xl = lds + lane * 16;
+    {
+        const u32x4* gv = reinterpret_cast<const u32x4*>(pk + (long)kPackKB * 1024 * NS);
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
+        const u32x4 v0 = gv[i0];
+        const u32x4 v1 = gv[i1 < ts::kVecFloats / 4 ? i1 : i0];
+        reinterpret_cast<u32x4*>(vec)[i0] = v0;
+        if (i1 < ts::kVecFloats / 4) reinterpret_cast<u32x4*>(vec)[i1] = v1;
+    }
+    auto chunk = [&](const int kb) __attribute__((always_inline)) { return pk + (long)kb * 1024 * NS; };
+    ts::Head<NS, 2> H;
+    ts::gemm_head<NS, 12, 2>(chunk(kS0 + 2 * w * 12), lane, H);
+    const int64_t tile0 = (int64_t)blockIdx.x * 2;
+    const int64_t tiles32 = a.n_pad / 32;
+    int64_t pc[2];
+    float g[2];                                               // cotangent of the lane's point in column tile p (zero for padding points)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int64_t pt = (tile0 + p) * 32 + j;
+        const bool valid = pt < a.n;
+        pc[p] = valid ? pt : (a.n - 1);
+        g[p] = valid ? a.g_out[pc[p] * 6 + net] : 0.f;
+    }
+    const ts::Ident I = ts::make_ident(j, h);
+    SavedView sv = saved_view(a.saved, a.n_pad, NS);
+    OperandView ov = operand_view(a.operands, a.n_pad, NS);
+    u32 m1w[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) m1w[p] = reinterpret_cast<const u32*>(sv.m1 + ((int64_t)net * tiles32 + tile0 + p) * 64 + lane)[w];
+    if (w == 0) {                                             // lane (j, h): point j of column tile h
+        const int64_t pt = (tile0 + h) * 32 + j;
+        ov.gnet[(int64_t)net * a.n_pad + pt] = (pt < a.n) ? a.g_out[pt * 6 + net] : 0.f;
+    }
+    // cotangents of the 16 points this lane holds in the channel-per-lane (SWAP) accumulator layout, per column tile
+    float g16[2][16];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t q = (tile0 + p) * 32 + drow32(r, h);
+            g16[p][r] = (q < a.n) ? a.g_out[q * 6 + net] : 0.f;
+        }
+    // ---------------- Z0 -> X (k-steps 0..11) and K-layout rows: wave w builds the (column tile of Z0, point tile) units 3w .. 3w+2
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
+        const int u = 3 * w + uu, ct = u >> 1, p = u & 1;     // wave-uniform
+        const float gp = p ? g[1] : g[0];
+        const int64_t pcp = p ? pc[1] : pc[0];
+        float gjc = 0.f;
+        if (a.g_jxi && ((tile0 + p) * 32 + j) < a.n) gjc = a.g_jxi[(pcp * 6 + net) * 3 + (ct >> 1)];
+        Frag<NS> f0, f1;
+        ts::z0_frag<NS>(f0, a, 2 * ct, h, pcp, gp, gjc);
+        ts::z0_frag<NS>(f1, a, 2 * ct + 1, h, pcp, gp, gjc);
+        ts::x_store<NS>(xl, 2 * ct, p, f0);
+        ts::x_store<NS>(xl, 2 * ct + 1, p, f1);
+        ts::save_tile_k<NS, NS>(ov.Z0, net, tile0 + p, ct, lane, I, false, f0, f1);
+    }
+    ts::barrier_lds();
+    // ---------------- Z1 = m1 (.) (w1 Z0 + g b1) -> X (+ K-layout rows)
+    f32x16 acc[2][2];
+    Frag<NS> F[2][2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ts::acc_init(acc[t][p], vec, kVecB1, h, 2 * w + t, g[p]);
+    ts::gemm<NS, 12, 2>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
+    ts::gemm_head<NS, 16, 2>(chunk(kS1 + 2 * w * 16), lane, H);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const u32 bits = m1w[p] >> (16 * t + r);
+                frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, (bits & 1u) ? acc[t][p][r] : 0.f, (bits & 2u) ? acc[t][p][r + 1] : 0.f);
+            }
+            ts::save_tile_k<NS, NS>(ov.Z1, net, tile0 + p, 2 * w + t, lane, I, false, F[t][p][0], F[t][p][1]);
+        }
+    ts::barrier_lds();                                        // everybody is done reading Z0
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) ts::x_store<NS>(xl, 4 * w + 2 * t + kk, p, F[t][p][kk]);
+    ts::barrier_lds();
+    // ---------------- Z = w2 Z1 + Wd (g pe6) + g (b2 + bd + e): channel per lane (SWAP), acc[t][p] = [points of column tile p][channels of tile 2w+t]
+    {
+        const int rr = (j & 3) + 4 * (j >> 3), hh = (j >> 2) & 1;   // natural-order read of cvec for channel 32T + j from the [h][T][r] permuted vector
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float cv = vec[kVecCvec * 256 + hh * 128 + (2 * w + t) * 16 + rr];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][p][r] = g16[p][r] * cv;
+        }
+    }
+    ts::gemm<NS, 16, 2, true>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
+    ts::gemm_head<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), lane, H);
+    {   // G6 = g pe6 -> X (k-steps 0..11) and K-layout rows: units as for Z0
+        Frag<NS> f6[3][2];
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu) {
+            const int u = 3 * w + uu, ct = u >> 1, p = u & 1;
+            const float gp = p ? g[1] : g[0];
+            const int64_t pcp = p ? pc[1] : pc[0];
+            ts::pe6_frag<NS>(f6[uu][0], a, 2 * ct, h, pcp, gp);
+            ts::pe6_frag<NS>(f6[uu][1], a, 2 * ct + 1, h, pcp, gp);
+            ts::save_tile_k<NS, NS>(ov.G6, net, tile0 + p, ct, lane, I, false, f6[uu][0], f6[uu][1]);
+        }
+        ts::barrier_lds();                                    // everybody is done reading Z1
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu) {
+            const int u = 3 * w + uu, ct = u >> 1, p = u & 1;
+            ts::x_store<NS>(xl, 2 * ct, p, f6[uu][0]);
+            ts::x_store<NS>(xl, 2 * ct + 1, p, f6[uu][1]);
+        }
+        ts::barrier_lds();
+    }
+    ts::gemm<NS, 12, 2, true>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                f32x16 d = acc[t][p];
+                if (s == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const u32 hi = pack2(acc[t][p][r], acc[t][p][r + 1]);
+                        d[r] = acc[t][p][r] - bf_lo(hi); d[r + 1] = acc[t][p][r + 1] - bf_hi(hi);
+                    }
+                }
+                store_d_as_k(ov.Z, net, NS, s, tile0 + p, 2 * w + t, lane, d);
+            }
 }

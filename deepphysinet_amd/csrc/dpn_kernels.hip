@@ -879,9 +879,6 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
 #if DPN_HAS_POINT && defined(DPN_EXPERIMENT_FWD2)
 #include "../../tools/experiments/dpn_fwd2_eight_waves.h"       // shelved eight-wave variant (measured slower; see its header and DESIGN.md)
 #endif
-#if DPN_HAS_POINT
-#include "dpn_fwd_tiles.h"                                       // tile-split forward kernel (the hi+lo mode's default)
-#endif
 
 #if DPN_HAS_REST
 // g_pe[n][c] = sum_k g_out[n][k] * gpe[n][k][c]: the cotangent of caller-encoded coordinates (PhysicsNet.forward backward w.r.t. coord_x)
@@ -1164,6 +1161,10 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
         pipe.drain();
     }
 }
+
+#if DPN_HAS_POINT
+#include "dpn_fwd_tiles.h"                                       // tile-split forward / backward kernels (the hi+lo mode's default)
+#endif
 
 #if DPN_HAS_REST
 // ------------------------------------------------------------------------------------------------ backward, stage 2
@@ -2271,6 +2272,14 @@ int dpn_bwd_points(const float* x, const float* y, const float* t, const float* 
               const_cast<void*>(saved), operands};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
+    const char* force = getenv("DPN_BWD_KERNEL");          // ring | tiles (A/B measurements, bitwise comparison in the tests)
+    const bool tiles = force ? (force[0] == 't') : (prec == 2);
+    if (tiles && !pe_in) {
+        const dim3 grid64((unsigned)(a.n_pad / 64), kNets);
+        if (prec == 1) hipLaunchKernelGGL(dpn_bwd_tiles_kernel<1>, grid64, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(dpn_bwd_tiles_kernel<2>, grid64, dim3(256), 0, s, a);
+        return ck(hipGetLastError());
+    }
     if (prec == 1) hipLaunchKernelGGL(dpn_bwd_kernel<1>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(dpn_bwd_kernel<2>, grid, dim3(256), 0, s, a);
     return ck(hipGetLastError());

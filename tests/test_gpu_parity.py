@@ -1037,3 +1037,63 @@ def test_config4_fp8_encoder_workload():
     assert err_prod.max() <= 1e-3, err_prod                          # the product path on the same inputs (kink-free batches hold 1e-4)
     assert err_fp8.max() <= 0.5, err_fp8                             # configs[4]: stated tolerance
     assert err_fp8.max() > 10 * err_prod.max(), (err_fp8, err_prod)  # ... and it is a real precision loss, not noise
+
+
+@pytest.mark.parametrize('n', [1037, 70])
+def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n):
+    """The hi+lo mode's forward + Jacobian and backward stage-1 kernels exist in two decompositions: the ring form (one 512-register wave
+    per SIMD owns 32 points and all output tiles, weights shared through an LDS-DMA ring) and the tile-split form (the default: output
+    tiles split over the waves, activations shared through LDS, weights L2 -> VGPR, two workgroups per CU; csrc/dpn_fwd_tiles.h).  Both run
+    the same products in the same order per output tile, so everything they hand to the later kernels -- the saved state V, T1, M2, m1,
+    the Jacobian, the operands Z1, Z, Z0, G6, gnet -- must agree BIT FOR BIT (the fields differ in the order the four waves' partial sums
+    are added: 1e-6).  Ragged sizes: 1037 = 16 full 64-point workgroups + 13 points, 70 = one full + 6 points."""
+    import ctypes
+    from deepphysinet_amd import _lib as L, point_path as PP
+    inp = synthetic_inputs(n, tag='inter')
+    m = _model('bf16x2')
+    g = _gpu(inp)
+    cfg = m.point_config()
+    lib = L.load()
+    dev = _dev()
+    old = {k: os.environ.get(k) for k in ('DPN_FWD_KERNEL', 'DPN_BWD_KERNEL')}
+    try:
+        with torch.no_grad():
+            heads, evec, statics = m.physics_net.field_weights(g['field_data'], g['forecast_h'])
+            x_, y_, t_, f_ = (PP._f32c(g[k]).reshape(-1) for k in ('x', 'y', 't', 'f'))
+            cd_ = PP._f32c(g['coord_data'])
+            st = [PP._f32c(s_) for s_ in statics]
+            ws = PP._Workspace(n, cfg.prec, dev)
+            nets = PP._net_ptrs(PP._f32c(heads), PP._f32c(evec), st)
+            s = PP._stream()
+            L.check(lib.dpn_pack_weights(nets, cfg.prec, PP._ptr(ws.packed), s), 'pack')
+            geo, ph, fr = cfg.geometry(), cfg.physics(), PP._freqs(dev)
+            res = {}
+            for kind in ('ring', 'tiles'):
+                os.environ['DPN_FWD_KERNEL'] = os.environ['DPN_BWD_KERNEL'] = kind
+                out_n = torch.zeros((n, 6), device=dev); jac_n = torch.zeros((n, 6, 3), device=dev)
+                saved = torch.zeros(ws.sizes.saved, dtype=torch.uint8, device=dev)
+                L.check(lib.dpn_fwd(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed),
+                                    cfg.prec, PP._ptr(out_n), PP._ptr(jac_n), PP._ptr(saved), s), 'fwd')
+                g_out = torch.empty((n, 6), device=dev); g_jxi = torch.empty((n, 6, 3), device=dev)
+                L.check(lib.dpn_residual(PP._ptr(out_n), PP._ptr(jac_n), PP._ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, None, None,
+                                         PP._ptr(g_out), PP._ptr(g_jxi), s), 'res')
+                operands = torch.zeros(ws.sizes.operands, dtype=torch.uint8, device=dev)
+                # the backward kernels of BOTH forms read the ring forward's cotangents, so that only the kernel under test differs
+                if kind == 'ring':
+                    go, gj, sv = g_out.clone(), g_jxi.clone(), saved.clone()
+                L.check(lib.dpn_bwd_points(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed),
+                                           cfg.prec, PP._ptr(go), PP._ptr(gj), PP._ptr(sv), PP._ptr(operands), s), 'bwd')
+                torch.cuda.synchronize()
+                res[kind] = (out_n, jac_n, saved, operands)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    (o0, j0, s0, p0), (o1, j1, s1, p1) = res['ring'], res['tiles']
+    n_state = 2 * 6 * cfg.prec * ws.sizes.n_pad * 512 + 6 * ws.sizes.n_pad * 512 + 6 * ws.sizes.n_pad * 32       # V, T1 | M2 | m1 (the features behind them are the tile-split form's own)
+    assert torch.equal(j0, j1)
+    assert torch.equal(s0[:n_state], s1[:n_state])
+    assert torch.equal(p0, p1)
+    assert float((o0 - o1).abs().max()) <= 2e-6 * float(o0.abs().max())
