@@ -40,6 +40,8 @@ DEV void barrier_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+struct NoSide { DEV void operator()(int) const {} };
+
 // Ablation builds (tools/variant_build.py; wrong results on purpose, timing only): TS_ABL_NOMFMA keeps the operands alive and drops the
 // products, TS_ABL_NOSINCOS replaces the feature evaluation by one multiply, TS_ABL_NOALOAD multiplies with whatever is in the registers.
 #ifdef TS_ABL_NOSINCOS
@@ -79,13 +81,19 @@ DEV void mma3(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16& acc) {
 // weight stream of a layer then starts under that epilogue (packing, saved-state stores, the two barriers) instead of cold behind it --
 // and in front of its stores: vmcnt retires in order, a load issued behind the saved-state stores would wait for them as well.
 #ifndef TS_PF
-#define TS_PF 4
+#define TS_PF 3      // two k-steps ahead: with the deferred saved-state hand-over (TS_DEFER_SAVES) a fourth slot spills 44 registers (measured slower)
 #endif
 // Issue priority between the two waves of a SIMD (they belong to different workgroups): 0 = none, 1 = s_setprio 1 around every k-step's
 // MFMAs, 2 = s_setprio 1 everywhere EXCEPT the multiply loops (the feature / epilogue / store phases are a workgroup's serial chain; a
 // multiplying wave needs one issue slot in eight)
 #ifndef TS_PRIO
 #define TS_PRIO 2
+#endif
+// Saved-state hand-over (V, T1, M2 as K-layout rows: two transposing MFMAs, eight packs and two streaming stores per plane and tile) issued
+// k-step by k-step inside the NEXT layer's multiply loop instead of in the serial epilogue between two barriers (nobody in the kernel waits
+// for it).  0 = in the epilogue.
+#ifndef TS_DEFER_SAVES
+#define TS_DEFER_SAVES 1
 #endif
 constexpr int kPF = TS_PF;
 template <int NS, int NT> struct Head { u32x4 a[kPF - 1][NT][NS]; };
@@ -128,8 +136,10 @@ DEV void gemm_head(const char* wg, const int lane, Head<NS, NT>& H) {
 #pragma unroll
     for (int k = 0; k < kPF - 1; ++k) src.next(H.a[k]);
 }
-template <int NS, int NK, int NT, bool SWAP = false>
-DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>& H, f32x16 (&acc)[2][2]) {
+// side(ks): work of the PREVIOUS layer that nobody waits for (its saved-state transposes and stores), issued k-step by k-step in the shadow
+// of this layer's MFMAs instead of in the serial epilogue between two barriers
+template <int NS, int NK, int NT, bool SWAP = false, class Side = NoSide>
+DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>& H, f32x16 (&acc)[2][2], const Side& side = Side()) {
     static_assert(NK >= kPF, "k-steps per chunk");
     WSrc<NS, NK, NT> src;
     src.init(wg, lane, kPF - 1);
@@ -165,6 +175,7 @@ DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>
 #if TS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #endif
+        side(ks);
     }
 #if TS_PRIO == 2
     __builtin_amdgcn_s_setprio(1);
@@ -197,6 +208,15 @@ DEV Ident make_ident(const int j, const int h) {          // the identity B frag
         I.b[p] = (j >= 16) ? v : 0u;
     }
     return I;
+}
+// one plane (hi or lo) of one column tile: two transposing MFMAs, eight packs, two 16-byte streaming stores
+DEV void save_plane_k(const KMat& m, const int net, const int nstore, const int s, const int64_t tile32, const int ct, const int lane, const Ident& I,
+                      const bool zero, u32x4 a0, u32x4 a1) {
+    if (zero) { a0 = (u32x4)0u; a1 = (u32x4)0u; }
+    f32x16 d = (f32x16)0.f;
+    d = mfma(as_bf(a0), as_bf(I.a), d);
+    d = mfma(as_bf(a1), as_bf(I.b), d);
+    store_d_as_k(m, net, nstore, s, tile32, ct, lane, d);
 }
 // store_tile_k of the ring kernel: fragments (k-steps 2ct, 2ct+1) of one column tile -> K-layout rows of the 32-point tile
 template <int NS, int NSTORE>
@@ -364,9 +384,9 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     const ts::Ident I = ts::make_ident(j, h);
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     const bool save = a.saved != nullptr;
-    // features of this workgroup's 64 points, evaluated once per point by dpn_features_kernel (stored behind the saved state); without a
-    // saved-state buffer (inference, fields-only calls) they are evaluated here
-    const char* ft = save ? reinterpret_cast<const char*>(a.saved) + saved_state_bytes(a.n_pad, NS) + (int64_t)blockIdx.x * ts::feat_tile_bytes<NS>() : nullptr;
+    // features of this workgroup's 64 points: evaluated here, or -- DPN_FEATURES_PREPASS=1, a measured experiment -- once per point by
+    // dpn_features_kernel (stored behind the saved state)
+    const char* ft = a.feat ? a.feat + (int64_t)blockIdx.x * ts::feat_tile_bytes<NS>() : nullptr;
     const int64_t tiles32 = a.n_pad / 32;
     auto chunk = [&](const int kb) __attribute__((always_inline)) { return pk + (long)kb * 1024 * NS; };
 
@@ -503,12 +523,14 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     TS_STAMP(15);
     if (save || a.jac_n) ts::gemm_head<NS, 16, 2>(chunk(kS3 + 2 * w * 16), lane, H);
     float adot[2] = {0.f, 0.f};
+    Frag<1> MK[2][2][2];                     // relu-2 mask as bf16 0 / 1 fragments (one plane)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const f32x4* uvp = reinterpret_cast<const f32x4*>(vec + kVecU * 256 + h * 128 + (2 * w + t) * 16);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            Frag<1> mk0, mk1;
+            Frag<1>& mk0 = MK[t][p][0];
+            Frag<1>& mk1 = MK[t][p][1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 uq = uvp[q];
@@ -526,7 +548,9 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
                     if (r < 8) mk0.w[0][(r & 7) >> 1] = mw; else mk1.w[0][(r & 7) >> 1] = mw;
                 }
             }
+#if !TS_DEFER_SAVES
             if (save) ts::save_tile_k<1, 1>(sv.M2, net, tile0 + p, 2 * w + t, lane, I, zero_rows[p], mk0, mk1);
+#endif
         }
     }
 #pragma unroll
@@ -552,7 +576,19 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> X (+ saved V)
     init_all(kVecWo, 2.0f);
     TS_STAMP(18);
+#if TS_DEFER_SAVES
+    {
+        auto side = [&](const int ks) __attribute__((always_inline)) {            // M2: four (tile, column tile) units over the 16 k-steps
+            if (!save) return;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ks == 4 * u + 1) ts::save_plane_k(sv.M2, net, 1, 0, tile0 + (u & 1), 2 * w + (u >> 1), lane, I, zero_rows[u & 1], MK[u >> 1][u & 1][0].w[0], MK[u >> 1][u & 1][1].w[0]);
+        };
+        ts::gemm<NS, 16, 2, false>(chunk(kS3 + 2 * w * 16), xl, lane, H, acc, side);
+    }
+#else
     ts::gemm<NS, 16, 2>(chunk(kS3 + 2 * w * 16), xl, lane, H, acc);
+#endif
     TS_STAMP(19);
     ts::gemm_head<NS, 16, 2>(chunk(kS4 + 2 * w * 16), lane, H);
 #pragma unroll
@@ -561,7 +597,9 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, acc[t][p][r], acc[t][p][r + 1]);
+#if !TS_DEFER_SAVES
             if (save) ts::save_tile_k<NS, NS>(sv.V, net, tile0 + p, 2 * w + t, lane, I, zero_rows[p], F[t][p][0], F[t][p][1]);
+#endif
         }
     TS_STAMP(20);
     ts::barrier_lds();
@@ -572,7 +610,24 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc[t][0] = (f32x16)0.f; acc[t][1] = (f32x16)0.f; }
     TS_STAMP(22);
+    // F (the v fragments) stays live through this loop: the next epilogue rewrites it only afterwards
+    auto side_planes = [&](const KMat& m, const int ks) __attribute__((always_inline)) {       // 4 x NS (tile, column tile, plane) units over 16 k-steps
+        if (!save) return;
+#pragma unroll
+        for (int u = 0; u < 4 * NS; ++u) {
+            const int tp = u / NS, s_ = u % NS;
+            if (ks == (16 / (4 * NS)) * u + 1)
+                ts::save_plane_k(m, net, NS, s_, tile0 + (tp & 1), 2 * w + (tp >> 1), lane, I, zero_rows[tp & 1], F[tp >> 1][tp & 1][0].w[s_], F[tp >> 1][tp & 1][1].w[s_]);
+        }
+    };
+#if TS_DEFER_SAVES
+    {
+        auto side = [&](const int ks) __attribute__((always_inline)) { side_planes(sv.V, ks); };
+        ts::gemm<NS, 16, 2, false>(chunk(kS4 + 2 * w * 16), xl, lane, H, acc, side);
+    }
+#else
     ts::gemm<NS, 16, 2>(chunk(kS4 + 2 * w * 16), xl, lane, H, acc);
+#endif
     TS_STAMP(23);
     if (a.jac_n && w < 3) ts::gemm_head<NS, 16, 2>(chunk(kS5 + 2 * w * 16), lane, H);
 #pragma unroll
@@ -584,7 +639,11 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
                 const u32 bits = m1w[p] >> (16 * t + r);
                 frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, (bits & 1u) ? acc[t][p][r] : 0.f, (bits & 2u) ? acc[t][p][r + 1] : 0.f);
             }
+#if TS_DEFER_SAVES
+            if (save && (!a.jac_n || w >= 3)) ts::save_tile_k<NS, NS>(sv.T1, net, tile0 + p, 2 * w + t, lane, I, zero_rows[p], F[t][p][0], F[t][p][1]);
+#else
             if (save) ts::save_tile_k<NS, NS>(sv.T1, net, tile0 + p, 2 * w + t, lane, I, zero_rows[p], F[t][p][0], F[t][p][1]);
+#endif
         }
     if (!a.jac_n) return;
     TS_STAMP(24);
@@ -597,7 +656,14 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc[t][0] = (f32x16)0.f; acc[t][1] = (f32x16)0.f; }
     TS_STAMP(26);
+#if TS_DEFER_SAVES
+    {
+        auto side = [&](const int ks) __attribute__((always_inline)) { side_planes(sv.T1, ks); };
+        ts::gemm<NS, 16, 2, false>(chunk(kS5 + 2 * w * 16), xl, lane, H, acc, side);
+    }
+#else
     ts::gemm<NS, 16, 2>(chunk(kS5 + 2 * w * 16), xl, lane, H, acc);
+#endif
     TS_STAMP(27);
     {
         const int c = w;

@@ -578,7 +578,10 @@ DPN_HD int64_t saved_state_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kN
 // the saved state is followed by the positional features of the tile-split forward kernel (dpn_fwd_tiles.h: per 64 points the pe3 and pe6
 // fragment images and the d pe3 / d xi table, evaluated once per point instead of once per point and net)
 DPN_HD int64_t feature_bytes(int64_t n_pad, int ns) { return (n_pad / 64) * (int64_t)(2 * 12 * 2 * ns * 1024 + 3 * 2 * 2 * 64 * 64); }
-static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_pad, ns) + feature_bytes(n_pad, ns); }
+// DPN_FEATURES_PREPASS=1 (measured experiment, OFF by default): the pre-pass kernel costs 25 us (it writes 86 MB) and shortens the forward kernel
+// by 19 us -- no net gain at six nets per point; without it the features are evaluated inside the kernels, hidden behind the partner wave
+static bool features_prepass() { const char* e = getenv("DPN_FEATURES_PREPASS"); return e && e[0] == '1'; }
+static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_pad, ns) + (features_prepass() ? feature_bytes(n_pad, ns) : 0); }
 
 struct OperandView {     // written by dpn_bwd_points
     KMat Z1, Z;          // [6][NS] x 256
@@ -608,6 +611,7 @@ struct FwdArgs {
     float* out_n;
     float* jac_n;
     void* saved;
+    const char* feat;        // positional features of dpn_features_kernel (tile-split kernel, DPN_FEATURES_PREPASS=1), else null
 #ifdef DPN_TIMELINE
     unsigned* timeline;      // [blocks][6 nets][8 wave slots][64]: s_memtime (low word) at the start of every pipeline step (experiment build only)
 #endif
@@ -2197,9 +2201,9 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
     if (!coord_data || !freqs || !geo || !packed || !out_n || n <= 0 || (prec != 1 && prec != 2)) return -1;
     if (!pe_in && (!x || !y || !t)) return -1;
 #ifdef DPN_TIMELINE
-    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, g_timeline};
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, g_timeline};
 #else
-    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved};
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr};
 #endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
@@ -2217,8 +2221,9 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
     const bool tiles = force ? (force[0] == 't') : (prec == 2);
     if (tiles && !pe_in) {
         const dim3 grid64((unsigned)(a.n_pad / 64), kNets);
-        if (saved) {                                   // positional features once per point (read by the six nets' workgroups)
+        if (saved && features_prepass()) {             // positional features once per point (read by the six nets' workgroups)
             char* feat = reinterpret_cast<char*>(saved) + saved_state_bytes(a.n_pad, prec);
+            a.feat = feat;
             if (prec == 1) hipLaunchKernelGGL(dpn_features_kernel<1>, dim3(grid64.x), dim3(256), 0, s, a, feat);
             else hipLaunchKernelGGL(dpn_features_kernel<2>, dim3(grid64.x), dim3(256), 0, s, a, feat);
         }

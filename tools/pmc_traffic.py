@@ -34,7 +34,7 @@ def main():
     out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_traffic.json')
     fetch, write = last_dispatch(fdb, 'FETCH_SIZE'), last_dispatch(wdb, 'WRITE_SIZE')
     tab = json.load(open(out)) if os.path.exists(out) else {}
-    for kernel in ('dpn_fwd_kernel', 'dpn_wgrad_kernel', 'dpn_bwd_kernel'):
+    for kernel in ('dpn_fwd_kernel', 'dpn_fwd_tiles_kernel', 'dpn_features_kernel', 'dpn_wgrad_kernel', 'dpn_bwd_kernel', 'dpn_bwd_tiles_kernel'):
         f = next((v for k, v in fetch.items() if k.startswith(kernel)), None)
         w = next((v for k, v in write.items() if k.startswith(kernel)), None)
         if f is None or w is None:
