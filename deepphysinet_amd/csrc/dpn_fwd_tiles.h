@@ -760,6 +760,15 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
             g16[p][r] = (q < a.n) ? a.g_out[q * 6 + net] : 0.f;
         }
     // ---------------- Z0 -> X (k-steps 0..11) and K-layout rows: wave w builds the (column tile of Z0, point tile) units 3w .. 3w+2
+    Frag<NS> Z0f[3][2];
+    // the K-layout hand-over of a unit set {f[uu][0], f[uu][1]} (three units x NS planes) spread over a 12-k-step multiply loop
+    auto side_units = [&](const KMat& m, const Frag<NS> (&f)[3][2], const int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < 3 * NS; ++v) {
+            const int uu = v / NS, s_ = v % NS, u = 3 * w + uu;
+            if (ks == (12 / (3 * NS)) * v + 1) ts::save_plane_k(m, net, NS, s_, tile0 + (u & 1), u >> 1, lane, I, false, f[uu][0].w[s_], f[uu][1].w[s_]);
+        }
+    };
 #pragma unroll
     for (int uu = 0; uu < 3; ++uu) {
         const int u = 3 * w + uu, ct = u >> 1, p = u & 1;     // wave-uniform
@@ -767,12 +776,15 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
         const int64_t pcp = p ? pc[1] : pc[0];
         float gjc = 0.f;
         if (a.g_jxi && ((tile0 + p) * 32 + j) < a.n) gjc = a.g_jxi[(pcp * 6 + net) * 3 + (ct >> 1)];
-        Frag<NS> f0, f1;
+        Frag<NS>& f0 = Z0f[uu][0];
+        Frag<NS>& f1 = Z0f[uu][1];
         ts::z0_frag<NS>(f0, a, 2 * ct, h, pcp, gp, gjc);
         ts::z0_frag<NS>(f1, a, 2 * ct + 1, h, pcp, gp, gjc);
         ts::x_store<NS>(xl, 2 * ct, p, f0);
         ts::x_store<NS>(xl, 2 * ct + 1, p, f1);
+#if !TS_DEFER_SAVES
         ts::save_tile_k<NS, NS>(ov.Z0, net, tile0 + p, ct, lane, I, false, f0, f1);
+#endif
     }
     ts::barrier_lds();
     // ---------------- Z1 = m1 (.) (w1 Z0 + g b1) -> X (+ K-layout rows)
@@ -782,7 +794,14 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) ts::acc_init(acc[t][p], vec, kVecB1, h, 2 * w + t, g[p]);
+#if TS_DEFER_SAVES
+    {
+        auto side = [&](const int ks) __attribute__((always_inline)) { side_units(ov.Z0, Z0f, ks); };
+        ts::gemm<NS, 12, 2, false>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc, side);
+    }
+#else
     ts::gemm<NS, 12, 2>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
+#endif
     ts::gemm_head<NS, 16, 2>(chunk(kS1 + 2 * w * 16), lane, H);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -793,7 +812,9 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
                 const u32 bits = m1w[p] >> (16 * t + r);
                 frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, (bits & 1u) ? acc[t][p][r] : 0.f, (bits & 2u) ? acc[t][p][r + 1] : 0.f);
             }
+#if !TS_DEFER_SAVES
             ts::save_tile_k<NS, NS>(ov.Z1, net, tile0 + p, 2 * w + t, lane, I, false, F[t][p][0], F[t][p][1]);
+#endif
         }
     ts::barrier_lds();                                        // everybody is done reading Z0
 #pragma unroll
@@ -815,10 +836,24 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
                 for (int r = 0; r < 16; ++r) acc[t][p][r] = g16[p][r] * cv;
         }
     }
+#if TS_DEFER_SAVES
+    {
+        auto side = [&](const int ks) __attribute__((always_inline)) {             // Z1 (still in F): 4 x NS plane units over the 16 k-steps
+#pragma unroll
+            for (int u = 0; u < 4 * NS; ++u) {
+                const int tp = u / NS, s_ = u % NS;
+                if (ks == (16 / (4 * NS)) * u + 1)
+                    ts::save_plane_k(ov.Z1, net, NS, s_, tile0 + (tp & 1), 2 * w + (tp >> 1), lane, I, false, F[tp >> 1][tp & 1][0].w[s_], F[tp >> 1][tp & 1][1].w[s_]);
+            }
+        };
+        ts::gemm<NS, 16, 2, true>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc, side);
+    }
+#else
     ts::gemm<NS, 16, 2, true>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
+#endif
     ts::gemm_head<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), lane, H);
+    Frag<NS> f6[3][2];
     {   // G6 = g pe6 -> X (k-steps 0..11) and K-layout rows: units as for Z0
-        Frag<NS> f6[3][2];
 #pragma unroll
         for (int uu = 0; uu < 3; ++uu) {
             const int u = 3 * w + uu, ct = u >> 1, p = u & 1;
@@ -826,7 +861,9 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
             const int64_t pcp = p ? pc[1] : pc[0];
             ts::pe6_frag<NS>(f6[uu][0], a, 2 * ct, h, pcp, gp);
             ts::pe6_frag<NS>(f6[uu][1], a, 2 * ct + 1, h, pcp, gp);
+#if !TS_DEFER_SAVES
             ts::save_tile_k<NS, NS>(ov.G6, net, tile0 + p, ct, lane, I, false, f6[uu][0], f6[uu][1]);
+#endif
         }
         ts::barrier_lds();                                    // everybody is done reading Z1
 #pragma unroll
@@ -837,7 +874,14 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
         }
         ts::barrier_lds();
     }
+#if TS_DEFER_SAVES
+    {
+        auto side = [&](const int ks) __attribute__((always_inline)) { side_units(ov.G6, f6, ks); };
+        ts::gemm<NS, 12, 2, true>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc, side);
+    }
+#else
     ts::gemm<NS, 12, 2, true>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc);
+#endif
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll

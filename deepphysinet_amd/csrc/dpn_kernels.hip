@@ -1441,6 +1441,8 @@ struct FinishArgs {
     float* scratch_r;       // [6][256] r vector (lives in the partials buffer tail)
     int splits[4], ns;      // point ranges per product, as dpn_wgrad_kernel cut them
     int64_t n;
+    int phase;              // 0: everything; 1: what the hyper-network's backward needs (d w1b1, d w2b2, d evec: products 1 and 3);
+                            // 2: the static tensors' gradients (products 0 and 2, the rank-1 fc.2 part) -- dpn_wgrad_part / _finish_part
 };
 
 DEV int slot_of_ch(int ch) { return (ch & ~15) + 8 * ((ch >> 2) & 1) + 4 * ((ch >> 3) & 1) + (ch & 3); }
@@ -1462,12 +1464,12 @@ DEV int slot_of_pe6(int orig) {
 // loads in flight at once (a loop of load -> wait -> add, which is what hipcc makes of the obvious code, costs one HBM round trip per
 // range and per sum: 40 in a row per thread).  Ranges beyond ks[q] re-read the last one and are not added; the additions keep the
 // range order, so the result does not depend on how the loads are grouped.
-constexpr int kMaxSplits = 12;                  // choose_plan() never returns more for one product
-template <int NQ>
-DEV void part_sums(const float* partials, const int (&ks)[NQ], int net, const int (&off)[NQ], float (&out)[NQ]) {
-    float v[kMaxSplits][NQ];
+constexpr int kMaxSplits = 24;                  // choose_plan() / part_plan() never return more for one product
+template <int NQ, int MAXS>
+DEV void part_sums_n(const float* partials, const int (&ks)[NQ], int net, const int (&off)[NQ], float (&out)[NQ]) {
+    float v[MAXS][NQ];
 #pragma unroll
-    for (int k = 0; k < kMaxSplits; ++k) {
+    for (int k = 0; k < MAXS; ++k) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             v[k][q] = __builtin_nontemporal_load(partials + ((int64_t)min(k, ks[q] - 1) * kNets + net) * kPartFloats + off[q]);   // read once
@@ -1476,9 +1478,17 @@ DEV void part_sums(const float* partials, const int (&ks)[NQ], int net, const in
     for (int q = 0; q < NQ; ++q) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < kMaxSplits; ++k) t += (k < ks[q]) ? v[k][q] : 0.f;
+        for (int k = 0; k < MAXS; ++k) t += (k < ks[q]) ? v[k][q] : 0.f;
         out[q] = t;
     }
+}
+template <int NQ>
+DEV void part_sums(const float* partials, const int (&ks)[NQ], int net, const int (&off)[NQ], float (&out)[NQ]) {
+    int most = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) most = ks[q] > most ? ks[q] : most;
+    if (most <= 12) part_sums_n<NQ, 12>(partials, ks, net, off, out);       // the one-launch plan (choose_plan): at most 11 ranges per product
+    else part_sums_n<NQ, kMaxSplits>(partials, ks, net, off, out);          // the two-part plan (part_plan)
 }
 
 // one block per (output row o, net): reduces the splits, un-permutes, writes dW1, d(w2b2), d(w1b1), dWd rows and r[o]
@@ -1492,42 +1502,75 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
     const float* vec = reinterpret_cast<const float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
     const int T = o >> 5, w = o & 31, hh = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);
     const float uo = vec[kVecU * 256 + hh * 128 + T * 16 + r];
+    const bool heads = a.phase != 2, stat = a.phase != 1;
     // thread 0 also owns the row's three vector entries: fetched with everything else, not after the reduction
     float rowv[3] = {0.f, 0.f, 0.f};
     if (i == 0) {
         const int offv[3] = {kPartVec + 0 * 256 + so, kPartVec + 2 * 256 + so, kPartVec + 3 * 256 + so};     // written by products 0, 1, 3
-        const int ksv[3] = {a.splits[0], a.splits[1], a.splits[3]};
+        const int ksv[3] = {stat ? a.splits[0] : 1, a.splits[1], heads ? a.splits[3] : 1};
         part_sums<3>(a.partials, ksv, net, offv, rowv);
     }
-    const int off2[2] = {part_off(0) + so * 256 + i, part_off(1) + so * 256 + si};      // Z's columns are in natural order (SWAP output)
-    float g2[2];
-    const int ks2[2] = {a.splits[0], a.splits[1]};
-    part_sums<2>(a.partials, ks2, net, off2, g2);
-    const float Goi = g2[0];
-    Gd.W1[o * 256 + i] = uo * Goi;
-    red[i] = P.W1[o * 256 + i] * Goi;
-    Gd.w2b2[o * Gd.ld_w2b2 + i] = g2[1];
-    if (i < kPe) {
-        const int offp[2] = {part_off(2) + so * 192 + slot_of_pe6(i), part_off(3) + so * 192 + slot_of_pe3(i)};
-        float gp[2];
-        const int ksp[2] = {a.splits[2], a.splits[3]};
-        part_sums<2>(a.partials, ksp, net, offp, gp);
-        Gd.Wd[o * kPe + i] = gp[0];
-        Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[1];
+    float Goi = 0.f;
+    if (a.phase == 0) {
+        const int off2[2] = {part_off(0) + so * 256 + i, part_off(1) + so * 256 + si};      // Z's columns are in natural order (SWAP output)
+        float g2[2];
+        const int ks2[2] = {a.splits[0], a.splits[1]};
+        part_sums<2>(a.partials, ks2, net, off2, g2);
+        Goi = g2[0];
+        Gd.w2b2[o * Gd.ld_w2b2 + i] = g2[1];
+    } else if (heads) {
+        const int off1[1] = {part_off(1) + so * 256 + si};
+        float g1[1];
+        const int ks1[1] = {a.splits[1]};
+        part_sums<1>(a.partials, ks1, net, off1, g1);
+        Gd.w2b2[o * Gd.ld_w2b2 + i] = g1[0];
+    } else {
+        const int off0[1] = {part_off(0) + so * 256 + i};
+        float g0[1];
+        const int ks0[1] = {a.splits[0]};
+        part_sums<1>(a.partials, ks0, net, off0, g0);
+        Goi = g0[0];
     }
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (i < s) red[i] += red[i + s];
+    if (stat) {
+        Gd.W1[o * 256 + i] = uo * Goi;
+        red[i] = P.W1[o * 256 + i] * Goi;
+    }
+    if (i < kPe) {
+        if (a.phase == 0) {
+            const int offp[2] = {part_off(2) + so * 192 + slot_of_pe6(i), part_off(3) + so * 192 + slot_of_pe3(i)};
+            float gp[2];
+            const int ksp[2] = {a.splits[2], a.splits[3]};
+            part_sums<2>(a.partials, ksp, net, offp, gp);
+            Gd.Wd[o * kPe + i] = gp[0];
+            Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[1];
+        } else {
+            const int offp[1] = {heads ? part_off(3) + so * 192 + slot_of_pe3(i) : part_off(2) + so * 192 + slot_of_pe6(i)};
+            float gp[1];
+            const int ksp[1] = {heads ? a.splits[3] : a.splits[2]};
+            part_sums<1>(a.partials, ksp, net, offp, gp);
+            if (heads) Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[0];
+            else Gd.Wd[o * kPe + i] = gp[0];
+        }
+    }
+    if (stat) {
         __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (i < s) red[i] += red[i + s];
+            __syncthreads();
+        }
     }
     if (i == 0) {
         const float mvec = rowv[0], gcv = rowv[1], db1 = rowv[2];
-        a.scratch_r[net * 256 + o] = red[0] + P.bf1[o] * mvec;
-        Gd.bf1[o] = uo * mvec;
-        Gd.w2b2[o * Gd.ld_w2b2 + 256] = gcv;
-        Gd.w1b1[o * Gd.ld_w1b1 + 192] = db1;
-        Gd.bd[o] = gcv;
-        Gd.evec[o] = gcv;
+        if (stat) {
+            a.scratch_r[net * 256 + o] = red[0] + P.bf1[o] * mvec;
+            Gd.bf1[o] = uo * mvec;
+            Gd.bd[o] = gcv;
+        }
+        if (heads) {
+            Gd.w2b2[o * Gd.ld_w2b2 + 256] = gcv;
+            Gd.w1b1[o * Gd.ld_w1b1 + 192] = db1;
+            Gd.evec[o] = gcv;
+        }
     }
 }
 
@@ -2160,6 +2203,22 @@ static inline SplitPlan choose_plan(int64_t n_pad, int ns) {
     return p;
 }
 #endif  // DPN_HAS_REST
+#if DPN_HAS_REST
+// Two-part weight-gradient reduction (dpn_wgrad_part): part 1 = the products the hyper-network's backward waits for (dw2 = V^T Z1,
+// dw1 = T1^T Z0) cut into TWICE as many point ranges, so that they fill the chip on their own (252 workgroups, half the tiles each);
+// part 2 = the products that end in static tensors (G = M2^T Z, dWd = V^T G6) with the usual ranges: 120 workgroups = 120 CUs, which the
+// caller runs on a second stream BESIDE the encoder's backward chain -- a chain of ~35 latency-bound kernels that needs a few dozen free
+// CUs at a time (measured, tools/wgrad_overlap_probe.py: with >= 52 CUs free the two overlap, with all 252 taken they run back to back).
+static inline SplitPlan part_plan(int64_t n_pad, int ns, int part) {
+    const SplitPlan b = choose_plan(n_pad, ns);
+    const int s1 = b.s[1] * 2 - 1 > kMaxSplits ? kMaxSplits : b.s[1] * 2 - 1, s3 = b.s[3] * 2 - 1 > kMaxSplits ? kMaxSplits : b.s[3] * 2 - 1;
+    SplitPlan p;
+    if (part == 1) p = SplitPlan{{0, s1, 0, s3}, s1 > s3 ? s1 : s3};
+    else if (part == 2) p = SplitPlan{{b.s[0], 0, b.s[2], 0}, b.s[0] > b.s[2] ? b.s[0] : b.s[2]};
+    else { p = SplitPlan{{b.s[0], s1, b.s[2], s3}, 0}; for (int k = 0; k < 4; ++k) if (p.s[k] > p.most) p.most = p.s[k]; }
+    return p;
+}
+#endif
 static inline int ck(hipError_t e) { return (int)e; }
 
 extern "C" {
@@ -2174,7 +2233,7 @@ int dpn_sizes(int64_t n, int prec, DpnSizes* out) {
     out->packed = (int64_t)kNets * pack_bytes_per_net(prec);
     out->saved = saved_bytes(n_pad, prec);
     out->operands = operand_bytes(n_pad, prec);
-    out->k_splits = choose_plan(n_pad, prec).most;
+    out->k_splits = part_plan(n_pad, prec, 0).most;            // sized for the two-part plan as well (dpn_wgrad_part)
     out->partials = ((int64_t)out->k_splits * kNets * kPartFloats + kNets * 256) * 4;
     return 0;
 }
@@ -2312,21 +2371,46 @@ int dpn_wgrad(int64_t n, int prec, const float* g_out, const void* saved, const 
     return ck(hipGetLastError());
 }
 
-int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
-                     const DpnNetGradPtrs grads[DPN_NETS], void* stream) {
-    if (!nets || !packed || !partials || !grads || n <= 0 || (prec != 1 && prec != 2)) return -1;
+static int wgrad_finish_impl(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
+                             const DpnNetGradPtrs grads[DPN_NETS], int part, void* stream) {
+    if (!nets || !packed || !partials || !grads || n <= 0 || (prec != 1 && prec != 2) || part < 0 || part > 2) return -1;
     FinishArgs a;
     for (int k = 0; k < kNets; ++k) { a.net[k] = nets[k]; a.grad[k] = grads[k]; }
     a.packed = reinterpret_cast<const char*>(packed);
     a.partials = reinterpret_cast<const float*>(partials);
-    const SplitPlan plan = choose_plan(pad_points(n), prec);
+    const SplitPlan plan = part ? part_plan(pad_points(n), prec, 0) : choose_plan(pad_points(n), prec);
     for (int k = 0; k < 4; ++k) a.splits[k] = plan.s[k];
     a.ns = prec;
     a.n = n;
-    a.scratch_r = const_cast<float*>(a.partials) + (int64_t)plan.most * kNets * kPartFloats;   // [6][256], tail of the partials buffer
+    a.phase = part;
+    // [6][256] r vector in the tail of the partials buffer (which dpn_sizes dimensions for the two-part plan)
+    a.scratch_r = const_cast<float*>(a.partials) + (int64_t)part_plan(pad_points(n), prec, 0).most * kNets * kPartFloats;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
+    if (part != 1) hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
+    return ck(hipGetLastError());
+}
+int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
+                     const DpnNetGradPtrs grads[DPN_NETS], void* stream) {
+    return wgrad_finish_impl(nets, packed, n, prec, partials, grads, 0, stream);
+}
+int dpn_wgrad_finish_part(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
+                          const DpnNetGradPtrs grads[DPN_NETS], int part, void* stream) {
+    if (part != 1 && part != 2) return -1;
+    return wgrad_finish_impl(nets, packed, n, prec, partials, grads, part, stream);
+}
+int dpn_wgrad_part(int64_t n, int prec, int part, const void* saved, const void* operands, void* partials, void* stream) {
+    if (!saved || !operands || !partials || n <= 0 || (prec != 1 && prec != 2) || (part != 1 && part != 2)) return -1;
+    const SplitPlan plan = part_plan(pad_points(n), prec, part);
+    WgradArgs a{n, pad_points(n), {plan.s[0], plan.s[1], plan.s[2], plan.s[3]}, const_cast<void*>(saved), const_cast<void*>(operands),
+                reinterpret_cast<float*>(partials)};
+#ifdef DPN_WGRAD_PHASES
+    a.phases = nullptr;
+#endif
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(plan.s[0] + plan.s[1] + plan.s[2] + plan.s[3], kNets);
+    if (prec == 1) hipLaunchKernelGGL(dpn_wgrad_kernel<1>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(dpn_wgrad_kernel<2>, grid, dim3(512), 0, s, a);
     return ck(hipGetLastError());
 }
 

@@ -10,13 +10,14 @@ PyTorch is used for device memory, the current HIP stream and autograd bookkeepi
 points happens in libdpn_hip.so (deepphysinet_amd/csrc/dpn_kernels.hip).  There is no CPU path.
 """
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
 
 import torch
 
 from . import _lib as L
-from .grad_arena import new_grad
+from .grad_arena import new_grad, slot_of
 
 # configs/DeepPhysiNet_NCEP_cfg.py:64-76 -- order u10, v10, pres, t2, q2, rio (network output order)
 OBS_ORDER = ('u10', 'v10', 'pres', 't2', 'q2', 'rio')
@@ -142,9 +143,30 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     return out_n, jac_n
 
 
+_side_stream = {}
+# Measured experiment, OFF by default (profiles/round3_two_stream_wgrad.txt): the overlap works (graph branches run side by side once more than
+# ~50 CUs are free) but part 2 takes HBM bandwidth from the latency-bound chain kernels beside it (335 -> 440 us) and part 1 costs 195 us against
+# 172 us for half of the one-launch kernel: the step does not get shorter (1.726 ms both ways).
+TWO_STREAM_WGRAD = os.environ.get('DPN_WGRAD_TWO_STREAMS', '0') == '1'
+
+
+def _side(dev):
+    if dev not in _side_stream:
+        # high priority: the side branch must be dispatched the moment its dependency clears, not when the main queue happens to leave a gap
+        _side_stream[dev] = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get('DPN_SIDE_PRIORITY', '1') == '1' else 0)
+    return _side_stream[dev]
+
+
 def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics, into=None):
     """Weight gradients from per-point cotangents.  Returns (g_heads [256,2700], g_evec [6,256], [48 static grads]); `into` = the same
-    triple preallocated by the caller (a batch of fields writes each field's gradients side by side)."""
+    triple preallocated by the caller (a batch of fields writes each field's gradients side by side).
+
+    Large batches inside an autograd backward pass take the TWO-STREAM form: the products the hyper-network's backward waits for (part 1)
+    run first on all CUs; the static tensors' products (part 2, 120 workgroups) run on a side stream beside the ~35 small kernels of the
+    heads' and the encoder's backward that autograd issues next on the main stream; the main stream joins the side stream in an
+    end-of-backward callback, i.e. before anything can read a static gradient.  Only gradients nobody touches during the backward pass may
+    be produced that way: the 48 static gradients must be fresh slots of the optimiser's flat buffer (grad_arena: autograd then only
+    stores the reference)."""
     lib = L.load()
     n = coord_data.shape[0]
     dev = coord_data.device
@@ -154,18 +176,42 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
     L.check(lib.dpn_bwd_points(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), n, _ptr(_freqs(dev)), ctypes.byref(geo),
                                _ptr(ws.packed), cfg.prec, _ptr(g_out), _ptr(g_jxi), _ptr(ws.saved), _ptr(operands), _stream()),
             'dpn_bwd_points')
-    L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
+    arena = False
     if into is None:
         g_heads = torch.empty((256, HEADS_COLS), dtype=torch.float32, device=dev)
         g_evec = torch.empty((6, 256), dtype=torch.float32, device=dev)
         # the 48 static parameters' gradients go straight into the optimiser's flat gradient buffer when one is registered (grad_arena)
         # (not when one tensor fills several slots -- VariableNet.forward standalone -- whose gradients must stay separate tensors)
         arena = len({s.data_ptr() for s in statics}) == len(statics)
-        g_stat = [new_grad(statics[k * 8 + j], STATIC_SHAPES[j]) if arena else torch.empty(STATIC_SHAPES[j], dtype=torch.float32, device=dev)
-                  for k in range(6) for j in range(8)]
+        slots = [slot_of(statics[k * 8 + j]) if arena else None for k in range(6) for j in range(8)]
+        g_stat = [s_.view(STATIC_SHAPES[i % 8]) if s_ is not None else torch.empty(STATIC_SHAPES[i % 8], dtype=torch.float32, device=dev)
+                  for i, s_ in enumerate(slots)]
+        arena = arena and all(s_ is not None for s_ in slots)
     else:
         g_heads, g_evec, g_stat = into
     garr = _net_ptrs(g_heads, g_evec, g_stat, cls=L.DpnNetGradPtrs)
+    if TWO_STREAM_WGRAD and arena and n >= 16384:
+        main = torch.cuda.current_stream()
+        side = _side(dev)
+        L.check(lib.dpn_wgrad_part(n, cfg.prec, 1, _ptr(ws.saved), _ptr(operands), _ptr(partials), main.cuda_stream), 'dpn_wgrad_part')
+        side.wait_stream(main)                                   # part 2 starts behind part 1 (which needs every CU)
+        L.check(lib.dpn_wgrad_part(n, cfg.prec, 2, _ptr(ws.saved), _ptr(operands), _ptr(partials), side.cuda_stream), 'dpn_wgrad_part')
+        L.check(lib.dpn_wgrad_finish_part(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, 1, main.cuda_stream), 'dpn_wgrad_finish_part')
+        L.check(lib.dpn_wgrad_finish_part(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, 2, side.cuda_stream), 'dpn_wgrad_finish_part')
+        # alive until the join: the side stream reads / writes them.  NOT the 48 gradient views: autograd steals a returned gradient only while
+        # nobody else holds it (a second reference makes AccumulateGrad copy all 48 -- before the side stream has written them); their memory is
+        # the optimiser's flat buffer
+        keep = (operands, partials, ws, nets, garr)
+
+        def join(keep=keep):
+            torch.cuda.current_stream().wait_stream(side)
+            del keep
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join)     # runs when this backward pass has issued its last node
+        except RuntimeError:                                     # not inside a backward pass: nothing to overlap with
+            join()
+        return g_heads, g_evec, g_stat
+    L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
     L.check(lib.dpn_wgrad_finish(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, _stream()), 'dpn_wgrad_finish')
     return g_heads, g_evec, g_stat
 

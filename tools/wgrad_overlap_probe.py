@@ -73,6 +73,9 @@ def main():
     os.environ.pop('DPN_WGRAD_PLAN')
     if '--overlap' not in sys.argv:
         return
+    if os.environ.get('DPN_OVERLAP_PLAN'):            # round 3: leave CUs free for the chain (the round-2 probe ran wgrad on all 252)
+        os.environ['DPN_WGRAD_PLAN'] = os.environ['DPN_OVERLAP_PLAN']
+        print('overlap section with wgrad plan', os.environ['DPN_WGRAD_PLAN'])
 
     # (ii) the encoder + heads chain (forward + backward) as one graph; wgrad as another; alone and together
     ws = PP._Workspace(n, cfg.prec, dev)
