@@ -10,7 +10,7 @@
 // (no LDS round trip, no cross-lane traffic): k-step ks, slot (h,e)  <->  channel chain_ch(ks,h,e).
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DPN_HD __host__ __device__ constexpr
 #else
 #define DPN_HD constexpr

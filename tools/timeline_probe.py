@@ -81,20 +81,23 @@ def main():
               (prec, '  '.join('%s %.0f' % (nm, P[..., k].mean()) for k, nm in enumerate(names) if k != 4), P.sum(-1).mean()))
         print('   per step: %s' % '  '.join('%s %.0f' % (nm, P[..., k].mean() / 54) for k, nm in enumerate(names) if k != 4))
     d = (T[..., 1:] - T[..., :-1]) & 0xFFFFFFFF            # wrap-safe deltas, [blk, net, wave, 63]
+    # a stamp that was never written (early exit) or a wave whose 32-bit clock word wrapped twice gives a delta of ~2^32: those samples are
+    # DROPPED from every statistic below (round 2's stage table averaged them in: "fc1 1 235 626 cycles per chunk")
+    d = np.where(d < (1 << 26), d, np.nan)
     total = (T[..., 62] - T[..., 0]) & 0xFFFFFFFF
     print('%s: waves %d, cycles per wave entry -> exit: mean %.0f  min %d  max %d' % (prec, total.size, total.mean(), total.min(), total.max()))
-    print('prologue (entry -> ring primed): %.0f   primed -> first step: %.0f' % (d[..., 0].mean(), d[..., 1].mean()))
+    print('prologue (entry -> ring primed): %.0f   primed -> first step: %.0f' % (np.nanmean(d[..., 0]), np.nanmean(d[..., 1])))
     nsplit = (3 if prec == 'bf16x2' else 1) * (4.0 / nw)         # the eight-wave kernel's waves multiply half of K each
     print('%-5s %6s %10s %10s %10s %12s' % ('stage', 'chunks', 'cyc/chunk', 'min', 'max', 'MFMA-bound'))
     for name, c0, c1, nk in STAGES:
         seg = d[..., 2 + c0:2 + c1]                        # step C spans stamp 2+C -> 3+C; the last step of the kernel ends at stamp 62
         if c1 == 54:
             seg = np.concatenate([d[..., 2 + c0:2 + c1 - 1], ((T[..., 62] - T[..., 2 + 53]) & 0xFFFFFFFF)[..., None]], axis=-1)
-        print('%-5s %6d %10.0f %10d %10d %12d' % (name, c1 - c0, seg.mean(), seg.min(), seg.max(), int(nk * 32 * nsplit)))
+        print('%-5s %6d %10.0f %10d %10d %12d' % (name, c1 - c0, np.nanmean(seg), np.nanmin(seg), np.nanmax(seg), int(nk * 32 * nsplit)))
     # per-chunk profile of one workgroup in the middle of the grid, wave 0..3
     blk = nblk // 2
     for w in range(nw):
-        print('blk %d net 2 wave %d:' % (blk, w), ' '.join('%d' % v for v in d[blk, 2, w, :56]))
+        print('blk %d net 2 wave %d:' % (blk, w), ' '.join(('%d' % v) if v == v else 'dropped' for v in d[blk, 2, w, :56]))
     starts = T[blk, 2, :, 2:56]
     print('inter-wave skew at step starts (max - min over the waves), blk %d net 2:' % blk, ' '.join('%d' % v for v in ((starts.max(0) - starts.min(0)) & 0xFFFFFFFF)))
 
