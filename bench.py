@@ -36,6 +36,7 @@ import torch
 ALG_FLOP_FWD_JAC = 11_218_944          # algorithmic FLOP per collocation point, fwd + Jacobian
 ALG_FLOP_STEP = 31_887_360             # fwd + Jacobian + bwd
 EXEC_MAC_FWD = 409_600                 # MACs per point per net actually issued by dpn_fwd_kernel
+EXEC_MAC_BWD1 = 163_840                # backward stage 1: w1 Z0 (192 x 256) + w2 Z1 (256 x 256) + Wd G6 (192 x 256) per point per net
 MFMA_PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12                      # HBM3E, MI355X_MICROARCH.md
 # HBM bytes per launch of the two roofline kernels come from the rocprofv3 PMC passes committed in profiles/ (bench.py cannot run PMC
@@ -446,6 +447,14 @@ def main():
                     'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': w_bytes / (w_ms * 1e-3) / HBM_PEAK, 'kernel_ms': w_ms, 'algorithmic_bytes': w_bytes,
                     'traffic': pmc_traffic('dpn_wgrad_kernel', prec, args.points)[0], 'bwd_points_kernel_ms': b_ms}
+        # backward stage 1 (dpn_bwd_tiles_kernel / dpn_bwd_kernel): per point and net it writes the K-layout operands of the four weight-gradient
+        # products -- Z1, Z (256 columns) and Z0, G6 (192 columns), each hi (+ lo) bf16 -- and reads 40 B of cotangents: bound by its HBM writes
+        b_bytes = ws.sizes.n_pad * 6 * (2 * 512 + 2 * 384) * ns
+        b_traffic = pmc_traffic('dpn_bwd_tiles_kernel' if ns == 2 else 'dpn_bwd_kernel', prec, args.points)[0]
+        roof_hbm['bwd_stage1_kernel'] = {'bound': 'hbm', 'kernel': 'dpn_bwd_tiles_kernel<2>' if ns == 2 else 'dpn_bwd_kernel<1>',
+                                         'achieved': b_bytes / (b_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                                         'frac': b_bytes / (b_ms * 1e-3) / HBM_PEAK, 'kernel_ms': b_ms, 'algorithmic_bytes': b_bytes, 'traffic': b_traffic,
+                                         'executed_mfma_frac_of_peak': args.points * 6 * EXEC_MAC_BWD1 * 2 * nsplit / (b_ms * 1e-3) / MFMA_PEAK_BF16}
         return roof, roof_hbm
 
     if rank == 0:
