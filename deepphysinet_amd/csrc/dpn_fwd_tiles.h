@@ -484,11 +484,13 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
             for (int p = 0; p < 2; ++p) ts::pe6_frag<NS>(f6[kk][p], a, 3 * w + kk, h, pc[p]);
+    TS_STAMP(8);
         ts::barrier_lds();                   // everybody is done reading h1
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
             for (int p = 0; p < 2; ++p) ts::x_store<NS>(xl, 3 * w + kk, p, f6[kk][p]);
+    TS_STAMP(9);
         ts::barrier_lds();
     }
     TS_STAMP(10);
