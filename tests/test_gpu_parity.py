@@ -1039,8 +1039,9 @@ def test_config4_fp8_encoder_workload():
     assert err_fp8.max() > 10 * err_prod.max(), (err_fp8, err_prod)  # ... and it is a real precision loss, not noise
 
 
+@pytest.mark.parametrize('prec', ['bf16x2', 'bf16'])
 @pytest.mark.parametrize('n', [1037, 70])
-def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n):
+def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n, prec):
     """The hi+lo mode's forward + Jacobian and backward stage-1 kernels exist in two decompositions: the ring form (one 512-register wave
     per SIMD owns 32 points and all output tiles, weights shared through an LDS-DMA ring) and the tile-split form (the default: output
     tiles split over the waves, activations shared through LDS, weights L2 -> VGPR, two workgroups per CU; csrc/dpn_fwd_tiles.h).  Both run
@@ -1050,7 +1051,7 @@ def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n):
     import ctypes
     from deepphysinet_amd import _lib as L, point_path as PP
     inp = synthetic_inputs(n, tag='inter')
-    m = _model('bf16x2')
+    m = _model(prec)                                          # plain bf16 defaults to the ring kernels; its tile-split instantiation is pinned here too
     g = _gpu(inp)
     cfg = m.point_config()
     lib = L.load()
