@@ -440,9 +440,9 @@ def main():
                 'algorithmic_bytes': args.points * 136,          # 40 B in + 96 B out per point: the kernel is MFMA-bound
                 'executed_mfma_tflops': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / 1e12,
                 'executed_mfma_frac_of_peak': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / MFMA_PEAK_BF16}
-        # operands of the four products per point per net, each read once: M2 (0/1 bf16, one plane: 512 B) + Z, V + Z1, V + G6, T1 + Z0
-        # = 512 + 3328 B of bf16 (the 3328 x2 in the hi+lo mode)
-        w_bytes = ws.sizes.n_pad * 6 * (512 + 3328 * ns)
+        # operands of the four products per point per net: M2 (0/1 bf16, one plane: 512 B) + Z, M2 + Z1, M2 + G6, T1 + Z0
+        # = 3 x 512 + 2304 B of bf16 (the 2304 x2 in the hi+lo mode); v is not an operand any more (affine in m2: csrc SavedView)
+        w_bytes = ws.sizes.n_pad * 6 * (3 * 512 + 2304 * ns)
         roof_hbm = {'bound': 'hbm', 'kernel': 'dpn_wgrad_kernel<%d>' % ns,
                     'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': w_bytes / (w_ms * 1e-3) / HBM_PEAK, 'kernel_ms': w_ms, 'algorithmic_bytes': w_bytes,

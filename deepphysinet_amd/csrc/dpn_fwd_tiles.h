@@ -176,6 +176,13 @@ DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>
         __builtin_amdgcn_s_setprio(0);
 #endif
         side(ks);
+#ifndef TS_NO_KSTEP_PIN
+        // k-steps stay k-steps: the MFMAs are pure values without a position of their own, and instruction selection is free to emit all of a
+        // layer's 144-192 of them AFTER the fragment loads of all its k-steps (seen after an unrelated change four layers later: 204 spilled
+        // registers in the first layer's loop, every load followed by s_waitcnt vmcnt(0) + a scratch store, 628 us instead of 478).  The empty
+        // volatile statement gives the accumulators a place in the order of the loads' running offsets (WSrc::next), which are volatile too.
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#endif
     }
 #if TS_PRIO == 2
     __builtin_amdgcn_s_setprio(1);
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         }
     }
     if (!save && !a.jac_n) return;
-    // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> X (+ saved V)
+    // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> X (v is not saved: SavedView)
     init_all(kVecWo, 2.0f);
     TS_STAMP(18);
 #if TS_DEFER_SAVES
@@ -599,9 +606,6 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, acc[t][p][r], acc[t][p][r + 1]);
-#if !TS_DEFER_SAVES
-            if (save) ts::save_tile_k<NS, NS>(sv.V, net, tile0 + p, 2 * w + t, lane, I, zero_rows[p], F[t][p][0], F[t][p][1]);
-#endif
         }
     TS_STAMP(20);
     ts::barrier_lds();
@@ -622,14 +626,7 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
                 ts::save_plane_k(m, net, NS, s_, tile0 + (tp & 1), 2 * w + (tp >> 1), lane, I, zero_rows[tp & 1], F[tp >> 1][tp & 1][0].w[s_], F[tp >> 1][tp & 1][1].w[s_]);
         }
     };
-#if TS_DEFER_SAVES
-    {
-        auto side = [&](const int ks) __attribute__((always_inline)) { side_planes(sv.V, ks); };
-        ts::gemm<NS, 16, 2, false>(chunk(kS4 + 2 * w * 16), xl, lane, H, acc, side);
-    }
-#else
     ts::gemm<NS, 16, 2>(chunk(kS4 + 2 * w * 16), xl, lane, H, acc);
-#endif
     TS_STAMP(23);
     if (a.jac_n && w < 3) ts::gemm_head<NS, 16, 2>(chunk(kS5 + 2 * w * 16), lane, H);
 #pragma unroll

@@ -559,22 +559,26 @@ DEV void store_tile_k(const KMat& m, int net, int64_t tile32, int ct, const Lane
 
 // saved-state / operand addressing ---------------------------------------------------------------------------
 struct SavedView {       // written by dpn_fwd
-    KMat V, T1;          // [6][NS] x 256 columns
+    KMat T1;             // [6][NS] x 256 columns: t1 = m1 (.) (w2^T v), the cotangent in front of the first ReLU
     KMat M2;             // [6][1]  x 256 columns, relu-2 mask as bf16 0/1
     uint4* m1;           // [6][tiles32][64] lane-format bits of relu mask 1
 };
+// v = d out / d c is NOT saved: it is affine in the second mask, v = W1^T (m2 (.) u) + 2 wo (W1 = cat_fc1.fc.0.weight, u = fc.2.weight^T wo),
+// so the two weight-gradient products it entered factor through the 0/1 matrix that is saved anyway,
+//   sum_pt v (x) z1 = W1^T diag(u) (M2^T Z1) + 2 wo (x) colsum(Z1)      (likewise with G6),
+// -- one 512-byte mask row per point and net instead of a 1-KB hi+lo row written once and read twice, two MFMAs per fragment pair instead
+// of three, and the 256 x 256 factor applied once per net in fp32 (dpn_finish_vside_kernel) instead of once per point in split bf16.
 DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
     SavedView s;
     char* b = reinterpret_cast<char*>(base);
     const int64_t mat = (int64_t)kNets * ns * n_pad * 512;
     const int64_t tiles32 = n_pad / 32;
-    s.V = KMat{b, tiles32, 8};
-    s.T1 = KMat{b + mat, tiles32, 8};
-    s.M2 = KMat{b + 2 * mat, tiles32, 8};
-    s.m1 = reinterpret_cast<uint4*>(b + 2 * mat + (int64_t)kNets * n_pad * 512);
+    s.T1 = KMat{b, tiles32, 8};
+    s.M2 = KMat{b + mat, tiles32, 8};
+    s.m1 = reinterpret_cast<uint4*>(b + mat + (int64_t)kNets * n_pad * 512);
     return s;
 }
-DPN_HD int64_t saved_state_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 512 + (int64_t)kNets * n_pad * 32; }
+DPN_HD int64_t saved_state_bytes(int64_t n_pad, int ns) { return (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 512 + (int64_t)kNets * n_pad * 32; }
 // the saved state is followed by the positional features of the tile-split forward kernel (dpn_fwd_tiles.h: per 64 points the pe3 and pe6
 // fragment images and the d pe3 / d xi table, evaluated once per point instead of once per point and net)
 DPN_HD int64_t feature_bytes(int64_t n_pad, int ns) { return (n_pad / 64) * (int64_t)(2 * 12 * 2 * ns * 1024 + 3 * 2 * 2 * 64 * 64); }
@@ -801,11 +805,10 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     }
     if (save) sv.m1[((int64_t)net * (a.n_pad / 32) + tile32) * 64 + L.lane] = make_uint4(m1w[0], m1w[1], m1w[2], m1w[3]);
     if (!save && !a.jac_n) { pipe.drain(); return; }
-    // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> actB (+ saved V)
+    // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> actB (not saved: SavedView)
     auto epiv = [&](const int T) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) frag_set2<NS>(actB[2 * T + (r >> 3)], (r & 7) >> 1, acc[T][r], acc[T][r + 1]);
-        if (save) store_tile_k<NS, NS>(sv.V, net, tile32, T, L, actB[2 * T], actB[2 * T + 1], partial);
     };
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
@@ -1173,17 +1176,17 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 #if DPN_HAS_REST
 // ------------------------------------------------------------------------------------------------ backward, stage 2
 // Points-reduction GEMMs  D[so][si] = sum_pt X[pt][so] * Y[pt][si]  for the four products of a net:
-//   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q = Z^T 1
-//   P1: dw2  = V^T  Z1   (256x256)  + gcvec = V^T g, sum g
-//   P2: dWd  = V^T  G6   (256x192)
+//   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q  = Z^T 1
+//   P1: S1   = M2^T Z1   (256x256)  + mv1  = M2^T g, q1 = Z1^T 1, sum g      dw2 = W1^T diag(u) S1 + 2 wo (x) q1   (dpn_finish_vside_kernel;
+//   P2: S2   = M2^T G6   (256x192)  +                q6 = G6^T 1             dWd = W1^T diag(u) S2 + 2 wo (x) q6    v is affine in m2: SavedView)
 //   P3: dw1  = T1^T Z0   (256x192)  + db1 = T1^T g
 // grid = (sum of the four products' point-range counts, 6 nets): each workgroup owns the whole output of its product for its range of
 // 32-point tiles (SplitPlan below says how many ranges each product is cut into) and writes one partial sum per range;
 // dpn_finish_* add the ranges in a fixed order.  Operands are already MFMA fragments in global memory (K-layout, written by
 // dpn_fwd / dpn_bwd_points), so a tile travels global -> LDS as a plain byte image.
-constexpr int kPartFloats = 65536 * 2 + 49152 * 2 + 5 * 256;       // per (split, net)
+constexpr int kPartFloats = 65536 * 2 + 49152 * 2 + 7 * 256;       // per (split, net)
 DPN_HD int part_off(int prod) { return prod == 0 ? 0 : prod == 1 ? 65536 : prod == 2 ? 131072 : 180224; }
-constexpr int kPartVec = 229376;                                    // mvec, q, gcvec, db1, [sum g]
+constexpr int kPartVec = 229376;                                    // mvec, q, mv1, db1, [sum g], q1, q6
 
 struct WgradArgs {
     int64_t n, n_pad;
@@ -1207,18 +1210,41 @@ struct WgradArgs {
 // registers) into a ring of RING slots, RING-1 tiles ahead; every operand byte is fetched from HBM exactly once per product.
 // Synchronisation per tile: counted s_waitcnt vmcnt (this wave's pieces of the tile have landed) + one raw s_barrier (all
 // pieces have landed AND everybody is done with the slot that is refilled next).
+//
+// The body is compiled once per product (WgradShape): the slot holds exactly that product's planes -- X: one plane for the 0/1 mask,
+// NS for T1; Y: NS planes of 8 or 6 column tiles -- so every wave issues the same number of 1-KB pieces per tile without dummy loads
+// (48 / 48 / 40 / 56 pieces in the hi+lo mode: 6 / 6 / 5 / 7 per wave), and the ring is as deep as 160 KB of LDS allow for THAT slot:
+// three slots for the mask products in the hi+lo mode where the common 66-KB slot allowed two.  The kernel's time per tile is the
+// latency of a tile's loads under load, not its bytes (measured: halving a product's bytes with the ring depth unchanged changed
+// nothing), so the number of tiles in flight is what counts.
+template <int NS, int PROD>
+struct WgradShape {
+    static constexpr int nct = PROD < 2 ? 8 : 6;                        // column tiles of Y (Z, Z1: 256 columns; G6, Z0: 192)
+    static constexpr int nsx = PROD == 3 ? NS : 1;                      // planes of X (the mask has no lo part)
+    static constexpr int kX = nsx * 16384, kYPlane = nct * 2048, kY = NS * kYPlane;
+    static constexpr int kPieces = (kX + kY) / 1024;
+    static constexpr int kIssue = (kPieces + 7) / 8;                    // 1-KB pieces per wave per tile; if they do not divide (single bf16, 192 columns:
+    static constexpr int kPad = kIssue * 8 - kPieces;                   // 28 pieces), the last waves re-read one fixed kilobyte into a dummy area
+    static constexpr int kSlot = kX + kY + 8 * 256 + (kPad ? 1024 : 0); // + 8 per-wave copies of g[64]
+    static constexpr int PER_TILE = kIssue + 1;                         // DMA instructions per wave per tile
+    static constexpr int RING = (160 * 1024) / kSlot < 5 ? (160 * 1024) / kSlot : 5;
+};
 template <int NS>
-__global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
-    constexpr int kSlot = NS * 32768 + 8 * 256;                        // X: NS x 16 KB | Y: NS x 16 KB | 8 per-wave copies of g[64]
-    constexpr int RING = (NS == 1) ? 4 : 2;
-    constexpr int PER_TILE = NS * 4 + 1;                               // DMA instructions per wave per tile
-    __shared__ __attribute__((aligned(16))) char lds[RING * kSlot];
-    int prod = 0, split = blockIdx.x;                                   // workgroup -> (product, point range): uniform scalar walk
-    while (prod < 3 && split >= a.splits[prod]) { split -= a.splits[prod]; ++prod; }
+constexpr int wgrad_lds_bytes() {
+    int m = 0;
+    const int v[4] = {WgradShape<NS, 0>::RING * WgradShape<NS, 0>::kSlot, WgradShape<NS, 1>::RING * WgradShape<NS, 1>::kSlot,
+                      WgradShape<NS, 2>::RING * WgradShape<NS, 2>::kSlot, WgradShape<NS, 3>::RING * WgradShape<NS, 3>::kSlot};
+    for (int k = 0; k < 4; ++k) m = v[k] > m ? v[k] : m;
+    return m;
+}
+
+template <int NS, int PROD>
+DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
+    using S = WgradShape<NS, PROD>;
+    constexpr int nct = S::nct, nsx = S::nsx, kSlot = S::kSlot, RING = S::RING, PER_TILE = S::PER_TILE, ncol = nct * 32;
     const int net = blockIdx.y;
-    const int ncol = prod < 2 ? 256 : 192, nct = ncol / 32;
     const int64_t tiles = a.n_pad / 32;
-    const int64_t per = (tiles + a.splits[prod] - 1) / a.splits[prod];
+    const int64_t per = (tiles + a.splits[PROD] - 1) / a.splits[PROD];
     const int64_t t0 = (int64_t)split * per;
     int64_t t1 = t0 + per < tiles ? t0 + per : tiles;
     if (t1 < t0) t1 = t0;
@@ -1229,37 +1255,35 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     const bool active = wn * 2 < nct;                                   // 192-column products leave the wn = 3 waves idle
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
-    const char* xb = (prod == 0) ? sv.M2.base : (prod == 3) ? sv.T1.base : sv.V.base;           // 8 column tiles
-    const char* yb = (prod == 0) ? ov.Z.base : (prod == 1) ? ov.Z1.base : (prod == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
-    const int nsx = (prod == 0) ? 1 : NS;                               // the 0/1 mask has no lo part
+    const char* xb = (PROD == 3) ? sv.T1.base : sv.M2.base;                                      // 8 column tiles
+    const char* yb = (PROD == 0) ? ov.Z.base : (PROD == 1) ? ov.Z1.base : (PROD == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
     const float* gnet = ov.gnet + (int64_t)net * a.n_pad;
-    const int xbytes = 16384, ybytes = nct * 2048;
 
-    // every wave issues PER_TILE DMA instructions per tile: piece q = wave + 8*j of the (X s=0.., Y s=0..) image, + its own g copy.
-    // Pieces beyond the image (192-column Y, mask without lo part) re-read a valid piece into a dummy LDS area (uniform count).
+    // every wave issues PER_TILE DMA instructions per tile: piece q = wave + 8*j of the (X planes, Y planes) image, + its own g copy.
     // (Letting only the four waves with wm == tile & 1 issue a tile -- twice the pieces each, in the shadow of their SIMD partners'
     //  MFMAs -- was measured: the issue phase shrinks from 1 900 to 1 100 cycles per tile and the barrier wait grows by as much,
-    //  360 us against 364 us in the hi+lo mode: at 4.8 TB/s the kernel sits on the HBM stream, not on its issue slots.  Not kept.)
+    //  360 us against 364 us in the hi+lo mode.  Not kept.)
+    // piece q = wave + 8 j of the slot image: where it comes from (address of tile 0, bytes per tile) and where it goes -- worked out once,
+    // so that issuing a tile is straight-line code
+    const char* pbase[S::kIssue];
+    int pstride[S::kIssue], pdst[S::kIssue];
+#pragma unroll
+    for (int j = 0; j < S::kIssue; ++j) {
+        const int q = wave + 8 * j;
+        if (S::kPad && q >= S::kPieces) {                               // a cache hit after the first time
+            pbase[j] = xb + ((int64_t)net * nsx * tiles + (t0 < tiles ? t0 : 0)) * 16384; pstride[j] = 0; pdst[j] = S::kX + S::kY + 8 * 256;
+        } else if (q < nsx * 16) {
+            pbase[j] = xb + ((int64_t)net * nsx + q / 16) * tiles * 16384 + (q % 16) * 1024; pstride[j] = 16384; pdst[j] = q * 1024;
+        } else {
+            const int qy = q - nsx * 16;
+            pbase[j] = yb + ((int64_t)net * NS + qy / (2 * nct)) * tiles * S::kYPlane + (qy % (2 * nct)) * 1024; pstride[j] = S::kYPlane; pdst[j] = q * 1024;
+        }
+    }
     auto issue = [&](int64_t tile, int slot) __attribute__((always_inline)) {
         char* sl = lds + slot * kSlot;
 #pragma unroll
-        for (int j = 0; j < NS * 4; ++j) {
-            const int q = wave + 8 * j;                                 // 1-KB piece index in [0, NS*32)
-            const int s2 = q / 32, r = q % 32;                          // split s2; r < 16: X piece r ; r >= 16: Y piece r-16
-            const char* src;
-            char* dst;
-            if (r < 16) {
-                const int sx = s2 < nsx ? s2 : 0;
-                src = xb + (((int64_t)net * nsx + sx) * tiles + tile) * xbytes + r * 1024;
-                dst = sl + s2 * 16384 + r * 1024;
-            } else {
-                const int ry = (r - 16) * 1024 < ybytes ? (r - 16) : 0;
-                src = yb + (((int64_t)net * NS + s2) * tiles + tile) * ybytes + ry * 1024;
-                dst = sl + NS * 16384 + s2 * 16384 + (r - 16) * 1024;
-            }
-            dma16_nt(src + lane * 16, dst);
-        }
-        dma4(reinterpret_cast<const char*>(gnet + tile * 32) + lane * 4, sl + NS * 32768 + wave * 256);
+        for (int j = 0; j < S::kIssue; ++j) dma16_nt(pbase[j] + tile * pstride[j] + lane * 16, sl + pdst[j]);
+        dma4(reinterpret_cast<const char*>(gnet + tile * 32) + lane * 4, sl + S::kX + S::kY + wave * 256);
     };
 
     f32x16 acc[4][2];
@@ -1276,63 +1300,56 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     };
     auto compute = [&](const int slot_) __attribute__((always_inline)) {
         const unsigned buf = lds_base + slot_ * kSlot;
-        const unsigned gl = buf + NS * 32768 + wave * 256;
+        const unsigned gl = buf + S::kX + S::kY + wave * 256;
         constexpr int KB = (NS == 1) ? 2 : 1;                       // single-bf16 fragments: both k-steps of the tile are read up front
-        u32x4 gqa[KB][2], faa[KB][NS][4], fba[KB][NS][2];
+        u32x4 gqa[KB][2], faa[KB][nsx][4], fba[KB][NS][2];
         auto issue_reads = [&](const int kk, const int b) __attribute__((always_inline)) {
             rd128(gqa[b][0], gl + (16 * kk + 4 * h) * 4);
             rd128(gqa[b][1], gl + (16 * kk + 4 * h + 8) * 4);
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) {
+            for (int s2 = 0; s2 < nsx; ++s2)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) rd128(faa[b][s2][m], buf + s2 * 16384 + ((kk * 8 + wm * 4 + m) * 64 + lane) * 16);   // s2 >= nsx: dummy area, unused
+                for (int m = 0; m < 4; ++m) rd128(faa[b][s2][m], buf + s2 * 16384 + ((kk * 8 + wm * 4 + m) * 64 + lane) * 16);
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) rd128(fba[b][s2][n2], buf + NS * 16384 + s2 * 16384 + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
-            }
+            for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) rd128(fba[b][s2][n2], buf + S::kX + s2 * S::kYPlane + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
         };
+        constexpr int kReads = 2 + 4 * nsx + 2 * NS;                // LDS reads per k-step
         if constexpr (NS == 1) { issue_reads(0, 0); issue_reads(1, 1); }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int b = (NS == 1) ? kk : 0;
             if constexpr (NS == 2) issue_reads(kk, 0);
-            u32x4 (&fa)[NS][4] = faa[b];
+            u32x4 (&fa)[nsx][4] = faa[b];
             u32x4 (&fb)[NS][2] = fba[b];
             u32x4& gq0 = gqa[b][0];
             u32x4& gq1 = gqa[b][1];
             // every value passes through the wait, so no use can be scheduled in front of it (LDS reads retire in order: with the
-            // second k-step's eight reads still behind, the first k-step is complete at lgkmcnt(8))
-            if constexpr (NS == 1) {
-                if (kk == 0)
-                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
-                                 "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory");
-                else
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
-                                 "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),
-                             "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),
-                             "+v"(fb[1][0]), "+v"(fb[1][1]) :: "memory");
-            }
+            // second k-step's reads still behind, the first k-step is complete at lgkmcnt(kReads))
+            if (NS == 1 && kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(kReads) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]));
+            if constexpr (NS == 2) asm volatile("" : "+v"(fb[1][0]), "+v"(fb[1][1]));
+            if constexpr (nsx == 2) asm volatile("" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]));
             const float gp[8] = {__uint_as_float(gq0[0]), __uint_as_float(gq0[1]), __uint_as_float(gq0[2]), __uint_as_float(gq0[3]),
                                  __uint_as_float(gq1[0]), __uint_as_float(gq1[1]), __uint_as_float(gq1[2]), __uint_as_float(gq1[3])};
-            if (prod == 1 && wave == 0 && i == 0) {
+            if (PROD == 1 && wave == 0 && i == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gsum += gp[e];
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                if (wn == (nct == 8 ? m : m % 3) && prod != 2) {         // row-side vector: sum_pt X[pt][row] * g[pt]; the four waves that
+                if (wn == (nct == 8 ? m : m % 3) && PROD != 2) {         // row-side vector: sum_pt X[pt][row] * g[pt]; the four waves that
                                                                          // hold this row tile's fragments take one tile each (all on
                                                                          // the wn = 0 waves it made them the workgroup's critical path:
                                                                          // +700 cycles per tile, everybody else waiting at the barrier);
                                                                          // 192-column products: the wn = 3 waves sit idle, three share
                     float d = 0.f;
 #pragma unroll
-                    for (int s2 = 0; s2 < NS; ++s2) {
-                        if (s2 < nsx) {
+                    for (int s2 = 0; s2 < nsx; ++s2) {
 #pragma unroll
-                            for (int p = 0; p < 4; ++p) { d = fmaf(bf_lo(fa[s2][m][p]), gp[2 * p], d); d = fmaf(bf_hi(fa[s2][m][p]), gp[2 * p + 1], d); }
-                        }
+                        for (int p = 0; p < 4; ++p) { d = fmaf(bf_lo(fa[s2][m][p]), gp[2 * p], d); d = fmaf(bf_hi(fa[s2][m][p]), gp[2 * p + 1], d); }
                     }
                     vecA[m] += d;
                 }
@@ -1340,12 +1357,12 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
                 for (int n2 = 0; n2 < 2; ++n2) {
                     if constexpr (NS == 2) {
                         acc[m][n2] = mfma(as_bf(fa[0][m]), as_bf(fb[1][n2]), acc[m][n2]);
-                        if (nsx == 2) acc[m][n2] = mfma(as_bf(fa[1][m]), as_bf(fb[0][n2]), acc[m][n2]);
+                        if constexpr (nsx == 2) acc[m][n2] = mfma(as_bf(fa[1][m]), as_bf(fb[0][n2]), acc[m][n2]);
                     }
                     acc[m][n2] = mfma(as_bf(fa[0][m]), as_bf(fb[0][n2]), acc[m][n2]);
                 }
             }
-            if (prod == 0) {                                             // column-side vector: q = sum_pt Z[pt][col], one column tile per wm
+            if (PROD != 3) {                                             // column-side vector: q = sum_pt Y[pt][col] (Z, Z1, G6), one column tile per wm
 #pragma unroll
                 for (int n2 = 0; n2 < 2; ++n2) {
                     if (wm != n2) continue;
@@ -1389,14 +1406,14 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
 #ifdef DPN_WGRAD_PHASES
     if (a.phases && lane == 0) {
         unsigned* o = a.phases + (((int64_t)net * gridDim.x + blockIdx.x) * 8 + wave) * 8;
-        o[0] = ph_wait; o[1] = ph_bar; o[2] = ph_issue; o[3] = ph_comp; o[4] = (unsigned)(t1 - t0); o[5] = prod;
+        o[0] = ph_wait; o[1] = ph_bar; o[2] = ph_issue; o[3] = ph_comp; o[4] = (unsigned)(t1 - t0); o[5] = PROD;
     }
 #endif
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     // ---- write this split's partial sums: natural [row slot][col] order
     float* part = a.partials + ((int64_t)split * kNets + net) * kPartFloats;
-    float* out = part + part_off(prod);
+    float* out = part + part_off(PROD);
     if (active) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -1414,22 +1431,34 @@ __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
         const float v = vecA[m] + __shfl_xor(vecA[m], 32);
         if (wn == (nct == 8 ? m : m % 3) && h == 0) {
             const int rr = wm * 128 + 32 * m + i;
-            if (prod == 0) part[kPartVec + 0 * 256 + rr] = v;          // mvec
-            if (prod == 1) part[kPartVec + 2 * 256 + rr] = v;          // gcvec
-            if (prod == 3) part[kPartVec + 3 * 256 + rr] = v;          // db1
+            if (PROD == 0) part[kPartVec + 0 * 256 + rr] = v;          // mvec
+            if (PROD == 1) part[kPartVec + 2 * 256 + rr] = v;          // mv1 (= mvec again: the hyper-network's half of the reduction does not wait for P0)
+            if (PROD == 3) part[kPartVec + 3 * 256 + rr] = v;          // db1
         }
     }
-    if (prod == 1 && wave == 0) {
+    if (PROD == 1 && wave == 0) {
         const float gs = gsum + __shfl_xor(gsum, 32);                  // lanes 0 and 32 hold the two halves
         if (lane == 0) part[kPartVec + 4 * 256] = gs;
     }
-    if (prod == 0) {
+    if (PROD != 3 && active) {
+        const int qo = kPartVec + (PROD == 0 ? 1 : PROD == 1 ? 5 : 6) * 256;             // q = colsum(Z), q1 = colsum(Z1), q6 = colsum(G6)
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
             const float v = vecB[n2] + __shfl_xor(vecB[n2], 32);
-            if (wm == n2 && h == 0) part[kPartVec + 1 * 256 + wn * 64 + 32 * n2 + i] = v;   // q = colsum(Z)
+            if (wm == n2 && h == 0) part[qo + wn * 64 + 32 * n2 + i] = v;
         }
     }
+}
+
+template <int NS>
+__global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[wgrad_lds_bytes<NS>()];
+    int prod = 0, split = blockIdx.x;                                   // workgroup -> (product, point range): uniform scalar walk
+    while (prod < 3 && split >= a.splits[prod]) { split -= a.splits[prod]; ++prod; }
+    if (prod == 0) wgrad_body<NS, 0>(a, lds, split);
+    else if (prod == 1) wgrad_body<NS, 1>(a, lds, split);
+    else if (prod == 2) wgrad_body<NS, 2>(a, lds, split);
+    else wgrad_body<NS, 3>(a, lds, split);
 }
 
 // ------------------------------------------------------------------------------------------------ backward, stage 3
@@ -1438,11 +1467,12 @@ struct FinishArgs {
     DpnNetGradPtrs grad[kNets];
     const char* packed;
     const float* partials;
-    float* scratch_r;       // [6][256] r vector (lives in the partials buffer tail)
+    float* scratch_r;       // [6][256] r vector (lives in the partials buffer tail, like the three below)
+    float* scratch_s1;      // [6][256][256] diag(u) M2^T Z1, natural order          (dpn_finish_rows_kernel -> dpn_finish_vside_kernel)
+    float* scratch_s2;      // [6][256][192] diag(u) M2^T G6
+    float* scratch_mv;      // [6][256]      diag(u) M2^T g
     int splits[4], ns;      // point ranges per product, as dpn_wgrad_kernel cut them
     int64_t n;
-    int phase;              // 0: everything; 1: what the hyper-network's backward needs (d w1b1, d w2b2, d evec: products 1 and 3);
-                            // 2: the static tensors' gradients (products 0 and 2, the rank-1 fc.2 part) -- dpn_wgrad_part / _finish_part
 };
 
 DEV int slot_of_ch(int ch) { return (ch & ~15) + 8 * ((ch >> 2) & 1) + 4 * ((ch >> 3) & 1) + (ch & 3); }
@@ -1464,7 +1494,7 @@ DEV int slot_of_pe6(int orig) {
 // loads in flight at once (a loop of load -> wait -> add, which is what hipcc makes of the obvious code, costs one HBM round trip per
 // range and per sum: 40 in a row per thread).  Ranges beyond ks[q] re-read the last one and are not added; the additions keep the
 // range order, so the result does not depend on how the loads are grouped.
-constexpr int kMaxSplits = 24;                  // choose_plan() / part_plan() never return more for one product
+constexpr int kMaxSplits = 16;                  // choose_plan() never returns more for one product
 template <int NQ, int MAXS>
 DEV void part_sums_n(const float* partials, const int (&ks)[NQ], int net, const int (&off)[NQ], float (&out)[NQ]) {
     float v[MAXS][NQ];
@@ -1487,11 +1517,11 @@ DEV void part_sums(const float* partials, const int (&ks)[NQ], int net, const in
     int most = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) most = ks[q] > most ? ks[q] : most;
-    if (most <= 12) part_sums_n<NQ, 12>(partials, ks, net, off, out);       // the one-launch plan (choose_plan): at most 11 ranges per product
-    else part_sums_n<NQ, kMaxSplits>(partials, ks, net, off, out);          // the two-part plan (part_plan)
+    if (most <= 12) part_sums_n<NQ, 12>(partials, ks, net, off, out);       // single bf16: at most 11 ranges per product
+    else part_sums_n<NQ, kMaxSplits>(partials, ks, net, off, out);          // hi+lo: 13 for dw1
 }
 
-// one block per (output row o, net): reduces the splits, un-permutes, writes dW1, d(w2b2), d(w1b1), dWd rows and r[o]
+// one block per (output row o, net): reduces the splits, un-permutes, writes dW1, d(w1b1) rows, r[o] and row o of the two mask-side sums
 __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
     const int o = blockIdx.x, net = blockIdx.y, i = threadIdx.x;
     const DpnNetPtrs& P = a.net[net];
@@ -1502,75 +1532,94 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
     const float* vec = reinterpret_cast<const float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
     const int T = o >> 5, w = o & 31, hh = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);
     const float uo = vec[kVecU * 256 + hh * 128 + T * 16 + r];
-    const bool heads = a.phase != 2, stat = a.phase != 1;
     // thread 0 also owns the row's three vector entries: fetched with everything else, not after the reduction
     float rowv[3] = {0.f, 0.f, 0.f};
     if (i == 0) {
         const int offv[3] = {kPartVec + 0 * 256 + so, kPartVec + 2 * 256 + so, kPartVec + 3 * 256 + so};     // written by products 0, 1, 3
-        const int ksv[3] = {stat ? a.splits[0] : 1, a.splits[1], heads ? a.splits[3] : 1};
+        const int ksv[3] = {a.splits[0], a.splits[1], a.splits[3]};
         part_sums<3>(a.partials, ksv, net, offv, rowv);
     }
-    float Goi = 0.f;
-    if (a.phase == 0) {
-        const int off2[2] = {part_off(0) + so * 256 + i, part_off(1) + so * 256 + si};      // Z's columns are in natural order (SWAP output)
-        float g2[2];
-        const int ks2[2] = {a.splits[0], a.splits[1]};
-        part_sums<2>(a.partials, ks2, net, off2, g2);
-        Goi = g2[0];
-        Gd.w2b2[o * Gd.ld_w2b2 + i] = g2[1];
-    } else if (heads) {
-        const int off1[1] = {part_off(1) + so * 256 + si};
-        float g1[1];
-        const int ks1[1] = {a.splits[1]};
-        part_sums<1>(a.partials, ks1, net, off1, g1);
-        Gd.w2b2[o * Gd.ld_w2b2 + i] = g1[0];
-    } else {
-        const int off0[1] = {part_off(0) + so * 256 + i};
-        float g0[1];
-        const int ks0[1] = {a.splits[0]};
-        part_sums<1>(a.partials, ks0, net, off0, g0);
-        Goi = g0[0];
-    }
-    if (stat) {
-        Gd.W1[o * 256 + i] = uo * Goi;
-        red[i] = P.W1[o * 256 + i] * Goi;
-    }
+    const int off2[2] = {part_off(0) + so * 256 + i, part_off(1) + so * 256 + si};      // Z's columns are in natural order (SWAP output)
+    float g2[2];
+    const int ks2[2] = {a.splits[0], a.splits[1]};
+    part_sums<2>(a.partials, ks2, net, off2, g2);
+    const float Goi = g2[0];
+    a.scratch_s1[((int64_t)net * 256 + o) * 256 + i] = uo * g2[1];
+    Gd.W1[o * 256 + i] = uo * Goi;
+    red[i] = P.W1[o * 256 + i] * Goi;
     if (i < kPe) {
-        if (a.phase == 0) {
-            const int offp[2] = {part_off(2) + so * 192 + slot_of_pe6(i), part_off(3) + so * 192 + slot_of_pe3(i)};
-            float gp[2];
-            const int ksp[2] = {a.splits[2], a.splits[3]};
-            part_sums<2>(a.partials, ksp, net, offp, gp);
-            Gd.Wd[o * kPe + i] = gp[0];
-            Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[1];
-        } else {
-            const int offp[1] = {heads ? part_off(3) + so * 192 + slot_of_pe3(i) : part_off(2) + so * 192 + slot_of_pe6(i)};
-            float gp[1];
-            const int ksp[1] = {heads ? a.splits[3] : a.splits[2]};
-            part_sums<1>(a.partials, ksp, net, offp, gp);
-            if (heads) Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[0];
-            else Gd.Wd[o * kPe + i] = gp[0];
-        }
+        const int offp[2] = {part_off(2) + so * 192 + slot_of_pe6(i), part_off(3) + so * 192 + slot_of_pe3(i)};
+        float gp[2];
+        const int ksp[2] = {a.splits[2], a.splits[3]};
+        part_sums<2>(a.partials, ksp, net, offp, gp);
+        a.scratch_s2[((int64_t)net * 256 + o) * kPe + i] = uo * gp[0];
+        Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[1];
     }
-    if (stat) {
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (i < s) red[i] += red[i + s];
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (i < s) red[i] += red[i + s];
-            __syncthreads();
-        }
     }
     if (i == 0) {
-        const float mvec = rowv[0], gcv = rowv[1], db1 = rowv[2];
-        if (stat) {
-            a.scratch_r[net * 256 + o] = red[0] + P.bf1[o] * mvec;
-            Gd.bf1[o] = uo * mvec;
-            Gd.bd[o] = gcv;
-        }
-        if (heads) {
-            Gd.w2b2[o * Gd.ld_w2b2 + 256] = gcv;
-            Gd.w1b1[o * Gd.ld_w1b1 + 192] = db1;
-            Gd.evec[o] = gcv;
-        }
+        const float mvec = rowv[0], mv1 = rowv[1], db1 = rowv[2];
+        a.scratch_mv[net * 256 + o] = uo * mv1;
+        a.scratch_r[net * 256 + o] = red[0] + P.bf1[o] * mvec;
+        Gd.bf1[o] = uo * mvec;
+        Gd.w1b1[o * Gd.ld_w1b1 + 192] = db1;
+    }
+}
+
+// The factor that turns the mask-side sums into the gradients that used to need v per point (SavedView):
+//   d(w2b2)[o][i] = sum_j W1[j][o] S1[j][i] + 2 wo[o] q1[i]        S1 = diag(u) M2^T Z1   (i < 256),  column 256: S1 -> diag(u) M2^T g, q1 -> sum g
+//   dWd[o][i]     = sum_j W1[j][o] S2[j][i] + 2 wo[o] q6[i]        S2 = diag(u) M2^T G6
+// and d evec = d bd = column 256.  One workgroup per 32 x 32 output tile: grid (8 row tiles x 15 column tiles [8 of d w2, the vector, 6 of
+// dWd], 6 nets); the four waves take 64 of the 256 j each on the exact-fp32 matrix instruction (operands straight from global memory: both
+// are contiguous along the lane index) and their partial tiles are added in a fixed order through LDS.
+DEV f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__global__ __launch_bounds__(256) void dpn_finish_vside_kernel(FinishArgs a) {
+    const int rt = blockIdx.x & 7, ctile = blockIdx.x >> 3, net = blockIdx.y;
+    const int kind = ctile < 8 ? 0 : ctile == 8 ? 1 : 2;                  // d w2 | vector column | dWd
+    const DpnNetPtrs& P = a.net[net];
+    const DpnNetGradPtrs& Gd = a.grad[net];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, kh = lane >> 5;
+    const int o0 = 32 * rt, n0 = kind == 0 ? 32 * ctile : kind == 2 ? 32 * (ctile - 9) : 0, ncol = kind == 0 ? 256 : kind == 2 ? kPe : 1;
+    const float* B = kind == 0 ? a.scratch_s1 + (int64_t)net * 65536 : kind == 2 ? a.scratch_s2 + (int64_t)net * 256 * kPe : a.scratch_mv + net * 256;
+    const int ldb = ncol;
+    const bool colok = n0 + col < ncol;
+    // the rank-one term's column factor: q1 / q6 / sum g over the point ranges (loads in flight under the products)
+    float qv[1] = {0.f};
+    if (wv == 0 && colok) {
+        const int i = n0 + col;
+        const int offq[1] = {kind == 0 ? kPartVec + 5 * 256 + slot_of_ch(i) : kind == 2 ? kPartVec + 6 * 256 + slot_of_pe6(i) : kPartVec + 4 * 256};
+        const int ksq[1] = {kind == 2 ? a.splits[2] : a.splits[1]};
+        part_sums<1>(a.partials, ksq, net, offq, qv);
+    }
+    f32x16 acc = (f32x16)0.f;
+    float av[32], bv[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        const int j = 64 * wv + 2 * kk + kh;
+        av[kk] = P.W1[j * 256 + o0 + col];
+        bv[kk] = colok ? B[(int64_t)j * ldb + n0 + col] : 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) acc = mfma_f32_32x32x2(av[kk], bv[kk], acc);
+    __shared__ float red[4][16][64];
+    __shared__ float qs[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv][r][lane] = acc[r];
+    if (wv == 0 && kh == 0) qs[col] = qv[0];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wv + 4 * q;                                         // element (r, lane) of the tile: row drow32(r, kh), column col
+        const float sum = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+        const int o = o0 + drow32(r, kh), i = n0 + col;
+        if (!colok) continue;
+        const float v = sum + 2.0f * P.wo[o] * qs[col];
+        if (kind == 0) Gd.w2b2[o * Gd.ld_w2b2 + i] = v;
+        else if (kind == 2) Gd.Wd[o * kPe + i] = v;
+        else { Gd.w2b2[o * Gd.ld_w2b2 + 256] = v; Gd.evec[o] = v; Gd.bd[o] = v; }
     }
 }
 
@@ -2181,16 +2230,16 @@ static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 #if DPN_HAS_REST
 // Point ranges per product.  One 8-wave workgroup per CU (the LDS ring fills it) and a kernel time that falls as 1 / workgroups up to
 // one round (measured, hi+lo mode, 37 265 points: 120 workgroups 671 us, 192 452 us, 240 396 us, 288 562 us -- the tail round), so
-// the plan fills one round of the 256 CUs: 42 workgroups per net, the two extra ranges going to the products that measured slowest
-// (dw2 = V^T Z1 and dw1 = T1^T Z0 in the hi+lo mode).  A cut in proportion to the bytes per tile (9 / 12 / 10 / 11) measured WORSE
-// than uniform: the time of a workgroup follows its number of tiles, not its bytes.  Uniform 10 x 4: 377 us, this plan 364 us
-// (hi+lo); 170 us against 168 us (single bf16) -- tools/wgrad_overlap_probe.py.
+// the plan fills one round of the 256 CUs: 42 workgroups per net.  Hi+lo mode: dw1 = T1^T Z0 is the one product whose slot (two X planes)
+// leaves room for a ring of two only, so its tiles take longest and it gets the most ranges; measured (tools/wgrad_overlap_probe.py,
+// profiles/round3_wgrad_plans.txt): 10,11,10,11 327 us, 11,11,9,11 303 us, 10,10,9,13 277 us, 10,10,8,14 277 us, 9,9,8,16 280 us --
+// a plateau at 5.0 TB/s.  Single bf16 (rings of four and five): 10,11,10,11 156 us, 10,10,9,13 160-163 us.
 struct SplitPlan { int s[4]; int most; };
 static inline SplitPlan choose_plan(int64_t n_pad, int ns) {
     int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
     SplitPlan p;
-    if (c >= 10) p = (ns == 2) ? SplitPlan{{10, 11, 10, 11}, 11} : SplitPlan{{11, 11, 10, 10}, 11};
+    if (c >= 10) p = (ns == 2) ? SplitPlan{{10, 10, 9, 13}, 13} : SplitPlan{{10, 11, 10, 11}, 11};
     else p = SplitPlan{{(int)c, (int)c, (int)c, (int)c}, (int)c};
 #ifdef DPN_EXPERIMENT_SPLITS                     // timing experiments only: DPN_WGRAD_PLAN="9,12,10,11"
     if (const char* e = getenv("DPN_WGRAD_PLAN")) {
@@ -2203,22 +2252,7 @@ static inline SplitPlan choose_plan(int64_t n_pad, int ns) {
     return p;
 }
 #endif  // DPN_HAS_REST
-#if DPN_HAS_REST
-// Two-part weight-gradient reduction (dpn_wgrad_part): part 1 = the products the hyper-network's backward waits for (dw2 = V^T Z1,
-// dw1 = T1^T Z0) cut into TWICE as many point ranges, so that they fill the chip on their own (252 workgroups, half the tiles each);
-// part 2 = the products that end in static tensors (G = M2^T Z, dWd = V^T G6) with the usual ranges: 120 workgroups = 120 CUs, which the
-// caller runs on a second stream BESIDE the encoder's backward chain -- a chain of ~35 latency-bound kernels that needs a few dozen free
-// CUs at a time (measured, tools/wgrad_overlap_probe.py: with >= 52 CUs free the two overlap, with all 252 taken they run back to back).
-static inline SplitPlan part_plan(int64_t n_pad, int ns, int part) {
-    const SplitPlan b = choose_plan(n_pad, ns);
-    const int s1 = b.s[1] * 2 - 1 > kMaxSplits ? kMaxSplits : b.s[1] * 2 - 1, s3 = b.s[3] * 2 - 1 > kMaxSplits ? kMaxSplits : b.s[3] * 2 - 1;
-    SplitPlan p;
-    if (part == 1) p = SplitPlan{{0, s1, 0, s3}, s1 > s3 ? s1 : s3};
-    else if (part == 2) p = SplitPlan{{b.s[0], 0, b.s[2], 0}, b.s[0] > b.s[2] ? b.s[0] : b.s[2]};
-    else { p = SplitPlan{{b.s[0], s1, b.s[2], s3}, 0}; for (int k = 0; k < 4; ++k) if (p.s[k] > p.most) p.most = p.s[k]; }
-    return p;
-}
-#endif
+constexpr int64_t kFinishScratchFloats = kNets * 256 + (int64_t)kNets * 65536 + (int64_t)kNets * 256 * 192 + kNets * 256;   // r | S1 | S2 | mv (FinishArgs)
 static inline int ck(hipError_t e) { return (int)e; }
 
 extern "C" {
@@ -2233,8 +2267,8 @@ int dpn_sizes(int64_t n, int prec, DpnSizes* out) {
     out->packed = (int64_t)kNets * pack_bytes_per_net(prec);
     out->saved = saved_bytes(n_pad, prec);
     out->operands = operand_bytes(n_pad, prec);
-    out->k_splits = part_plan(n_pad, prec, 0).most;            // sized for the two-part plan as well (dpn_wgrad_part)
-    out->partials = ((int64_t)out->k_splits * kNets * kPartFloats + kNets * 256) * 4;
+    out->k_splits = choose_plan(n_pad, prec).most;
+    out->partials = ((int64_t)out->k_splits * kNets * kPartFloats + kFinishScratchFloats) * 4;
     return 0;
 }
 
@@ -2371,46 +2405,26 @@ int dpn_wgrad(int64_t n, int prec, const float* g_out, const void* saved, const 
     return ck(hipGetLastError());
 }
 
-static int wgrad_finish_impl(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
-                             const DpnNetGradPtrs grads[DPN_NETS], int part, void* stream) {
-    if (!nets || !packed || !partials || !grads || n <= 0 || (prec != 1 && prec != 2) || part < 0 || part > 2) return -1;
+int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
+                     const DpnNetGradPtrs grads[DPN_NETS], void* stream) {
+    if (!nets || !packed || !partials || !grads || n <= 0 || (prec != 1 && prec != 2)) return -1;
     FinishArgs a;
     for (int k = 0; k < kNets; ++k) { a.net[k] = nets[k]; a.grad[k] = grads[k]; }
     a.packed = reinterpret_cast<const char*>(packed);
     a.partials = reinterpret_cast<const float*>(partials);
-    const SplitPlan plan = part ? part_plan(pad_points(n), prec, 0) : choose_plan(pad_points(n), prec);
+    const SplitPlan plan = choose_plan(pad_points(n), prec);
     for (int k = 0; k < 4; ++k) a.splits[k] = plan.s[k];
     a.ns = prec;
     a.n = n;
-    a.phase = part;
-    // [6][256] r vector in the tail of the partials buffer (which dpn_sizes dimensions for the two-part plan)
-    a.scratch_r = const_cast<float*>(a.partials) + (int64_t)part_plan(pad_points(n), prec, 0).most * kNets * kPartFloats;
+    // scratch in the tail of the partials buffer (dpn_sizes)
+    a.scratch_r = const_cast<float*>(a.partials) + (int64_t)plan.most * kNets * kPartFloats;
+    a.scratch_s1 = a.scratch_r + kNets * 256;
+    a.scratch_s2 = a.scratch_s1 + (int64_t)kNets * 65536;
+    a.scratch_mv = a.scratch_s2 + (int64_t)kNets * 256 * 192;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
-    if (part != 1) hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
-    return ck(hipGetLastError());
-}
-int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
-                     const DpnNetGradPtrs grads[DPN_NETS], void* stream) {
-    return wgrad_finish_impl(nets, packed, n, prec, partials, grads, 0, stream);
-}
-int dpn_wgrad_finish_part(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
-                          const DpnNetGradPtrs grads[DPN_NETS], int part, void* stream) {
-    if (part != 1 && part != 2) return -1;
-    return wgrad_finish_impl(nets, packed, n, prec, partials, grads, part, stream);
-}
-int dpn_wgrad_part(int64_t n, int prec, int part, const void* saved, const void* operands, void* partials, void* stream) {
-    if (!saved || !operands || !partials || n <= 0 || (prec != 1 && prec != 2) || (part != 1 && part != 2)) return -1;
-    const SplitPlan plan = part_plan(pad_points(n), prec, part);
-    WgradArgs a{n, pad_points(n), {plan.s[0], plan.s[1], plan.s[2], plan.s[3]}, const_cast<void*>(saved), const_cast<void*>(operands),
-                reinterpret_cast<float*>(partials)};
-#ifdef DPN_WGRAD_PHASES
-    a.phases = nullptr;
-#endif
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid(plan.s[0] + plan.s[1] + plan.s[2] + plan.s[3], kNets);
-    if (prec == 1) hipLaunchKernelGGL(dpn_wgrad_kernel<1>, grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(dpn_wgrad_kernel<2>, grid, dim3(512), 0, s, a);
+    hipLaunchKernelGGL(dpn_finish_vside_kernel, dim3(8 * 15, kNets), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
     return ck(hipGetLastError());
 }
 

@@ -143,30 +143,12 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     return out_n, jac_n
 
 
-_side_stream = {}
-# Measured experiment, OFF by default (profiles/round3_two_stream_wgrad.txt): the overlap works (graph branches run side by side once more than
-# ~50 CUs are free) but part 2 takes HBM bandwidth from the latency-bound chain kernels beside it (335 -> 440 us) and part 1 costs 195 us against
-# 172 us for half of the one-launch kernel: the step does not get shorter (1.726 ms both ways).
-TWO_STREAM_WGRAD = os.environ.get('DPN_WGRAD_TWO_STREAMS', '0') == '1'
-
-
-def _side(dev):
-    if dev not in _side_stream:
-        # high priority: the side branch must be dispatched the moment its dependency clears, not when the main queue happens to leave a gap
-        _side_stream[dev] = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get('DPN_SIDE_PRIORITY', '1') == '1' else 0)
-    return _side_stream[dev]
-
-
 def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics, into=None):
     """Weight gradients from per-point cotangents.  Returns (g_heads [256,2700], g_evec [6,256], [48 static grads]); `into` = the same
     triple preallocated by the caller (a batch of fields writes each field's gradients side by side).
 
-    Large batches inside an autograd backward pass take the TWO-STREAM form: the products the hyper-network's backward waits for (part 1)
-    run first on all CUs; the static tensors' products (part 2, 120 workgroups) run on a side stream beside the ~35 small kernels of the
-    heads' and the encoder's backward that autograd issues next on the main stream; the main stream joins the side stream in an
-    end-of-backward callback, i.e. before anything can read a static gradient.  Only gradients nobody touches during the backward pass may
-    be produced that way: the 48 static gradients must be fresh slots of the optimiser's flat buffer (grad_arena: autograd then only
-    stores the reference)."""
+    (A two-stream form -- the static tensors' products on a side stream beside the encoder's backward chain -- was built and measured in
+    round 3: no gain, profiles/round3_two_stream_wgrad.txt; removed.)"""
     lib = L.load()
     n = coord_data.shape[0]
     dev = coord_data.device
@@ -190,27 +172,6 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
     else:
         g_heads, g_evec, g_stat = into
     garr = _net_ptrs(g_heads, g_evec, g_stat, cls=L.DpnNetGradPtrs)
-    if TWO_STREAM_WGRAD and arena and n >= 16384:
-        main = torch.cuda.current_stream()
-        side = _side(dev)
-        L.check(lib.dpn_wgrad_part(n, cfg.prec, 1, _ptr(ws.saved), _ptr(operands), _ptr(partials), main.cuda_stream), 'dpn_wgrad_part')
-        side.wait_stream(main)                                   # part 2 starts behind part 1 (which needs every CU)
-        L.check(lib.dpn_wgrad_part(n, cfg.prec, 2, _ptr(ws.saved), _ptr(operands), _ptr(partials), side.cuda_stream), 'dpn_wgrad_part')
-        L.check(lib.dpn_wgrad_finish_part(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, 1, main.cuda_stream), 'dpn_wgrad_finish_part')
-        L.check(lib.dpn_wgrad_finish_part(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, 2, side.cuda_stream), 'dpn_wgrad_finish_part')
-        # alive until the join: the side stream reads / writes them.  NOT the 48 gradient views: autograd steals a returned gradient only while
-        # nobody else holds it (a second reference makes AccumulateGrad copy all 48 -- before the side stream has written them); their memory is
-        # the optimiser's flat buffer
-        keep = (operands, partials, ws, nets, garr)
-
-        def join(keep=keep):
-            torch.cuda.current_stream().wait_stream(side)
-            del keep
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(join)     # runs when this backward pass has issued its last node
-        except RuntimeError:                                     # not inside a backward pass: nothing to overlap with
-            join()
-        return g_heads, g_evec, g_stat
     L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
     L.check(lib.dpn_wgrad_finish(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, _stream()), 'dpn_wgrad_finish')
     return g_heads, g_evec, g_stat
@@ -547,11 +508,11 @@ def relu_masks(cfg: PointConfig, x, y, t, coord_data, heads, evec, statics):
         _forward_points(cfg, ws, _net_ptrs(hd_, ev_, st), x_, y_, t_, None, cd_, want_jac=True, want_saved=True)
         n_pad, ns = int(ws.sizes.n_pad), int(cfg.prec)
         tiles = n_pad // 32
-        mat = 6 * ns * n_pad * 512
+        mat = 6 * ns * n_pad * 512                                                      # T1 (hi, lo planes) | M2 | m1: SavedView
         raw = ws.saved
         # M2: [6][tiles][kk 2][ct 8][lane 64][8 bf16 of 0/1]: register r = 8 kk + e of lane (col jj = lane & 31, h = lane >> 5) is the mask of
         # channel chain_ch(2 ct + (jj >> 4), (jj >> 3) & 1, jj & 7) at point drow32(r, h) of the tile
-        m2_raw = raw[2 * mat:2 * mat + 6 * n_pad * 512].view(torch.int16).view(6, tiles, 2, 8, 64, 8) != 0
+        m2_raw = raw[mat:mat + 6 * n_pad * 512].view(torch.int16).view(6, tiles, 2, 8, 64, 8) != 0
         lane = torch.arange(64, device=dev)
         jj, hh = lane & 31, lane >> 5
         ct = torch.arange(8, device=dev)
@@ -565,7 +526,7 @@ def relu_masks(cfg: PointConfig, x, y, t, coord_data, heads, evec, statics):
         ci = chan[:, :, None].expand(8, 64, 16)
         m2[:, :, pi, ci] = src
         # m1: uint4 per (net, tile, lane): bit 16 (T & 1) + r of word T >> 1 = mask of channel 32 T + drow32(r, h) at point lane & 31
-        m1_raw = raw[2 * mat + 6 * n_pad * 512:2 * mat + 6 * n_pad * 512 + 6 * n_pad * 32].view(torch.int32).view(6, tiles, 64, 4)
+        m1_raw = raw[mat + 6 * n_pad * 512:mat + 6 * n_pad * 512 + 6 * n_pad * 32].view(torch.int32).view(6, tiles, 64, 4)
         T = torch.arange(8, device=dev)
         words = m1_raw[:, :, :, T >> 1]                                                # [net, tile, lane, T]
         bits = (words[..., None] >> (16 * (T & 1)[:, None] + r[None, :])) & 1           # [net, tile, lane, T, r]

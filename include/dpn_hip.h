@@ -119,23 +119,10 @@ int dpn_bwd_points(const float* x, const float* y, const float* t, const float* 
 /* Backward, stage 2: weight-gradient reductions over points (split-K partial sums). */
 int dpn_wgrad(int64_t n_points, int prec, const float* g_out, const void* saved, const void* operands, void* partials, void* stream);
 
-/* Backward, stage 3: reduce the partial sums, undo the fragment permutations and assemble every
- * gradient of DpnNetPtrs (incl. the rank-1 cat_fc1.fc.2 gradients). */
+/* Backward, stage 3: reduce the partial sums, undo the fragment permutations, apply the 256 x 256 factor W1^T diag(u) to the two mask-side
+ * sums (d w2b2, d Wd: csrc SavedView) and assemble every gradient of DpnNetPtrs (incl. the rank-1 cat_fc1.fc.2 gradients). */
 int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n_points, int prec,
                      const void* partials, const DpnNetGradPtrs grads[DPN_NETS], void* stream);
-
-/* Stages 2 + 3 in two parts, for a caller that overlaps the second part with other work (point_path._backward_points runs it on a side
- * stream beside the encoder's backward chain):
- *   part 1  the products the hyper-network's backward waits for (d w2b2 = V^T Z1, d w1b1 = T1^T Z0, d evec), cut into twice as many
- *           point ranges so that they fill the chip alone;
- *   part 2  the products that end in static tensors (G = M2^T Z -> dW1, dbf1, rank-1 fc.2; dWd = V^T G6), 20 workgroups per net: they
- *           leave more than half of the CUs to whatever runs beside them.
- * Both parts write the partial-sum buffer dpn_sizes dimensions (partials); dpn_wgrad_finish_part(part) assembles that part's gradients
- * (part 2 after part 1: it reads part 1's sum of cotangents).  Results are bit-identical to dpn_wgrad + dpn_wgrad_finish for part 2's
- * tensors; part 1's differ in the summation order over point ranges (fixed, run-to-run deterministic). */
-int dpn_wgrad_part(int64_t n_points, int prec, int part, const void* saved, const void* operands, void* partials, void* stream);
-int dpn_wgrad_finish_part(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n_points, int prec,
-                          const void* partials, const DpnNetGradPtrs grads[DPN_NETS], int part, void* stream);
 
 /* SmoothL1(beta) data loss on the normalised fields (losses/weights_loss.py:17-20): per-block sums -> loss_sum[ceil(6N/256)] (fp64,
  * written not accumulated; the caller adds them in a fixed order), g_out = scale * dSmoothL1 (may be NULL). */

@@ -41,11 +41,11 @@ def test_sizes_host_function():
     assert lib.dpn_sizes(37265, 2, ctypes.byref(sz2)) == 0
     assert sz2.saved > sz.saved and sz2.operands > sz.operands
     # point ranges of the weight-gradient kernel: a per-product plan that fills one round of the chip at full size (42 workgroups per
-    # net, at most 11 ranges for one product), one range per 16 tiles below that
-    # k_splits dimensions the partial-sum buffer: sized for the two-part plan (dpn_wgrad_part: products 1 and 3 in 2 * 11 - 1 = 21 ranges)
-    assert sz.k_splits == 21 and sz2.k_splits == 21
+    # net: 10,11,10,11 ranges in single bf16, 10,10,9,13 in the hi+lo mode), one range per 16 tiles below that
+    # k_splits (the most ranges one product is cut into) dimensions the partial-sum buffer
+    assert sz.k_splits == 11 and sz2.k_splits == 13
     small = _lib.DpnSizes()
-    assert lib.dpn_sizes(1037, 2, ctypes.byref(small)) == 0 and small.k_splits == 3
+    assert lib.dpn_sizes(1037, 2, ctypes.byref(small)) == 0 and small.k_splits == 2
     assert lib.dpn_sizes(256, 1, ctypes.byref(small)) == 0 and small.k_splits == 1
     assert lib.dpn_sizes(0, 1, ctypes.byref(sz)) != 0          # bad arguments are rejected, not ignored
     assert lib.dpn_sizes(16, 3, ctypes.byref(sz)) != 0

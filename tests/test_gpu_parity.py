@@ -1045,7 +1045,7 @@ def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n, prec):
     """The hi+lo mode's forward + Jacobian and backward stage-1 kernels exist in two decompositions: the ring form (one 512-register wave
     per SIMD owns 32 points and all output tiles, weights shared through an LDS-DMA ring) and the tile-split form (the default: output
     tiles split over the waves, activations shared through LDS, weights L2 -> VGPR, two workgroups per CU; csrc/dpn_fwd_tiles.h).  Both run
-    the same products in the same order per output tile, so everything they hand to the later kernels -- the saved state V, T1, M2, m1,
+    the same products in the same order per output tile, so everything they hand to the later kernels -- the saved state T1, M2, m1,
     the Jacobian, the operands Z1, Z, Z0, G6, gnet -- must agree BIT FOR BIT (the fields differ in the order the four waves' partial sums
     are added: 1e-6).  Ragged sizes: 1037 = 16 full 64-point workgroups + 13 points, 70 = one full + 6 points."""
     import ctypes
@@ -1093,7 +1093,7 @@ def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n, prec):
             else:
                 os.environ[k] = v
     (o0, j0, s0, p0), (o1, j1, s1, p1) = res['ring'], res['tiles']
-    n_state = 2 * 6 * cfg.prec * ws.sizes.n_pad * 512 + 6 * ws.sizes.n_pad * 512 + 6 * ws.sizes.n_pad * 32       # V, T1 | M2 | m1 (the features behind them are the tile-split form's own)
+    n_state = 6 * cfg.prec * ws.sizes.n_pad * 512 + 6 * ws.sizes.n_pad * 512 + 6 * ws.sizes.n_pad * 32       # T1 | M2 | m1 (the features behind them are the tile-split form's own)
     assert torch.equal(j0, j1)
     assert torch.equal(s0[:n_state], s1[:n_state])
     assert torch.equal(p0, p1)

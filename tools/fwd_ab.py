@@ -48,7 +48,7 @@ for n in sizes:
         (o0, j0, s0), (o1, j1, s1) = res['ring'], res['tiles']
         n_pad = ws.sizes.n_pad
         mat = 6 * cfg.prec * n_pad * 512
-        names = (('V', 0, mat), ('T1', mat, 2 * mat), ('M2', 2 * mat, 2 * mat + 6 * n_pad * 512), ('m1', 2 * mat + 6 * n_pad * 512, 2 * mat + 6 * n_pad * 512 + 6 * n_pad * 32))
+        names = (('T1', 0, mat), ('M2', mat, mat + 6 * n_pad * 512), ('m1', mat + 6 * n_pad * 512, mat + 6 * n_pad * 512 + 6 * n_pad * 32))
         print('n = %d (%s): out max|d| %.3e (rel %.3e)  fields-only vs full: ring %.1e tiles %.1e   jac bitwise %s (max|d| %.3e)' % (
             n, prec, float((o0 - o1).abs().max()), float((o0 - o1).abs().max() / o0.abs().max()),
             float((res['ring_fields'] - o0).abs().max()), float((res['tiles_fields'] - o1).abs().max()),

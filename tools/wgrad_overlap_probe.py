@@ -33,8 +33,8 @@ def main():
     lib = L.load()
     cfg = m.point_config()
 
-    def timed(fn, reps=20):
-        for _ in range(3):
+    def timed(fn, reps=60):
+        for _ in range(10):
             fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
