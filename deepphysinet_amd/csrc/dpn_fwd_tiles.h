@@ -138,7 +138,7 @@ DEV void gemm_head(const char* wg, const int lane, Head<NS, NT>& H) {
 }
 // side(ks): work of the PREVIOUS layer that nobody waits for (its saved-state transposes and stores), issued k-step by k-step in the shadow
 // of this layer's MFMAs instead of in the serial epilogue between two barriers
-template <int NS, int NK, int NT, bool SWAP = false, class Side = NoSide>
+template <int NS, int NK, int NT, bool SWAP = false, class Side = NoSide, bool PIN = true>
 DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>& H, f32x16 (&acc)[2][2], const Side& side = Side()) {
     static_assert(NK >= kPF, "k-steps per chunk");
     WSrc<NS, NK, NT> src;
@@ -176,13 +176,15 @@ DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>
         __builtin_amdgcn_s_setprio(0);
 #endif
         side(ks);
-#ifndef TS_NO_KSTEP_PIN
+        if constexpr (PIN) {
         // k-steps stay k-steps: the MFMAs are pure values without a position of their own, and instruction selection is free to emit all of a
         // layer's 144-192 of them AFTER the fragment loads of all its k-steps (seen after an unrelated change four layers later: 204 spilled
         // registers in the first layer's loop, every load followed by s_waitcnt vmcnt(0) + a scratch store, 628 us instead of 478).  The empty
         // volatile statement gives the accumulators a place in the order of the loads' running offsets (WSrc::next), which are volatile too.
+        // (PIN = false in the backward kernel: its loops carry side work in every layer, which holds the order by itself, and the pin costs it
+        // 19 us -- 241 -> 260 us measured on one box.)
         asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-#endif
+        }
     }
 #if TS_PRIO == 2
     __builtin_amdgcn_s_setprio(1);
@@ -796,10 +798,10 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
 #if TS_DEFER_SAVES
     {
         auto side = [&](const int ks) __attribute__((always_inline)) { side_units(ov.Z0, Z0f, ks); };
-        ts::gemm<NS, 12, 2, false>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc, side);
+        ts::gemm<NS, 12, 2, false, decltype(side), false>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc, side);
     }
 #else
-    ts::gemm<NS, 12, 2>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
+    ts::gemm<NS, 12, 2, false, ts::NoSide, false>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
 #endif
     ts::gemm_head<NS, 16, 2>(chunk(kS1 + 2 * w * 16), lane, H);
 #pragma unroll
@@ -845,10 +847,10 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
                     ts::save_plane_k(ov.Z1, net, NS, s_, tile0 + (tp & 1), 2 * w + (tp >> 1), lane, I, false, F[tp >> 1][tp & 1][0].w[s_], F[tp >> 1][tp & 1][1].w[s_]);
             }
         };
-        ts::gemm<NS, 16, 2, true>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc, side);
+        ts::gemm<NS, 16, 2, true, decltype(side), false>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc, side);
     }
 #else
-    ts::gemm<NS, 16, 2, true>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
+    ts::gemm<NS, 16, 2, true, ts::NoSide, false>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
 #endif
     ts::gemm_head<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), lane, H);
     Frag<NS> f6[3][2];
@@ -876,10 +878,10 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
 #if TS_DEFER_SAVES
     {
         auto side = [&](const int ks) __attribute__((always_inline)) { side_units(ov.G6, f6, ks); };
-        ts::gemm<NS, 12, 2, true>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc, side);
+        ts::gemm<NS, 12, 2, true, decltype(side), false>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc, side);
     }
 #else
-    ts::gemm<NS, 12, 2, true>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc);
+    ts::gemm<NS, 12, 2, true, ts::NoSide, false>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc);
 #endif
 #pragma unroll
     for (int t = 0; t < 2; ++t)

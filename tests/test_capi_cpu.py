@@ -150,8 +150,33 @@ def test_inline_asm_lds_reads_are_waited_for_before_any_use(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'mfma_hazard_check.py'), asm, *kernels], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         assert r.stdout.count(' 0 of them touch') == 2 * len(kernels), r.stdout
-        assert 's_swappc_b64' not in open(asm).read(), 'a helper was not inlined: the kernels must not make calls'
+        text = open(asm).read()
+        assert 's_swappc_b64' not in text, 'a helper was not inlined: the kernels must not make calls'
+        if checked == 0:
+            _check_tile_split_schedule(text)
         checked += 1
+
+
+def _check_tile_split_schedule(text):
+    """The tile-split kernels' k-step loops are unrolled straight-line code whose shape hipcc decides: no spilled vector registers (a spill in
+    the first layer's loop once cost 150 us: every fragment load followed by s_waitcnt vmcnt(0) + scratch store) and weight loads
+    interleaved with the MFMAs (never more than two k-steps' worth -- 2 k-steps x 2 tiles x 2 planes -- of buffer loads in a row)."""
+    import re
+    for name in ('_Z20dpn_fwd_tiles_kernelILi2EEv7FwdArgs', '_Z20dpn_bwd_tiles_kernelILi2EEv7BwdArgs'):
+        meta = text[text.index('.name:           ' + name):]
+        spills = int(re.search(r'\.vgpr_spill_count:\s+(\d+)', meta).group(1))
+        assert spills == 0, '%s spills %d vector registers' % (name, spills)
+        body = text[text.index(name + ':'):]
+        body = body[:body.index('s_endpgm')]
+        run = worst = 0
+        for line in body.splitlines():
+            ins = line.strip().split(' ')[0]
+            if ins.startswith('buffer_load_dwordx4'):
+                run += 1
+                worst = max(worst, run)
+            elif ins.startswith('v_mfma'):
+                run = 0
+        assert worst <= 12, '%s: %d weight-fragment loads in a row without an MFMA between them' % (name, worst)
 
 
 def test_mfma_hazard_checker_flags_inline_asm_on_a_fresh_accumulator(tmp_path):

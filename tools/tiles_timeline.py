@@ -25,7 +25,7 @@ lib.dpn_debug_set_timeline.argtypes = [ctypes.c_void_p]
 b = synth_batch(n, dev, seed=1)
 NAMES = ['prologue: vectors, pe3 features', 'barrier', 'L1 multiply', 'L1 epilogue (relu, mask, pack)', 'barrier A', 'store + barrier B',
          'L2 multiply (w2.h1)', 'pe6 features', 'barrier A', 'store + barrier B', 'L2 multiply (Wd.pe6)', 'L2 epilogue (wo.c, pack)', 'barrier A', 'store + barrier B',
-         'fc1 multiply', 'fc1 epilogue (mask, t2, M2 save)', 'barrier A', 'store + barrier B + field', 'v multiply', 'v epilogue (pack, V save)', 'barrier A', 'store + barrier B',
+         'fc1 multiply', 'fc1 epilogue (mask, t2, M2 save)', 'barrier A', 'store + barrier B + field', 'v multiply', 'v epilogue (pack)', 'barrier A', 'store + barrier B',
          'y multiply', 'y epilogue (mask, T1 save)', 'barrier A', 'store + barrier B', 'gpe multiply', 'Jacobian contraction']
 with torch.no_grad():
     heads, evec, statics = m.physics_net.field_weights(b['field_data'], b['forecast_h'])
