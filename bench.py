@@ -131,9 +131,10 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=16384)
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
-    ap.add_argument('--encoder-fp8', action='store_true',
+    ap.add_argument('--encoder-fp8', nargs='?', const='1', default=None, choices=['1', 'mx'],
                     help='BASELINE configs[4]: the encoder layers\' forward GEMMs on fp8 (OCP e4m3) MFMA, bf16x2 Jacobian path; OFF by default -- it moves '
-                         'the PDE losses by 1e-2 ... 2e-1 (tests/test_gpu_parity.py::test_config4_fp8_encoder_workload) and buys no time')
+                         'the PDE losses by 1e-2 ... 2e-1 (tests/test_gpu_parity.py::test_config4_fp8_encoder_workload) and buys no time.  '
+                         '"mx": the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 form (one E8M0 scale per 32 k)')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -145,7 +146,7 @@ def main():
         raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%s: the launcher and the flag disagree' % (args.gpus, env_world))
 
     if args.encoder_fp8:
-        os.environ['DPN_ENCODER_FP8'] = '1'      # read by deepphysinet_amd.encoder_ops at call time
+        os.environ['DPN_ENCODER_FP8'] = args.encoder_fp8      # read by deepphysinet_amd.encoder_ops at call time
     from deepphysinet_amd import distributed as D
     # DPN_BENCH_BACKEND=gloo + DPN_BENCH_ONE_DEVICE=1: exercise the N > 1 code path with every rank on GPU 0 (test boxes have one GPU)
     # DPN_BENCH_RCCL_ONE_RANK=1: a one-rank RCCL group + the N > 1 step shape (segment graphs, bucket all-reduces): the real collective
@@ -346,7 +347,7 @@ def main():
         'collective': coll,
     }
     if args.encoder_fp8:
-        out['config']['encoder_fp8'] = True
+        out['config']['encoder_fp8'] = 'mx (E8M0 scale per 32 k, v_mfma_scale_f32_32x32x64_f8f6f4)' if args.encoder_fp8 == 'mx' else 'per-row scales, v_mfma_f32_32x32x16_fp8_fp8'
         out['dtype'] += '; encoder forward GEMMs fp8 e4m3 MFMA (configs[4])'
 
     if rank == 0 and args.leads == 1:

@@ -106,6 +106,7 @@ EXPORTS = {
                                    c_float, c_float, c_void_p, c_void_p]),
     'dpn_clip_adam_flat_dev': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_gemm_fp8': (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'dpn_gemm_fp8_mx': (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dpn_selftest': (c_int, [c_void_p, c_void_p]),
 }
 

@@ -154,10 +154,13 @@ class _EncoderLayerFn(torch.autograd.Function):
         Fh = wc1.shape[0]
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
         # BASELINE configs[4] experiment, off in the product: the six forward GEMMs of the layer on the fp8 matrix cores (csrc/dpn_fp8.hip)
-        fp8 = os.environ.get('DPN_ENCODER_FP8') == '1'
+        # ('1': per-row scales, v_mfma_f32_32x32x16_fp8_fp8; 'mx': one E8M0 scale per 32 k, v_mfma_scale_f32_32x32x64_f8f6f4)
+        fp8_mode = os.environ.get('DPN_ENCODER_FP8')
+        fp8 = fp8_mode in ('1', 'mx')
 
         def gemm8(M, N, K, A, W, bias, C, epi=0, aux_out=None):
-            L.check(lib.dpn_gemm_fp8(M, N, K, _p(A), K, _p(W), K, _p(bias), _p(C), N, epi, _p(aux_out), _s()), 'dpn_gemm_fp8')
+            fn = lib.dpn_gemm_fp8_mx if fp8_mode == 'mx' else lib.dpn_gemm_fp8
+            L.check(fn(M, N, K, _p(A), K, _p(W), K, _p(bias), _p(C), N, epi, _p(aux_out), _s()), 'dpn_gemm_fp8')
         q, k, v = new(n, D), new(n, D), new(n, D)
         if fp8:
             for w, b, y in ((wq, bq, q), (wk, bk, k), (wv, bv, v)):

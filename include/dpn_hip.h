@@ -284,6 +284,11 @@ int dpn_clip_adam_flat_dev(int n_tensors, float* const* params, const float* con
  * receives the pre-activation).  Replaces nothing of the reference by default: its measured parity error is why. */
 int dpn_gemm_fp8(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int epi,
                  float* aux_out, void* stream);
+/* The same GEMM on the block-scaled (MX) fp8 instruction v_mfma_scale_f32_32x32x64_f8f6f4: one E8M0 power-of-two scale per 32 consecutive k of
+ * a row (OCP MX), applied by the hardware; K % 64 == 0.  DPN_ENCODER_FP8=mx routes the encoder's forward GEMMs here (measurement:
+ * profiles/round3_fp8_mx_encoder.json). */
+int dpn_gemm_fp8_mx(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int epi,
+                 float* aux_out, void* stream);
 
 /* Self-test of the MFMA fragment-layout assumptions in dpn_layout.h (A = I against an asymmetric B). Returns 0 if they hold. */
 int dpn_selftest(void* scratch_dev /* >= 64 KiB */, void* stream);

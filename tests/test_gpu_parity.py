@@ -1006,6 +1006,45 @@ def test_fp8_gemm_experiment_kernel_matches_its_definition():
         assert 1e-3 < err < 0.2, err                                                       # the fp8 operand rounding itself: percent level
 
 
+
+def test_fp8_mx_gemm_kernel_matches_the_mx_definition():
+    """The block-scaled form (v_mfma_scale_f32_32x32x64_f8f6f4, csrc/dpn_fp8.hip dpn_gemm_fp8_mx): one power-of-two scale per 32 consecutive
+    k of a row (OCP MX: E8M0), e4m3 elements -- against the same definition written with torch casts.  Pins the instruction's operand
+    layout (which k a lane's 32 bytes are, whose scale applies to them) with unequal block magnitudes along K."""
+    import ctypes
+    from deepphysinet_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    torch.manual_seed(0)
+
+    def mx(t):                                               # [R, K] -> dequantised MX image
+        R, K = t.shape
+        b = t.view(R, K // 32, 32)
+        amax = b.abs().amax(dim=2, keepdim=True)
+        e = torch.ceil(torch.log2(amax.clamp_min(1e-38) / 448.0))
+        scale = torch.where(amax > 0, torch.exp2(e), torch.ones_like(e))
+        return ((b / scale).to(torch.float8_e4m3fn).float() * scale).view(R, K)
+
+    for M, N, K, epi in ((287, 256, 256, 0), (1000, 256, 256, 1), (64, 96, 64, 0)):
+        ramp = torch.exp2(torch.arange(K // 32, device=dev, dtype=torch.float32) * 1.5 - 3.0).repeat_interleave(32)   # blocks 2^-3 .. 2^7.5
+        A = torch.randn(M, K, device=dev) * 1.7 * ramp
+        W = torch.randn(N, K, device=dev) / K ** 0.5 * ramp.flip(0)
+        bias = torch.randn(N, device=dev) * 0.1
+        C = torch.empty(M, N, device=dev)
+        pre = torch.empty(M, N, device=dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        assert lib.dpn_gemm_fp8_mx(M, N, K, p(A), K, p(W), K, p(bias), p(C), N, epi, p(pre) if epi else None, torch.cuda.current_stream().cuda_stream) == 0
+        want = (mx(A).double() @ mx(W).double().t()).float() + bias
+        exact = A @ W.t() + bias
+        if epi:
+            assert float((pre - want).abs().max() / want.abs().max()) < 1e-4
+            want, exact = torch.nn.functional.gelu(want), torch.nn.functional.gelu(exact)
+        # same operands and scales; the instruction's 64-term sum is not an fp32 fmaf chain (measured 3e-5 of the largest entry against the
+        # fp64 sum of the same quantised operands) -- a wrong block / scale assignment shows up at 1e-1 (it did: 0.75 before the layout probe)
+        assert float((C - want).abs().max() / want.abs().max()) < 1e-4, (M, N, K)
+        err = float((C - exact).abs().max() / exact.abs().max())
+        assert 1e-3 < err < 0.2, err                                                       # the e4m3 rounding itself
+
 def test_config4_fp8_encoder_workload():
     """BASELINE configs[4] as a CONFIGURATION (bench.py --encoder-fp8): the encoder layers' forward GEMMs on fp8 (OCP e4m3) MFMA, everything
     behind them -- hyper-network heads, fused forward + Jacobian in bf16x2, residuals -- as in the product, on the configs[1] workload
