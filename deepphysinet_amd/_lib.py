@@ -71,6 +71,8 @@ EXPORTS = {
     'dpn_pack_weights': (c_int, [POINTER(DpnNetPtrs), c_int, c_void_p, c_void_p]),
     'dpn_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
                         c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_fwd_ref': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
+                            c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_contract_gpe': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'dpn_residual': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(DpnGeometry), POINTER(DpnPhysics), c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p]),

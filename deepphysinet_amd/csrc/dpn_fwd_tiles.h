@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         if (pt < a.n) {
             const float const0 = vec[kNumVecs * 256];
             const float o = (red[0 * 64 + h * 32 + j] + red[1 * 64 + h * 32 + j]) + (red[2 * 64 + h * 32 + j] + red[3 * 64 + h * 32 + j]);
-            a.out_n[pt * 6 + net] = o + const0 + a.coord_data[pt * 6 + net];           // + ref_data (variable_net.py:86)
+            a.out_n[pt * 6 + net] = o + const0 + (a.ref ? a.ref : a.coord_data)[pt * 6 + net];           // + ref_data (variable_net.py:86)
         }
     }
     if (!save && !a.jac_n) return;

@@ -616,6 +616,7 @@ struct FwdArgs {
     float* jac_n;
     void* saved;
     const char* feat;        // positional features of dpn_features_kernel (tile-split kernel, DPN_FEATURES_PREPASS=1), else null
+    const float* ref;        // [N][6] added to the output in place of coord_data (VariableNet.forward's own ref_data argument), else null
 #ifdef DPN_TIMELINE
     unsigned* timeline;      // [blocks][6 nets][8 wave slots][64]: s_memtime (low word) at the start of every pipeline step (experiment build only)
 #endif
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     float cd6[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) cd6[c] = a.coord_data[pc * 6 + c];
-    const float ref_data = a.coord_data[pc * 6 + net];
+    const float ref_data = (a.ref ? a.ref : a.coord_data)[pc * 6 + net];
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     const bool save = a.saved != nullptr;
 
@@ -2289,14 +2290,14 @@ int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, vo
 static unsigned* g_timeline = nullptr;
 int dpn_debug_set_timeline(void* buf) { g_timeline = reinterpret_cast<unsigned*>(buf); return 0; }    // experiment build only, not in dpn_hip.h
 #endif
-int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
-            const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream) {
+int dpn_fwd_ref(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, const float* ref_data, int64_t n,
+                const float* freqs, const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream) {
     if (!coord_data || !freqs || !geo || !packed || !out_n || n <= 0 || (prec != 1 && prec != 2)) return -1;
     if (!pe_in && (!x || !y || !t)) return -1;
 #ifdef DPN_TIMELINE
-    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, g_timeline};
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, ref_data, g_timeline};
 #else
-    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr};
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, ref_data};
 #endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
@@ -2327,6 +2328,11 @@ int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, 
     if (prec == 1) hipLaunchKernelGGL(dpn_fwd_kernel<1>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(dpn_fwd_kernel<2>, grid, dim3(256), 0, s, a);
     return ck(hipGetLastError());
+}
+
+int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
+            const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream) {
+    return dpn_fwd_ref(x, y, t, pe_in, coord_data, nullptr, n, freqs, geo, packed, prec, out_n, jac_n, saved, stream);
 }
 
 #endif  // DPN_HAS_POINT

@@ -61,8 +61,14 @@ class VariableNet(nn.Module):
         """Reference signature: coord is the [N,192] encoded coordinate tensor, ref_data [N,1] is added to the output."""
         from ..point_path import PointConfig, point_fields
         w1b1, w2b2, evec = self.hyper_weights(meta_out, fore_h)
-        cfg = getattr(self, '_point_cfg', None) or PointConfig()
+        import copy
+        cfg = copy.copy(getattr(self, '_point_cfg', None) or PointConfig())
         heads = torch.cat([w1b1] * 6 + [w2b2] * 6, dim=1)
+        # the point kernels evaluate six nets per launch (this one fills all six slots; a one-net launch would need a net count in every
+        # entry point of the C ABI, for a surface the training step never calls) and add ref_data inside the kernel (dpn_fwd_ref): the output
+        # is the kernel's own sum, not rebuilt by subtraction.  ref_data enters as a constant; where the caller needs d out / d ref_data
+        # (= 1) it is added outside
+        ref = ref_data.reshape(-1, 1)
+        cfg.ref6 = (torch.zeros_like(ref) if ref.requires_grad else ref.detach()).expand(-1, 6).contiguous()
         out = point_fields(cfg, coord_data, heads, evec.unsqueeze(0).expand(6, -1).contiguous(), self.static_params() * 6, pe_in=coord)
-        # the kernel adds coord_data[:, k] as ref_data of slot k; replace slot 0's by the caller's ref_data
-        return out[:, 0:1] - coord_data[:, 0:1] + ref_data
+        return out[:, 0:1] + ref if ref.requires_grad else out[:, 0:1]

@@ -127,7 +127,7 @@ class _Workspace:
         self.saved = torch.empty(self.sizes.saved, dtype=torch.uint8, device=self.device)
 
 
-def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, want_jac, want_saved):
+def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, want_jac, want_saved, ref6=None):
     lib = L.load()
     n = coord_data.shape[0]
     dev = coord_data.device
@@ -138,8 +138,9 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     if want_saved:
         ws.alloc_saved()
     geo = cfg.geometry()
-    L.check(lib.dpn_fwd(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), n, _ptr(_freqs(dev)), ctypes.byref(geo),
-                        _ptr(ws.packed), cfg.prec, _ptr(out_n), _ptr(jac_n), _ptr(ws.saved), _stream()), 'dpn_fwd')
+    # ref6 [N,6]: the reference's separate ref_data argument (VariableNet.forward standalone); None: coord_data's columns (PhysicsNet.forward)
+    L.check(lib.dpn_fwd_ref(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), _ptr(ref6), n, _ptr(_freqs(dev)), ctypes.byref(geo),
+                            _ptr(ws.packed), cfg.prec, _ptr(out_n), _ptr(jac_n), _ptr(ws.saved), _stream()), 'dpn_fwd')
     return out_n, jac_n
 
 
@@ -237,7 +238,9 @@ class _PointFieldsFn(torch.autograd.Function):
         want_gpe = pe_in is not None and pe_in.requires_grad
         ws = _Workspace(cd_.shape[0], cfg.prec, cd_.device)
         nets = _net_ptrs(hd_, ev_, st)
-        out_n, gpe = _forward_points(cfg, ws, nets, x_, y_, t_, pe_, cd_, want_jac=want_gpe, want_saved=need_grad)
+        ref6 = getattr(cfg, 'ref6', None)                 # VariableNet.forward's own ref_data (a constant: no gradient flows to it here)
+        out_n, gpe = _forward_points(cfg, ws, nets, x_, y_, t_, pe_, cd_, want_jac=want_gpe, want_saved=need_grad,
+                                     ref6=None if ref6 is None else _f32c(ref6.detach()))
         ctx.cfg, ctx.ws, ctx.gpe = cfg, ws, gpe
         ctx.keep = (x_, y_, t_, pe_, cd_, hd_, ev_, st)
         ctx.stamp = _stamp((heads, evec) + tuple(statics))

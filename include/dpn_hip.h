@@ -95,6 +95,12 @@ int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, vo
 int dpn_fwd(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n_points,
             const float* freqs, const DpnGeometry* geo, const void* packed, int prec,
             float* out_n, float* jac_n, void* saved, void* stream);
+/* dpn_fwd with the reference's separate ref_data argument (model/variable_net.py:49, :86: `out_fc(y) + ref_data`): ref_data [N][6] is added to
+ * out_n in place of coord_data (NULL: coord_data, i.e. dpn_fwd -- PhysicsNet.forward passes coord_data[:, k] as net k's ref_data,
+ * physics_net.py:49-54).  VariableNet.forward standalone uses it, so that its output is not rebuilt by subtraction. */
+int dpn_fwd_ref(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, const float* ref_data,
+                int64_t n_points, const float* freqs, const DpnGeometry* geo, const void* packed, int prec,
+                float* out_n, float* jac_n, void* saved, void* stream);
 
 /* g_pe[N][192] = sum_k g_out[N][k] * gpe[N][k][192]: backward of PhysicsNet.forward w.r.t. its encoded-coordinate input. */
 int dpn_contract_gpe(const float* g_out, const float* gpe, int64_t n_points, float* g_pe, void* stream);
