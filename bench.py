@@ -219,13 +219,13 @@ def main():
         sync = D.GradientAllReduce(opt, single_rank_too=one_rank_rccl) if (world > 1 or one_rank_rccl) else None
         coll['gradient_buckets_mb'] = [round((b - a) * 4 / 2 ** 20, 2) for a, b in opt.bucket_bounds]
         segments, staged = make_step(m, opt)
-        n_reduce = len(segments) - 1 if split_step else 0     # segment i completes gradient bucket i; the last segment is the optimiser
+        n_reduce = len(segments) - 1 if split_step else 0     # segment i completes the layout buckets staged.stage_buckets[i]; the last segment is the optimiser
 
         def eager():
             for i, seg in enumerate(segments):
                 seg()
                 if sync is not None and i < n_reduce:
-                    sync.reduce_bucket(i)
+                    sync.reduce_bucket(*staged.stage_buckets[i])
                     if i == n_reduce - 1:
                         sync.wait()
         graphs = None
@@ -249,7 +249,7 @@ def main():
                         for i, seg in enumerate(segments):
                             seg()
                             if i < n_reduce:
-                                sync.reduce_bucket(i)
+                                sync.reduce_bucket(*staged.stage_buckets[i])
                                 if i == n_reduce - 1:
                                     sync.wait()
                     graphs.append(g)
@@ -278,7 +278,7 @@ def main():
                 for i, g in enumerate(graphs):
                     g.replay()
                     if sync is not None and i < n_reduce:
-                        sync.reduce_bucket(i)         # queued behind segment i, runs under segments i+1..
+                        sync.reduce_bucket(*staged.stage_buckets[i])         # queued behind segment i, runs under segments i+1..
                         if i == n_reduce - 1:
                             sync.wait()               # the optimiser segment waits for every bucket
         for _ in range(warmup):

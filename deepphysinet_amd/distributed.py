@@ -82,12 +82,13 @@ class GradientAllReduce:
     def n_buckets(self):
         return len(self.opt.bucket_bounds)
 
-    def reduce_bucket(self, i, async_op=True):
-        """Queue the averaging all-reduce of layout bucket i (its gradients must already be queued on the current stream)."""
+    def reduce_bucket(self, i, end=None, async_op=True):
+        """Queue the averaging all-reduce of layout bucket i -- or of the buckets i .. end-1 as ONE collective on their contiguous slice of
+        the flat buffer (their gradients must already be queued on the current stream)."""
         if not self.active():
             return
         self._check_layout()
-        a, b = self.opt.bucket_bounds[i]
+        a, b = self.opt.bucket_bounds[i][0], self.opt.bucket_bounds[(i + 1 if end is None else end) - 1][1]
         w = _all_reduce_mean(self.opt.flat_gradients()[a:b], dist.get_world_size(self.group), self.group, async_op)
         if w is not None and async_op:
             self._work.append(w)
@@ -106,8 +107,7 @@ class GradientAllReduce:
             return
         if self.opt is not None:
             self.opt.gather_gradients(zero_missing=True)
-            for i in range(self.n_buckets()):
-                self.reduce_bucket(i)
+            self.reduce_bucket(0, self.n_buckets())          # nothing left to overlap with: the whole flat buffer as one collective
             self.wait()
             return
         world = dist.get_world_size(self.group)

@@ -277,14 +277,14 @@ class InterfacePhysics(nn.Module):
         if staged:
             # data-parallel step: the backward pass is cut where a bucket of gradients is complete and that bucket's all-reduce is queued at
             # once, so it travels under the rest of the backward (what DistributedDataParallel's bucket hooks do in the reference, :903-907,
-            # :1056): point statics | hyper-network heads | encoder -- the optimiser's layout buckets (PhysicsNet.gradient_buckets)
+            # :1056).  Layout buckets (PhysicsNet.gradient_buckets): point statics | hyper-network heads | encoder; the first two travel as
+            # ONE all-reduce (the heads' backward is two launches: a collective of its own costs more than the 40 us it could start earlier)
             buckets = self.physics_net.gradient_buckets()
             g = torch.autograd.grad(train_loss, [heads, evec] + list(statics), grad_outputs=self._seed)
             optimizer.place_gradients(list(statics), g[2:])
-            grad_sync.reduce_bucket(0)
             g2 = torch.autograd.grad([heads, evec], [meta_out] + buckets[1], grad_outputs=[g[0], g[1]], allow_unused=True)
             optimizer.place_gradients(buckets[1], g2[1:])
-            grad_sync.reduce_bucket(1)
+            grad_sync.reduce_bucket(0, 2)
             g3 = torch.autograd.grad([meta_out], buckets[2], grad_outputs=[g2[0]], allow_unused=True)
             optimizer.place_gradients(buckets[2], g3)
             grad_sync.reduce_bucket(2)
@@ -470,10 +470,14 @@ class StagedPdeStep:
     """place_one_batch + backward of one field sample, cut where a bucket of gradients is complete (PhysicsNet.gradient_buckets), so that
     a data-parallel caller can start that bucket's all-reduce while the rest of the backward pass runs (BASELINE configs[3]: "bucketed
     overlap with backward"; the reference gets the same from DistributedDataParallel's bucket hooks, interface_physics.py:903-907,:1056):
-        stages[0]  zero_grad, encoder + heads forward, point forward / residuals, point backward   -> bucket 0 (48 static tensors)
-        stages[1]  hyper-network heads backward                                                     -> bucket 1
-        stages[2]  encoder backward                                                                 -> bucket 2
-    Each stage is a plain callable (capturable in a hipGraph of its own, on one capture stream and one memory pool)."""
+        stages[0]  zero_grad, encoder + heads forward, point forward / residuals, point backward,
+                   hyper-network heads backward                                                     -> layout buckets 0 and 1 (48 static tensors,
+                                                                                                       the heads): stage_buckets[0] = (0, 2)
+        stages[1]  encoder backward                                                                 -> layout bucket 2: stage_buckets[1] = (2, 3)
+    Each stage is a plain callable (capturable in a hipGraph of its own, on one capture stream and one memory pool); after stage i the caller
+    queues `grad_sync.reduce_bucket(*stage_buckets[i])`.  (Round 2 cut the heads' backward off as a stage of its own: three collectives and
+    four graph segments cost 1.80 -> 2.00 ms with a one-rank RCCL group; the heads' backward is two launches, so the statics' all-reduce
+    loses ~40 us of head start and still has the whole encoder backward, 0.3 ms, to travel under.)"""
 
     def __init__(self, interface, optimizer, batch, loss_factor=None):
         self.m, self.opt, self.b = interface, optimizer, batch
@@ -481,7 +485,8 @@ class StagedPdeStep:
         net = interface.physics_net
         self.buckets = net.gradient_buckets()
         self.loss = None
-        self.stages = (self.stage_points, self.stage_heads, self.stage_encoder)
+        self.stages = (self.stage_points_and_heads, self.stage_encoder)
+        self.stage_buckets = ((0, 2), (2, 3))
         self._seed = None
 
     def _assign(self, params, grads):
@@ -502,6 +507,11 @@ class StagedPdeStep:
         self._assign(statics, g[2:])
         self.loss = total.detach()
         return self.loss
+
+    def stage_points_and_heads(self):
+        loss = self.stage_points()
+        self.stage_heads()
+        return loss
 
     def stage_heads(self):
         params = self.buckets[1]

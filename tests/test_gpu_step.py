@@ -152,7 +152,8 @@ def test_fused_optimizer_is_a_torch_optimizer_with_device_side_lr():
 
 
 def test_staged_step_equals_the_plain_step():
-    """StagedPdeStep (three segments, a gradient bucket complete after each) gives bit-for-bit the gradients of loss.backward()."""
+    """StagedPdeStep (two backward segments, the layout buckets stage_buckets[i] complete after segment i) gives bit-for-bit the gradients of
+    loss.backward()."""
     from deepphysinet_amd.interface.interface_physics import StagedPdeStep
     g = _gpu(synthetic_inputs(700, tag='inter'))
     m = _model()
@@ -165,8 +166,8 @@ def test_staged_step_equals_the_plain_step():
     done = []
     for i, stage in enumerate(st.stages):
         stage()
-        ready = m.physics_net.gradient_buckets()[i]
-        assert all(p.grad is not None for p in ready)
+        for k in range(*st.stage_buckets[i]):
+            assert all(p.grad is not None for p in m.physics_net.gradient_buckets()[k])
         done.append(i)
     assert float(st.loss) == float(loss.detach())
     for k, p in m.physics_net.named_parameters():
@@ -205,7 +206,7 @@ g['field_data'] = g['field_data'] * (1.0 + 0.25 * rank)
 st = StagedPdeStep(m, opt, g)
 for i, stage in enumerate(st.stages):
     stage()
-    sync.reduce_bucket(i)
+    sync.reduce_bucket(*st.stage_buckets[i])
 sync.wait()
 torch.cuda.synchronize()
 out = {{k: p.grad.detach().cpu().numpy() for k, p in m.physics_net.named_parameters()}}
