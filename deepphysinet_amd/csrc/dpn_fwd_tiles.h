@@ -314,7 +314,7 @@ DEV void dpe_tile(float (&d)[16], const Args& a, const int c, const int t, const
 }  // namespace ts
 
 template <int NS>
-__global__ __launch_bounds__(256) void dpn_features_kernel(FwdArgs a, char* feat) {
+__global__ __launch_bounds__(256) void dpn_features_kernel(FwdArgs a, char* feat) {      // a.feat_table_only: the dpe table alone
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int64_t tile0 = (int64_t)blockIdx.x * 2;
@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void dpn_features_kernel(FwdArgs a, char* feat
         const int64_t pc = pt < a.n ? pt : (a.n - 1);
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
+            if (a.feat_table_only) break;
             const int ks = 3 * w + kk;
             Frag<NS> f3, f6;
             ts::pe3_frag<NS>(f3, a, ks, h, pc);
@@ -420,7 +421,8 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     ts::Head<NS, 2> H;
     ts::gemm_head<NS, 12, 2>(chunk(kS0 + 2 * w * 12), lane, H);
     // ---------------- coordinate features pe3 -> X (k-steps 0..11)
-    if (ft) {                                // linear copy of the stored image: 16 bytes per thread and step, all loads in flight at once
+    const bool ft_pe = ft && !a.feat_table_only;
+    if (ft_pe) {                             // linear copy of the stored image: 16 bytes per thread and step, all loads in flight at once
         constexpr int kSteps = ts::feat_pe_bytes<NS>() / 4096;
         u32x4 v[kSteps];
 #pragma unroll
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     ts::gemm<NS, 16, 2>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
     TS_STAMP(7);
     ts::gemm_head<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), lane, H);
-    if (ft) {   // data features pe6: copy of the stored image
+    if (ft_pe) {   // data features pe6: copy of the stored image
         constexpr int kSteps = ts::feat_pe_bytes<NS>() / 4096;
         u32x4 v[kSteps];
 #pragma unroll

@@ -583,8 +583,10 @@ DPN_HD int64_t saved_state_bytes(int64_t n_pad, int ns) { return (int64_t)kNets 
 // fragment images and the d pe3 / d xi table, evaluated once per point instead of once per point and net)
 DPN_HD int64_t feature_bytes(int64_t n_pad, int ns) { return (n_pad / 64) * (int64_t)(2 * 12 * 2 * ns * 1024 + 3 * 2 * 2 * 64 * 64); }
 // DPN_FEATURES_PREPASS=1 (measured experiment, OFF by default): the pre-pass kernel costs 25 us (it writes 86 MB) and shortens the forward kernel
-// by 19 us -- no net gain at six nets per point; without it the features are evaluated inside the kernels, hidden behind the partner wave
-static bool features_prepass() { const char* e = getenv("DPN_FEATURES_PREPASS"); return e && e[0] == '1'; }
+// by 19 us -- no net gain at six nets per point; without it the features are evaluated inside the kernels, hidden behind the partner wave.
+// DPN_FEATURES_PREPASS=2: only the d pe3 / d xi table of the Jacobian contraction (29 MB; that phase is 9 % of a wave's lifetime in the
+// timeline): same-box steps 1.618-1.623 ms against 1.624 ms without -- nothing either, the phase overlaps the partner workgroup's MFMAs
+static int features_prepass() { const char* e = getenv("DPN_FEATURES_PREPASS"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
 static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_pad, ns) + (features_prepass() ? feature_bytes(n_pad, ns) : 0); }
 
 struct OperandView {     // written by dpn_bwd_points
@@ -616,6 +618,7 @@ struct FwdArgs {
     float* jac_n;
     void* saved;
     const char* feat;        // positional features of dpn_features_kernel (tile-split kernel, DPN_FEATURES_PREPASS=1), else null
+    int feat_table_only;     // DPN_FEATURES_PREPASS=2: `feat` holds only the d pe3 / d xi table (the features themselves are evaluated in the kernel)
     const float* ref;        // [N][6] added to the output in place of coord_data (VariableNet.forward's own ref_data argument), else null
 #ifdef DPN_TIMELINE
     unsigned* timeline;      // [blocks][6 nets][8 wave slots][64]: s_memtime (low word) at the start of every pipeline step (experiment build only)
@@ -2295,9 +2298,9 @@ int dpn_fwd_ref(const float* x, const float* y, const float* t, const float* pe_
     if (!coord_data || !freqs || !geo || !packed || !out_n || n <= 0 || (prec != 1 && prec != 2)) return -1;
     if (!pe_in && (!x || !y || !t)) return -1;
 #ifdef DPN_TIMELINE
-    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, ref_data, g_timeline};
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, 0, ref_data, g_timeline};
 #else
-    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, ref_data};
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, 0, ref_data};
 #endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
@@ -2318,6 +2321,7 @@ int dpn_fwd_ref(const float* x, const float* y, const float* t, const float* pe_
         if (saved && features_prepass()) {             // positional features once per point (read by the six nets' workgroups)
             char* feat = reinterpret_cast<char*>(saved) + saved_state_bytes(a.n_pad, prec);
             a.feat = feat;
+            a.feat_table_only = features_prepass() == 2;
             if (prec == 1) hipLaunchKernelGGL(dpn_features_kernel<1>, dim3(grid64.x), dim3(256), 0, s, a, feat);
             else hipLaunchKernelGGL(dpn_features_kernel<2>, dim3(grid64.x), dim3(256), 0, s, a, feat);
         }
