@@ -433,7 +433,9 @@ def main():
         ns = 2 if prec == 'bf16x2' else 1
         nsplit = 3 if prec == 'bf16x2' else 1
         traffic, source = pmc_traffic('dpn_fwd_tiles_kernel' if ns == 2 else 'dpn_fwd_kernel', prec, args.points)
-        fwd_name = 'dpn_fwd_tiles_kernel<2> (+ dpn_features_kernel<2>, its per-point feature pre-pass)' if ns == 2 else 'dpn_fwd_kernel<1>'
+        fwd_name = 'dpn_fwd_kernel<1>'
+        if ns == 2:
+            fwd_name = 'dpn_fwd_tiles_kernel<2>' + (' (+ dpn_features_kernel<2>, the opt-in feature pre-pass)' if os.environ.get('DPN_FEATURES_PREPASS', '0') in ('1', '2') else '')
         roof = {'bound': 'mfma', 'kernel': fwd_name,
                 'achieved': ach / 1e12, 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_BF16,
                 'traffic': traffic, 'traffic_source': source, 'kernel_ms': k_ms,
