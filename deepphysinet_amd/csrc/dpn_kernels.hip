@@ -567,7 +567,7 @@ struct SavedView {       // written by dpn_fwd
 // so the two weight-gradient products it entered factor through the 0/1 matrix that is saved anyway,
 //   sum_pt v (x) z1 = W1^T diag(u) (M2^T Z1) + 2 wo (x) colsum(Z1)      (likewise with G6),
 // -- one 512-byte mask row per point and net instead of a 1-KB hi+lo row written once and read twice, two MFMAs per fragment pair instead
-// of three, and the 256 x 256 factor applied once per net in fp32 (dpn_finish_vside_kernel) instead of once per point in split bf16.
+// of three, and the 256 x 256 factor applied once per net in fp32 (dpn_finish_vside_fc2_kernel) instead of once per point in split bf16.
 DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
     SavedView s;
     char* b = reinterpret_cast<char*>(base);
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 // ------------------------------------------------------------------------------------------------ backward, stage 2
 // Points-reduction GEMMs  D[so][si] = sum_pt X[pt][so] * Y[pt][si]  for the four products of a net:
 //   P0: G    = M2^T Z    (256x256)  + mvec = M2^T g, q  = Z^T 1
-//   P1: S1   = M2^T Z1   (256x256)  + mv1  = M2^T g, q1 = Z1^T 1, sum g      dw2 = W1^T diag(u) S1 + 2 wo (x) q1   (dpn_finish_vside_kernel;
+//   P1: S1   = M2^T Z1   (256x256)  + mv1  = M2^T g, q1 = Z1^T 1, sum g      dw2 = W1^T diag(u) S1 + 2 wo (x) q1   (dpn_finish_vside_fc2_kernel;
 //   P2: S2   = M2^T G6   (256x192)  +                q6 = G6^T 1             dWd = W1^T diag(u) S2 + 2 wo (x) q6    v is affine in m2: SavedView)
 //   P3: dw1  = T1^T Z0   (256x192)  + db1 = T1^T g
 // grid = (sum of the four products' point-range counts, 6 nets): each workgroup owns the whole output of its product for its range of
@@ -1472,7 +1472,7 @@ struct FinishArgs {
     const char* packed;
     const float* partials;
     float* scratch_r;       // [6][256] r vector (lives in the partials buffer tail, like the three below)
-    float* scratch_s1;      // [6][256][256] diag(u) M2^T Z1, natural order          (dpn_finish_rows_kernel -> dpn_finish_vside_kernel)
+    float* scratch_s1;      // [6][256][256] diag(u) M2^T Z1, natural order          (dpn_finish_rows_kernel -> dpn_finish_vside_fc2_kernel)
     float* scratch_s2;      // [6][256][192] diag(u) M2^T G6
     float* scratch_mv;      // [6][256]      diag(u) M2^T g
     int splits[4], ns;      // point ranges per product, as dpn_wgrad_kernel cut them
@@ -1580,8 +1580,8 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
 // dWd], 6 nets); the four waves take 64 of the 256 j each on the exact-fp32 matrix instruction (operands straight from global memory: both
 // are contiguous along the lane index) and their partial tiles are added in a fixed order through LDS.
 DEV f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-__global__ __launch_bounds__(256) void dpn_finish_vside_kernel(FinishArgs a) {
-    const int rt = blockIdx.x & 7, ctile = blockIdx.x >> 3, net = blockIdx.y;
+DEV void finish_vside_body(const FinishArgs& a, const int bx, float (&red)[4][16][64], float (&qs)[32]) {
+    const int rt = bx & 7, ctile = bx >> 3, net = blockIdx.y;
     const int kind = ctile < 8 ? 0 : ctile == 8 ? 1 : 2;                  // d w2 | vector column | dWd
     const DpnNetPtrs& P = a.net[net];
     const DpnNetGradPtrs& Gd = a.grad[net];
@@ -1608,8 +1608,6 @@ __global__ __launch_bounds__(256) void dpn_finish_vside_kernel(FinishArgs a) {
     }
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) acc = mfma_f32_32x32x2(av[kk], bv[kk], acc);
-    __shared__ float red[4][16][64];
-    __shared__ float qs[32];
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wv][r][lane] = acc[r];
     if (wv == 0 && kh == 0) qs[col] = qv[0];
@@ -1628,11 +1626,10 @@ __global__ __launch_bounds__(256) void dpn_finish_vside_kernel(FinishArgs a) {
 }
 
 // one block per (row o', net): dW2 = wo (x) r, dbf2, dwo, dbo
-__global__ __launch_bounds__(256) void dpn_finish_fc2_kernel(FinishArgs a) {
-    const int op = blockIdx.x, net = blockIdx.y, o = threadIdx.x;
+DEV void finish_fc2_body(const FinishArgs& a, const int op, float* red) {
+    const int net = blockIdx.y, o = threadIdx.x;
     const DpnNetPtrs& P = a.net[net];
     const DpnNetGradPtrs& Gd = a.grad[net];
-    __shared__ float red[256];
     float sq[2] = {0.f, 0.f};
     if (o == 0) {
         const int offv[2] = {kPartVec + 4 * 256, kPartVec + 1 * 256 + op};       // sum g: product 1; q: product 0
@@ -1654,6 +1651,16 @@ __global__ __launch_bounds__(256) void dpn_finish_fc2_kernel(FinishArgs a) {
         Gd.wo[op] = red[0] + P.bf2[op] * s + 2.f * q;
         if (op == 0) Gd.bo[0] = s;
     }
+}
+
+// ONE launch for the two independent consumers of dpn_finish_rows_kernel's results: blocks 0..119 = the W1^T diag(u) factor (what the
+// hyper-network's backward waits for), blocks 120..375 = the rank-1 fc.2 gradients -- side by side instead of one behind the other
+constexpr int kVsideBlocks = 8 * 15;
+__global__ __launch_bounds__(256) void dpn_finish_vside_fc2_kernel(FinishArgs a) {
+    __shared__ float red[4][16][64];
+    __shared__ float qs[32];
+    if ((int)blockIdx.x < kVsideBlocks) finish_vside_body(a, blockIdx.x, red, qs);
+    else finish_fc2_body(a, blockIdx.x - kVsideBlocks, &red[0][0][0]);
 }
 
 // ------------------------------------------------------------------------------------------------ small fp32 GEMM
@@ -2433,8 +2440,7 @@ int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_
     a.scratch_mv = a.scratch_s2 + (int64_t)kNets * 256 * 192;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(dpn_finish_vside_kernel, dim3(8 * 15, kNets), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dpn_finish_vside_fc2_kernel, dim3(kVsideBlocks + 256, kNets), dim3(256), 0, s, a);
     return ck(hipGetLastError());
 }
 
