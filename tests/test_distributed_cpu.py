@@ -152,6 +152,51 @@ def _worker_mismatch(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_ranges(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(5)
+    lin = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    params = list(lin.parameters())
+    owner = _FlatOwner(params, [2, 3, 1])
+    sync = GradientAllReduce(owner)
+    torch.manual_seed(60 + rank)
+    lin(torch.randn(6, 7)).pow(2).mean().backward()
+    owner.gather_gradients()
+    mine = owner.flat_gradients().clone()
+    sync.reduce_bucket(0, 2)                                     # the staged step's schedule: layout buckets 0 and 1 as ONE collective ...
+    sync.wait()
+    after_first = owner.flat_gradients().clone()
+    sync.reduce_bucket(2)                                        # ... then the last one
+    sync.wait()
+    q.put((rank, mine.tolist(), after_first.tolist(), owner.flat_gradients().tolist(), owner.bucket_bounds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_ranges_reduce_as_one_collective():
+    """reduce_bucket(i, end): the contiguous slice of layout buckets i .. end-1 is averaged by one all-reduce (StagedPdeStep.stage_buckets:
+    the statics' and the heads' buckets travel together), the buckets outside the range are untouched until their own call."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ranges, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, first0, fin0, bounds), (_, g1, first1, fin1, _) = out
+    g0, g1, first0, fin0, fin1 = (torch.tensor(v) for v in (g0, g1, first0, fin0, fin1))
+    mean = (g0 + g1) / 2
+    cut = bounds[1][1]                                           # end of layout bucket 1
+    assert torch.allclose(first0[:cut], mean[:cut], rtol=1e-6, atol=1e-8)
+    assert torch.equal(first0[cut:], g0[cut:])                   # bucket 2 not reduced yet
+    assert torch.allclose(fin0, mean, rtol=1e-6, atol=1e-8) and torch.equal(fin0, fin1)
+
+
 def test_flat_bucket_allreduce_refuses_mismatched_layouts():
     world = 2
     ctx = mp.get_context('spawn')
