@@ -1,4 +1,8 @@
 # One gpurun call that produces every file of profiles/ for the current round (copy gpurun_out/$R/* to profiles/round3_* afterwards).
+# Before the call, HERE (hipcc cross-compiles): rebuild the two experiment libraries the probes load, or they miss entry points added since --
+#   python tools/timeline_probe.py --build -DDPN_EXPERIMENT_SPLITS      (libdpn_hip_timeline.so: wgrad_overlap_probe.py's range plans)
+#   python tools/variant_build.py tl -DDPN_TIMELINE -DTS_TIMELINE       (libdpn_hip_tl.so: tiles_timeline.py)
+# and the micro-benchmarks under tools/microbench/ (hipcc --offload-arch=gfx950 -O3 -o X X.hip).
 set -x
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 R=gpurun_out/r3; mkdir -p $R
