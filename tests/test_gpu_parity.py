@@ -522,6 +522,47 @@ def test_full_grid_step_is_bitwise_deterministic():
         assert torch.equal(a_, b_)
 
 
+def test_lead_batch_backward_paths_agree():
+    """pde_losses_batch runs each field's point backward right behind its forward (unit cotangent of the field's total, scaled when the real
+    cotangent arrives).  Against it: the same function with the state parked until the backward pass (DPN_BATCH_EAGER_BACKWARD=0 path), and
+    the general path a cotangent on the individual loss terms takes (forward again) -- gradients of the heads, the lead-time embeddings and
+    two static tensors, all three ways."""
+    from deepphysinet_amd import point_path as PP
+    B, N = 3, 300
+    m = _model('bf16x2')
+    samples = [synthetic_inputs(N, GEO.lon, GEO.lat, GEO.dx, GEO.dy, tag='eager%d' % b, forecast_h=24.0 * b / 360.0) for b in range(B)]
+    g = [_gpu(s_) for s_ in samples]
+    x, y, t, f = (torch.stack([g_[k].reshape(-1) for g_ in g]) for k in ('x', 'y', 't', 'f'))
+    cd = torch.stack([g_['coord_data'] for g_ in g])
+    cfg = m.point_config()
+    with torch.no_grad():
+        hw = [m.physics_net.field_weights(g_['field_data'], g_['forecast_h']) for g_ in g]
+    heads0 = torch.stack([h[0] for h in hw])
+    evec0 = torch.stack([h[1] for h in hw])
+    statics = [s_.detach().clone().requires_grad_(True) for s_ in hw[0][2]]
+    wts = torch.tensor([0.5, 2.0, 1.25], device=_dev())
+
+    def run(eager, through_terms):
+        heads, evec = heads0.clone().requires_grad_(True), evec0.clone().requires_grad_(True)
+        old = PP._PdeLossBatchFn.EAGER
+        PP._PdeLossBatchFn.EAGER = eager
+        try:
+            losses, totals = PP.pde_losses_batch(cfg, x, y, t, f, cd, heads, evec, statics)
+            obj = (losses.sum(dim=1) * wts).sum() if through_terms else (totals * wts).sum()
+            got = torch.autograd.grad(obj, [heads, evec, statics[0], statics[2]])
+        finally:
+            PP._PdeLossBatchFn.EAGER = old
+        return [v.detach().clone() for v in got]
+
+    base = run(False, False)                                 # state parked, cotangents known before the point backward runs
+    for name, other in (('eager', run(True, False)), ('terms', run(True, True)), ('terms, parked', run(False, True))):
+        for a_, b_ in zip(base, other):
+            # the same kernels; the eager path multiplies by the cotangent AFTER the reductions instead of before (one rounding per element),
+            # the per-term path adds six cotangents where the other adds one total (the reference's summation order of the total differs
+            # from sum(dim=1) in the last bit)
+            assert float((a_ - b_).abs().max()) <= 2e-5 * float(a_.abs().max()), name
+
+
 def test_config2_lead_batch_in_one_step_equals_the_loop():
     """BASELINE configs[2] as ONE step: place_lead_batch over B field samples (batched encoder, per-field point kernels, fixed-order
     sums of the per-field parameter gradients) against (i) the CPU oracle per field and (ii) the same samples pushed one by one through
