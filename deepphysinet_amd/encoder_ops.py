@@ -354,6 +354,28 @@ class _HeadsFn(torch.autograd.Function):
         dev = m3.device
         heads = torch.empty((B, 256, HEADS_COLS), dtype=torch.float32, device=dev)
         evec = torch.empty((B, 6, 256), dtype=torch.float32, device=dev)
+        if B > 1 and os.environ.get('DPN_HEADS_PER_FIELD') != '1':      # (=1: the per-field launches of rounds 1-3, kept for A/B measurements)
+            # B fields: ONE launch over all of them (it was one per field: 61 launches of 15 us at configs[2]).  The encoder output of the
+            # fields is brought into [field * 256 + channel][token] order once (16 MB at B = 61), so that a head is ONE problem with
+            # B * 256 rows; the backward pass reuses the copy as the K-operand of the weight gradients.
+            acat = m3[:, :256, :].transpose(1, 2).contiguous().view(B * 256, 256)
+            problems, off = [], 0
+            for w, b in zip(hw, hb):                             # heads[f][c][off + j] = sum_tok meta[f][tok][c] W[j][tok] + b[j]
+                n_k = w.shape[0]
+                q = _problem(B * 256, n_k, 256, [(acat, 256, w, 256)], heads, HEADS_COLS, 0, 1, bias=b)
+                q.C = heads.data_ptr() + off * 4
+                problems.append(q)
+                off += n_k
+            for k, (w, b) in enumerate(zip(fw, fb)):             # evec[f][k] = fore_h_fc_k(pe_h[f])
+                q = _problem(B, 256, 192, [(pe2, 192, w, 192)], evec, 6 * 256, 0, 1, bias=b)
+                q.C = evec.data_ptr() + k * 256 * 4
+                problems.append(q)
+            _launch(problems)
+            ctx.save_for_backward(m3, pe2, acat, *hw)
+            ctx.batched = True
+            ctx.params = (hb, fw, fb)
+            return heads, evec
+        ctx.batched = False
         for f in range(B):
             m_ptr, h_ptr = m3.data_ptr() + f * Lt * 256 * 4, heads.data_ptr() + f * 256 * HEADS_COLS * 4
             problems, off = [], 0
@@ -375,6 +397,8 @@ class _HeadsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_heads, g_evec):
         from .linear import _launch, _problem
+        if ctx.batched:
+            return _HeadsFn._backward_batched(ctx, g_heads, g_evec)
         m3, pe2, *hw = ctx.saved_tensors
         dev = m3.device
         B, Lt = m3.shape[0], m3.shape[1]
@@ -428,4 +452,46 @@ class _HeadsFn(torch.autograd.Function):
             total = torch.empty(starts[-1], dtype=torch.float32, device=dev)
             L.check(lib.dpn_sum_parts(_p(flat), B, starts[-1], 0, _p(total), _s()), 'dpn_sum_parts')
             dest = [total[starts[i]:starts[i + 1]].view(shapes[i]) for i in range(36)]
+        return (d_meta, None, *dest)
+
+    @staticmethod
+    def _backward_batched(ctx, g_heads, g_evec):
+        """B > 1: two launches for all fields.  (1) d meta as ONE problem over the B * 256 (field, channel) rows -- twelve accumulated terms,
+        one per head --, transposed back into the encoder's [token][channel] order by one copy; (2) the twelve head-weight gradients and the
+        six fore_h_fc gradients as reductions over all fields at once (K = B * 256 resp. B): the sum over the fields happens inside the
+        GEMM's own fixed-order reduction, nothing is written per field and joined afterwards."""
+        from .linear import _launch, _problem
+        m3, pe2, acat, *hw = ctx.saved_tensors
+        dev = m3.device
+        B, Lt = m3.shape[0], m3.shape[1]
+        gh, ge = _c(g_heads), _c(g_evec)                          # [B, 256, 2700] = [(f, c)][j], [B, 6, 256]
+        offs, off = [], 0
+        for w in hw:
+            offs.append(off)
+            off += w.shape[0]
+        hb, fw, fb = ctx.params
+        shapes = [(w.shape[0], 256) for w in hw] + [(w.shape[0],) for w in hw] + [(256, 192)] * 6 + [(256,)] * 6
+        dest = [new_grad(t, shp) for t, shp in zip(list(hw) + list(hb) + list(fw) + list(fb), shapes)]
+        # (1) dmt[(f, c)][tok] = sum_k sum_j g[(f, c)][off_k + j] W_k[j][tok]
+        dmt = torch.empty((B * 256, 256), dtype=torch.float32, device=dev)
+        q0 = _problem(B * 256, 256, 256, [(gh, HEADS_COLS, hw[k], 256, hw[k].shape[0]) for k in range(12)], dmt, 256, 0, 0)
+        for k in range(12):
+            q0.A[k] = gh.data_ptr() + offs[k] * 4
+        _launch([q0])
+        d_meta = torch.empty(m3.shape, dtype=torch.float32, device=dev)
+        d_meta[:, :256, :].copy_(dmt.view(B, 256, 256).transpose(1, 2))
+        if Lt > 256:
+            d_meta[:, 256:, :].zero_()                           # tokens >= 256 feed no VariableNet
+        # (2) dW_k[j][tok] = sum_(f, c) g[(f, c)][off_k + j] acat[(f, c)][tok] ; db_k[j] = sum_(f, c) g[(f, c)][off_k + j]
+        problems = []
+        for k, w in enumerate(hw):
+            n_k = w.shape[0]
+            q = _problem(n_k, 256, B * 256, [(gh, HEADS_COLS, acat, 256)], dest[k], 256, 1, 0, asum=dest[12 + k])
+            q.A[0] = gh.data_ptr() + offs[k] * 4
+            problems.append(q)
+        for k in range(6):                                       # d fore_h_fc_k.weight[c][i] = sum_f g_evec[f][k][c] pe_h[f][i] ; bias: sum_f g_evec[f][k][c]
+            q = _problem(256, 192, B, [(ge, 6 * 256, pe2, 192)], dest[24 + k], 192, 1, 0, asum=dest[30 + k])
+            q.A[0] = ge.data_ptr() + k * 256 * 4
+            problems.append(q)
+        _launch(problems)
         return (d_meta, None, *dest)
