@@ -354,7 +354,9 @@ class _HeadsFn(torch.autograd.Function):
         dev = m3.device
         heads = torch.empty((B, 256, HEADS_COLS), dtype=torch.float32, device=dev)
         evec = torch.empty((B, 6, 256), dtype=torch.float32, device=dev)
-        if B > 1 and os.environ.get('DPN_HEADS_PER_FIELD') != '1':      # (=1: the per-field launches of rounds 1-3, kept for A/B measurements)
+        mode = os.environ.get('DPN_HEADS_PER_FIELD', '0')         # A/B measurements: 1 = the per-field launches of rounds 1-3; fwd / bwd = only that pass per field
+        ctx.per_field_bwd = B > 1 and mode in ('1', 'bwd')
+        if B > 1 and mode not in ('1', 'fwd'):
             # B fields: ONE launch over all of them (it was one per field: 61 launches of 15 us at configs[2]).  The encoder output of the
             # fields is brought into [field * 256 + channel][token] order once (16 MB at B = 61), so that a head is ONE problem with
             # B * 256 rows; the backward pass reuses the copy as the K-operand of the weight gradients.
@@ -373,9 +375,11 @@ class _HeadsFn(torch.autograd.Function):
             _launch(problems)
             ctx.save_for_backward(m3, pe2, acat, *hw)
             ctx.batched = True
+            ctx.has_acat = True
             ctx.params = (hb, fw, fb)
             return heads, evec
-        ctx.batched = False
+        ctx.batched = B > 1
+        ctx.has_acat = False
         for f in range(B):
             m_ptr, h_ptr = m3.data_ptr() + f * Lt * 256 * 4, heads.data_ptr() + f * 256 * HEADS_COLS * 4
             problems, off = [], 0
@@ -397,9 +401,12 @@ class _HeadsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_heads, g_evec):
         from .linear import _launch, _problem
-        if ctx.batched:
+        if ctx.batched and not ctx.per_field_bwd:
             return _HeadsFn._backward_batched(ctx, g_heads, g_evec)
-        m3, pe2, *hw = ctx.saved_tensors
+        if ctx.has_acat:
+            m3, pe2, _, *hw = ctx.saved_tensors
+        else:
+            m3, pe2, *hw = ctx.saved_tensors
         dev = m3.device
         B, Lt = m3.shape[0], m3.shape[1]
         lib = L.load()
@@ -461,7 +468,11 @@ class _HeadsFn(torch.autograd.Function):
         six fore_h_fc gradients as reductions over all fields at once (K = B * 256 resp. B): the sum over the fields happens inside the
         GEMM's own fixed-order reduction, nothing is written per field and joined afterwards."""
         from .linear import _launch, _problem
-        m3, pe2, acat, *hw = ctx.saved_tensors
+        if ctx.has_acat:
+            m3, pe2, acat, *hw = ctx.saved_tensors
+        else:
+            m3, pe2, *hw = ctx.saved_tensors
+            acat = m3[:, :256, :].transpose(1, 2).contiguous().view(m3.shape[0] * 256, 256)
         dev = m3.device
         B, Lt = m3.shape[0], m3.shape[1]
         gh, ge = _c(g_heads), _c(g_evec)                          # [B, 256, 2700] = [(f, c)][j], [B, 6, 256]
