@@ -337,7 +337,7 @@ HEADS_COLS = sum(HEAD_WIDTHS)
 class _HeadsFn(torch.autograd.Function):
     """The twelve hyper-network heads and the six lead-time embeddings of a PhysicsNet (model/variable_net.py:57-65,75-78), per field
     sample ONE launch forward (18 GEMM problems reading the encoder output transposed in place) and two launches backward (the input
-    gradient as four 3-term problems joined by dpn_sum_parts, twelve weight gradients with their bias sums, six outer products).
+    gradient as six 2-term problems joined by dpn_sum_parts, twelve weight gradients with their bias sums, six outer products).
     inputs: meta [B, L, 256] (tokens 0..255 are used), pe_h [B, 192], 12 head weights, 12 head biases, 6 fore_h_fc weights, 6 biases
     -> heads [B, 256, 2700] = [w1b1 of nets 0..5 | w2b2 of nets 0..5] per hidden channel, evec [B, 6, 256].
     With B > 1 the parameter gradients of the fields are written side by side and added in a fixed order by one dpn_sum_parts."""
@@ -430,15 +430,19 @@ class _HeadsFn(torch.autograd.Function):
                 starts.append(starts[-1] + int(torch.Size(shp).numel()))
             flat = torch.empty((B, starts[-1]), dtype=torch.float32, device=dev)
             ptrs = [[flat.data_ptr() + (f * starts[-1] + starts[i]) * 4 for i in range(36)] for f in range(B)]
-        parts = torch.empty((4, 256, 256), dtype=torch.float32, device=dev)
+        # d meta as NP accumulated-term problems side by side, joined by dpn_sum_parts: 6 two-term problems (with the 12 weight gradients and
+        # the 6 outer products exactly the 24 problems a launch takes).  Same box, 300-step runs, three times each: NP = 2 1.614 ms per
+        # step, 3 1.591, 4 1.614 (rounds 1-3), 6 1.580
+        NP = int(os.environ.get('DPN_HEADS_DMETA_PARTS', '6'))
+        parts = torch.empty((NP, 256, 256), dtype=torch.float32, device=dev)
         n_tail = (Lt - 256) * 256                                # tokens >= 256 feed no VariableNet: their gradient rows are zero
         for f in range(B):
             g_ptr, m_ptr = gh.data_ptr() + f * 256 * HEADS_COLS * 4, m3.data_ptr() + f * Lt * 256 * 4
-            # d_meta[tok][c] = sum_k sum_j W_k[j][tok] g[c][off_k + j]: a 12-term problem would walk 24 k-tiles in sequence, so four
-            # 3-term problems run side by side and dpn_sum_parts joins them
+            # d_meta[tok][c] = sum_k sum_j W_k[j][tok] g[c][off_k + j]: a 12-term problem would walk 24 k-tiles in sequence, so NP
+            # problems of 12 / NP terms run side by side and dpn_sum_parts joins them
             problems = []
-            for p_ in range(4):
-                grp = list(range(3 * p_, 3 * p_ + 3))
+            for p_ in range(NP):
+                grp = list(range((12 // NP) * p_, (12 // NP) * (p_ + 1)))
                 q0 = _problem(256, 256, 256, [(hw[k], 256, gh, HEADS_COLS, hw[k].shape[0]) for k in grp], parts, 256, 1, 1)
                 q0.C = parts.data_ptr() + p_ * 256 * 256 * 4
                 for i, k in enumerate(grp):
@@ -454,7 +458,7 @@ class _HeadsFn(torch.autograd.Function):
                 q.A[0], q.B[0], q.C, q.asum = ge.data_ptr() + (f * 6 + k) * 256 * 4, pe2.data_ptr() + f * 192 * 4, ptrs[f][24 + k], ptrs[f][30 + k]
                 problems.append(q)
             _launch(problems)
-            L.check(lib.dpn_sum_parts(_p(parts), 4, 256 * 256, n_tail, ctypes.c_void_p(d_meta.data_ptr() + f * Lt * 256 * 4), _s()), 'dpn_sum_parts')
+            L.check(lib.dpn_sum_parts(_p(parts), NP, 256 * 256, n_tail, ctypes.c_void_p(d_meta.data_ptr() + f * Lt * 256 * 4), _s()), 'dpn_sum_parts')
         if B > 1:
             total = torch.empty(starts[-1], dtype=torch.float32, device=dev)
             L.check(lib.dpn_sum_parts(_p(flat), B, starts[-1], 0, _p(total), _s()), 'dpn_sum_parts')
