@@ -51,6 +51,23 @@ class DpnColsumJob(Structure):
     _fields_ = [('partial', c_void_p), ('out_a', c_void_p), ('out_b', c_void_p), ('n_blocks', c_int32)]
 
 
+class DpnEncFwd(Structure):
+    """include/dpn_hip.h DpnEncFwd: one row-local forward launch of the encoder (csrc/dpn_encoder_chain.hip)."""
+    _fields_ = [('wpack', c_void_p)] + [(n, c_int32) for n in ('n_mats', 'rows', 'row_tiles', 'tail', 'next', 'm_o', 'm_c1', 'm_c2', 'm_n0', 'm_n1', 'm_n2')] + \
+               [(n, c_void_p) for n in ('o', 'x', 'xin', 'bo', 'g1', 'be1', 'bc1', 'bc2', 'g2', 'be2', 'gf', 'bef', 'bn0', 'bn1', 'bn2',
+                                        'x1', 'xhat1', 'rstd1', 'pre', 'act', 'x2', 'xhat2', 'rstd2', 'xf', 'xhatf', 'rstdf', 'y0', 'y1', 'y2')]
+
+
+class DpnEncBwd(Structure):
+    _fields_ = [('wpack', c_void_p)] + [(n, c_int32) for n in ('n_mats', 'rows', 'row_tiles', 'head', 'body', 'm_h0', 'm_h1', 'm_h2', 'm_c2', 'm_c1', 'm_o')] + \
+               [(n, c_void_p) for n in ('res', 'dq', 'dk', 'dv', 'dmeta', 'xhatf', 'rstdf', 'gin', 'xhat2', 'rstd2', 'pre', 'xhat1', 'rstd1', 'g2', 'g1', 'gf',
+                                        'gs2', 'dpre', 'gs1', 'dout', 'gx', 'partial_f', 'partial2', 'partial1')]
+
+
+ENC_MAX_MATS = 32
+GEMM_MAX_PROBLEMS, GEMM_MAX_JOBS = 26, 10
+
+
 class DpnSampler(Structure):
     _fields_ = [('lon', c_int32), ('lat', c_int32), ('lon_in', c_int32), ('lat_in', c_int32), ('t_in', c_int32), ('t_hours', c_int32),
                 ('cells_x', c_double), ('cells_y', c_double), ('t_step_hours', c_double), ('begin_lat', c_double), ('dlat', c_double),
@@ -89,6 +106,10 @@ EXPORTS = {
     'dpn_sgemm_batch': (c_int, [c_int, POINTER(DpnGemmProblem), c_void_p]),
     'dpn_attn_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'dpn_attn_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_enc_pack_bytes': (c_int64, [c_int]),
+    'dpn_enc_pack': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_enc_fwd': (c_int, [POINTER(DpnEncFwd), c_void_p]),
+    'dpn_enc_bwd': (c_int, [POINTER(DpnEncBwd), c_void_p]),
     'dpn_add_ln_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_add_ln_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_clip_adam_scratch_doubles': (c_int64, [c_int, c_void_p]),

@@ -9,7 +9,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, 'csrc', 'dpn_kernels.hip'), os.path.join(HERE, 'csrc', 'dpn_encoder.hip'),
-        os.path.join(HERE, 'csrc', 'dpn_sampler.hip'), os.path.join(HERE, 'csrc', 'dpn_fp8.hip')]
+        os.path.join(HERE, 'csrc', 'dpn_sampler.hip'), os.path.join(HERE, 'csrc', 'dpn_fp8.hip'),
+        os.path.join(HERE, 'csrc', 'dpn_encoder_chain.hip')]
 DEPS = SRCS + [os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(HERE, 'csrc', 'dpn_fwd_tiles.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h')]
 LIB = os.path.join(HERE, 'libdpn_hip.so')
 
@@ -28,7 +29,8 @@ UNITS = [(SRCS[0], ['-DDPN_TU=1', '-mllvm', '-amdgpu-mfma-vgpr-form'], 'dpn_poin
          (SRCS[0], ['-DDPN_TU=2'], 'dpn_rest.o'),
          (SRCS[1], [], 'dpn_encoder.o'),
          (SRCS[2], [], 'dpn_sampler.o'),
-         (SRCS[3], [], 'dpn_fp8.o')]
+         (SRCS[3], [], 'dpn_fp8.o'),
+         (SRCS[4], ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'dpn_encoder_chain.o')]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 
@@ -41,7 +43,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     obj_dir = os.path.join(HERE, 'csrc', '_obj')
     os.makedirs(obj_dir, exist_ok=True)
     procs = []
-    for src, flags, obj in UNITS:                                   # the four units compile side by side
+    for src, flags, obj in UNITS:                                   # the units compile side by side
         cmd = [hipcc, *COMMON, *flags, '-I' + os.path.join(os.path.dirname(HERE), 'include'), '-c', src, '-o', os.path.join(obj_dir, obj)]
         if verbose:
             print(' '.join(cmd))

@@ -1,0 +1,799 @@
+// Row-local fused nodes of the grid encoder ("MetaNet") for MI355X.
+//
+// Reference behaviour (paths relative to /root/reference/DeepPhysiNet):
+//   model/attn.py:177-196            q/k/v and out projections of an AttentionLayer
+//   model/transformer_net.py:28-44   x1 = norm1(x + attn_out);  out = norm2(x1 + conv2(gelu(conv1(x1))))   (1x1 convolutions = per-token linears)
+//   model/transformer_net.py:54-72   encoder.norm after the last layer;  :129 the output projection
+// Everything in an encoder layer except the attention itself is ROW-LOCAL: a token row never needs another row.  dpn_enc_fwd / dpn_enc_bwd
+// therefore run the whole stretch between two attention kernels as ONE launch: a workgroup owns 16 (or 32) token rows and carries them through
+//   forward :  out-projection + residual + LayerNorm1 + conv1 + GELU + conv2 + residual + LayerNorm2 + the NEXT layer's q/k/v projections
+//              (or encoder.norm + the output projection behind the last layer)
+//   backward:  d x = residual cotangent + dq Wq + dk Wk + dv Wv  (or the projection / encoder.norm backward), LayerNorm2 backward, conv2^T,
+//              GELU', conv1^T + residual, LayerNorm1 backward, out-projection^T (the attention backward's input)
+// with the row block in LDS / registers between the GEMMs; it writes exactly what the backward pass and the weight-gradient GEMMs need.
+// (Round 3 ran this stretch as five launches forward and four backward per layer: 31.6 us / layer forward on 287 x 256 tensors.)
+//
+// Arithmetic: the 256 x 256 GEMMs run on v_mfma_f32_16x16x32_f16 with BOTH operands split in two f16 values,
+//     x = hi + 2^-11 lo',   hi = f16(x),  lo' = f16(2^11 (x - hi))        (22 significant bits; round-to-nearest both times)
+//     x.w ~ hi.hi + 2^-11 (hi.lo' + lo'.hi)                                (three products, fp32 accumulate, two accumulators)
+// fp32-class: tools/precision_encoder_split.py -- encoder output 1e-6 of the fp64 run, like torch's own fp32 run (bf16 hi+lo: 1.2e-5;
+// bf16 needs a three-way split = six products).  Activation rows are scaled by a power of two per token (row maximum into [8, 16)) before
+// the split, so any magnitude (backward cotangents carry loss factors up to 1e14) stays inside f16's range; weights are split unscaled by
+// dpn_enc_pack, which raises a status flag for |w| >= 32768 (a 256-wide linear layer with such weights has no fp32 meaning either).
+// LayerNorm, GELU (exact erf), residual adds, biases: fp32 on the row block, the reference's formulas (two-pass variance, eps 1e-5).
+//
+// Weight stream: dpn_enc_pack writes every matrix as MFMA A-fragments in consumption order (per 16-channel tile and 32-wide k-step: hi
+// plane, lo plane, 1 KB each), once for x W^T (forward) and once for g W (backward).  A workgroup streams the images of its six GEMMs
+// (1.5 MB) from L2 straight into registers (buffer_load_dwordx4 with a scalar running offset), kPF k-steps ahead and ACROSS the row passes
+// and barriers between the GEMMs (LDS-only barriers: vmcnt stays in flight).  That stream at the CU's ~55 B/clk L2 path is the kernel's
+// bound (~12 us per launch); the MFMAs (2 304 per workgroup) take a third of it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dpn_hip.h"
+
+#define DEV __device__ __forceinline__
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 256;
+constexpr int kThreads = 512, kWaves = 8;
+constexpr int kImgBytes = 256 * 1024;            // one packed 256 x 256 image: [tile 16][k-step 8][hi | lo][lane 64][16 B]
+constexpr int kPF = 4;                           // weight fragments in flight: k-steps ahead (4 KB per wave and k-step)
+constexpr int kYS = 260;                         // row stride (floats) of the fp32 staging block
+constexpr int kXImg = 16384;                     // X image of 16 tokens: [hi | lo][slot 32][position 16][16 B]
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+DEV void barrier_lds() {                         // LDS-only workgroup barrier: global loads (weight prefetch) and stores stay in flight
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// ---- all-reduce over the 32 lanes of a half wave (a token row lives in one half: 32 lanes x 8 channels)
+template <int CTRL>
+DEV float dpp(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false)); }
+DEV float swz16(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)); }   // lane ^ 16
+DEV float half_sum(float v) {                    // fixed order: the same tree for every row
+    v += dpp<0xB1>(v);                           // quad_perm [1,0,3,2]
+    v += dpp<0x4E>(v);                           // quad_perm [2,3,0,1]
+    v += dpp<0x141>(v);                          // row_half_mirror: the other quad of the 8
+    v += dpp<0x140>(v);                          // row_mirror: the other 8 of the 16
+    v += swz16(v);
+    return v;
+}
+DEV float half_max(float v) {
+    v = fmaxf(v, dpp<0xB1>(v));
+    v = fmaxf(v, dpp<0x4E>(v));
+    v = fmaxf(v, dpp<0x141>(v));
+    v = fmaxf(v, dpp<0x140>(v));
+    v = fmaxf(v, swz16(v));
+    return v;
+}
+
+// exact-erf GELU and its derivative (torch's GeluCUDAKernelImpl / GeluBackwardCUDAKernelImpl, approximate='none'; transformer_net.py:26,41)
+DEV float gelu_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+DEV float gelu_exact_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
+    return cdf + x * pdf;
+}
+
+// ---- split: v -> hi + 2^-11 lo' (two f16 planes of eight values = one 16-byte fragment slot each)
+DEV void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 a = (_Float16)v[e];
+        h[e] = a;
+        l[e] = (_Float16)((v[e] - (float)a) * kLoScale);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+// X image position of (slot = k / 8, token n): quad index slot * 16 + (n ^ F(slot & 7)), F = {0,1,2,3,12,13,14,15}.  The readers (B fragments:
+// lane = (n, g), slot 4 ks + g) touch 16 distinct bank quads per ds_read_b128 lane group with any F that is constant per k-step up to an
+// XOR preserving {0-3,12-15} / {4-11}; the writers (8 consecutive slots of ONE token per ds_write_b128 lane group) get 8 distinct quads.
+DEV int xpos(int slot, int n) { return slot * 16 + (n ^ ((slot & 3) | ((slot & 4) ? 12 : 0))); }
+
+// Row-pass lane mapping: wave w, lane l -> token 2 w + (l >> 5) of each 16-token tile, channels 8 (l & 31) .. + 7.
+struct RowLane {
+    int tsel, slot, n16;                         // n16: token inside a 16-token tile
+    DEV RowLane(int wave, int lane) : tsel(lane >> 5), slot(lane & 31), n16(2 * wave + (lane >> 5)) {}
+};
+
+// scale the row so that its maximum lands in [8, 16), split it and store it as the B-fragment image of its tile; the inverse scale goes to rscale
+// (exponent arithmetic on the bits: powers of two, exact)
+DEV void row_to_ximg(const float (&v)[8], const float extra_max, const RowLane& rl, char* ximg_tile, float* rscale_tile) {
+    float m = extra_max;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+    m = half_max(m);
+    int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
+    eb = eb < 4 ? 4 : eb;                                                   // zero / tiny rows: any scale does
+    const float sc = __builtin_bit_cast(float, (257 - eb) << 23);           // 2^(3 - (eb - 127))
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = v[e] * sc;
+    u32x4 hi, lo;
+    split8(s, hi, lo);
+    char* p = ximg_tile + xpos(rl.slot, rl.n16) * 16;
+    *reinterpret_cast<u32x4*>(p) = hi;
+    *reinterpret_cast<u32x4*>(p + kXImg / 2) = lo;
+    if (rl.slot == 0) rscale_tile[rl.n16] = __builtin_bit_cast(float, (eb - 3) << 23);   // 2^((eb - 127) - 3)
+}
+DEV float row_absmax(const float (&v)[8]) {
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+    return m;
+}
+
+DEV void load8(float (&v)[8], const float* p, bool ok) {
+    if (ok) {
+        const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+}
+DEV void store8(float* p, const float (&v)[8], bool ok) {
+    if (ok) {
+        reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+DEV void lds8(float (&v)[8], const float* p) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+// LayerNorm over the 256 channels of the lane's row (nn.LayerNorm: biased variance, eps 1e-5, two passes)
+DEV void layer_norm8(const float (&v)[8], const float (&gam)[8], const float (&bet)[8], float (&xhat)[8], float (&y)[8], float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    const float mean = half_sum(s) * (1.f / kD);
+    float d[8], q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { d[e] = v[e] - mean; q = fmaf(d[e], d[e], q); }
+    rstd = 1.0f / sqrtf(half_sum(q) * (1.f / kD) + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xhat[e] = d[e] * rstd; y[e] = fmaf(xhat[e], gam[e], bet[e]); }
+}
+// its input gradient: gx = rstd (g gamma - mean(g gamma) - xhat mean(g gamma xhat)); the parameter sums g xhat, g accumulate into pg / pb
+DEV void layer_norm_bwd8(const float (&g)[8], const float (&xhat)[8], const float rstd, const float (&gam)[8], float (&gx)[8], float (&pg)[8],
+                         float (&pb)[8]) {
+    float t[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { t[e] = g[e] * gam[e]; s1 += t[e]; s2 = fmaf(t[e], xhat[e], s2); pg[e] = fmaf(g[e], xhat[e], pg[e]); pb[e] += g[e]; }
+    const float m1 = half_sum(s1) * (1.f / kD), m2 = half_sum(s2) * (1.f / kD);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gx[e] = rstd * (t[e] - m1 - xhat[e] * m2);
+}
+
+// ---- the weight stream of a wave: tiles 2 w, 2 w + 1 of every image, [k-step][hi | lo] 1 KB fragments
+struct WStream {
+    __amdgpu_buffer_rsrc_t rs;
+    int voff, tile_off;
+    DEV void init(const void* wpack, int64_t bytes, int wave, int lane) {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wpack), 0, (int)bytes, 0x00020000);
+        voff = lane * 16;
+        tile_off = wave * 2 * 16384;
+    }
+    DEV void load(u32x4 (&dst)[2][2], int img_off, int ks) const {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                dst[t][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + p * 1024, img_off + tile_off + t * 16384 + ks * 2048, 0));
+    }
+};
+struct Ring { u32x4 a[kPF][2][2]; };
+
+DEV f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int NTT>
+struct Acc {
+    f32x4 m[2][NTT], c[2][NTT];                  // main (hi.hi) and cross (hi.lo' + lo'.hi) accumulators of the wave's two channel tiles
+    DEV void zero() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) { m[t][tt] = (f32x4)0.f; c[t][tt] = (f32x4)0.f; }
+    }
+};
+
+// acc += W[wave's 32 channels][256] . X^T[256][16 NTT tokens]: eight k-steps; the ring holds this image's k-steps 0 .. kPF-1 on entry and the next
+// image's on exit (HAS_NEXT).  xr0 / xr1: the lane's read bases in the X image for even / odd k-steps.
+template <int NTT, bool HAS_NEXT>
+DEV void gemm(const WStream& ws, Ring& R, const int cur_off, const int next_off, const char* xr0, const char* xr1, Acc<NTT>& acc) {
+    u32x4 B[2][NTT][2];
+    auto loadB = [&](const int ks, const int buf) __attribute__((always_inline)) {
+        const char* base = ((ks & 1) ? xr1 : xr0) + ks * 1024;
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            B[buf][tt][0] = *reinterpret_cast<const u32x4*>(base + tt * kXImg);
+            B[buf][tt][1] = *reinterpret_cast<const u32x4*>(base + tt * kXImg + kXImg / 2);
+        }
+    };
+    loadB(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) loadB(ks + 1, (ks + 1) & 1);
+        const int s = ks % kPF, b = ks & 1;
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc.m[t][tt] = mfma(R.a[s][t][0], B[b][tt][0], acc.m[t][tt]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc.c[t][tt] = mfma(R.a[s][t][0], B[b][tt][1], acc.c[t][tt]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc.c[t][tt] = mfma(R.a[s][t][1], B[b][tt][0], acc.c[t][tt]);
+        }
+        if (ks + kPF < 8) ws.load(R.a[s], cur_off, ks + kPF);
+        else if (HAS_NEXT) ws.load(R.a[s], next_off, ks + kPF - 8);
+    }
+}
+
+// accumulator element (tile t, token tile tt, register j) = channel 32 w + 16 t + 4 g + j of token 16 tt + (lane & 15), g = lane >> 4
+template <int NTT>
+DEV void acc_to_staging(const Acc<NTT>& acc, float* Y, const float* rscale, int wave, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const float rs = rscale[tt * 16 + n];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(acc.c[t][tt][j], kLoInv, acc.m[t][tt][j]) * rs;
+            *reinterpret_cast<f32x4*>(Y + (tt * 16 + n) * kYS + wave * 32 + t * 16 + g * 4) = v;
+        }
+    }
+}
+// the same values (+ bias) straight to a [rows][256] tensor in global memory
+template <int NTT>
+DEV void acc_to_global(const Acc<NTT>& acc, float* out, const float* bias_lds, const float* rscale, int row0, int rows, int wave, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const float rs = rscale[tt * 16 + n];
+        const int row = row0 + tt * 16 + n;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ch = wave * 32 + t * 16 + g * 4;
+            f32x4 b = (f32x4)0.f;
+            if (bias_lds) b = *reinterpret_cast<const f32x4*>(bias_lds + ch);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(acc.c[t][tt][j], kLoInv, acc.m[t][tt][j]) * rs + b[j];
+            if (row < rows) *reinterpret_cast<f32x4*>(out + (int64_t)row * kD + ch) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+constexpr int kNVecF = 12;
+enum { VF_BO = 0, VF_G1, VF_BE1, VF_BC1, VF_BC2, VF_G2, VF_BE2, VF_GF, VF_BEF, VF_BN0, VF_BN1, VF_BN2 };
+struct FwdArgs {
+    const void* wpack;
+    int64_t wbytes;
+    int img[6];                                  // byte offsets of the images in consumption order
+    int rows;
+    const float *o, *x, *xin;
+    const float* vec[kNVecF];
+    float *x1, *xhat1, *rstd1, *pre, *act, *x2, *xhat2, *rstd2, *xf, *xhatf, *rstdf, *y0, *y1, *y2;
+};
+template <int NTT>
+struct Lds {
+    static constexpr int kX = 0;                                     // X images (up to three in the backward head)
+    static constexpr int kY = 3 * NTT * kXImg;
+    static constexpr int kVec = kY + NTT * 16 * kYS * 4;
+    static constexpr int kRs = kVec + kNVecF * 256 * 4;
+    static constexpr int kRed = kRs + NTT * 16 * 4;                  // [wave][512]: LayerNorm parameter partial sums (backward)
+    static constexpr int kBytes = kRed + kWaves * 512 * 4;
+};
+
+template <bool TAIL, int NEXT, int NTT>
+__global__ __launch_bounds__(kThreads) void dpn_enc_fwd_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ximg = smem + Lds<NTT>::kX;
+    float* Y = reinterpret_cast<float*>(smem + Lds<NTT>::kY);
+    float* vecs = reinterpret_cast<float*>(smem + Lds<NTT>::kVec);
+    float* rscale = reinterpret_cast<float*>(smem + Lds<NTT>::kRs);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * 16 * NTT;
+    WStream ws;
+    ws.init(a.wpack, a.wbytes, wave, lane);
+    Ring R;
+#pragma unroll
+    for (int ks = 0; ks < kPF; ++ks) ws.load(R.a[ks], a.img[0], ks);
+    for (int i = tid; i < kNVecF * 64; i += kThreads) {
+        const float* src = a.vec[i >> 6];
+        if (src) reinterpret_cast<float4*>(vecs)[i] = reinterpret_cast<const float4*>(src)[i & 63];
+    }
+    const RowLane rl(wave, lane);
+    const int n_r = lane & 15, g_r = lane >> 4;
+    const char* xr0 = ximg + (g_r * 16 + (n_r ^ g_r)) * 16;
+    const char* xr1 = ximg + (g_r * 16 + (n_r ^ g_r ^ 12)) * 16;
+    float res[NTT][8];
+    bool ok[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const int row = row0 + tt * 16 + rl.n16;
+        ok[tt] = row < a.rows;
+        float v[8];
+        load8(v, (TAIL ? a.o : a.xin) + (int64_t)row * kD + rl.slot * 8, ok[tt]);
+        if constexpr (TAIL) load8(res[tt], a.x + (int64_t)row * kD + rl.slot * 8, ok[tt]);
+        row_to_ximg(v, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+    }
+    barrier_lds();
+    Acc<NTT> acc;
+    constexpr int kFirstNext = TAIL ? 3 : 0;
+    if constexpr (TAIL) {
+        // ---- out-projection, residual, LayerNorm1 (attn.py:196, transformer_net.py:33-37)
+        acc.zero();
+        gemm<NTT, true>(ws, R, a.img[0], a.img[1], xr0, xr1, acc);
+        acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
+        barrier_lds();
+        {
+            float gam[8], bet[8], bo[8];
+            lds8(bo, vecs + VF_BO * 256 + rl.slot * 8); lds8(gam, vecs + VF_G1 * 256 + rl.slot * 8); lds8(bet, vecs + VF_BE1 * 256 + rl.slot * 8);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
+                float v[8], xh[8], y[8], rstd;
+                lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = res[tt][e] + (v[e] + bo[e]);
+                layer_norm8(v, gam, bet, xh, y, rstd);
+                store8(a.x1 + off, y, ok[tt]);
+                store8(a.xhat1 + off, xh, ok[tt]);
+                if (ok[tt] && rl.slot == 0) a.rstd1[row0 + tt * 16 + rl.n16] = rstd;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[tt][e] = y[e];
+                row_to_ximg(y, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+            }
+        }
+        barrier_lds();
+        // ---- conv1 + GELU (transformer_net.py:38-41)
+        acc.zero();
+        gemm<NTT, true>(ws, R, a.img[1], a.img[2], xr0, xr1, acc);
+        acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
+        barrier_lds();
+        {
+            float b1[8];
+            lds8(b1, vecs + VF_BC1 * 256 + rl.slot * 8);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
+                float v[8], h[8];
+                lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] += b1[e]; h[e] = gelu_exact(v[e]); }
+                store8(a.pre + off, v, ok[tt]);
+                store8(a.act + off, h, ok[tt]);
+                row_to_ximg(h, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+            }
+        }
+        barrier_lds();
+        // ---- conv2, residual, LayerNorm2 (transformer_net.py:42-44) (+ encoder.norm behind the last layer, :68)
+        acc.zero();
+        gemm<NTT, NEXT != 0>(ws, R, a.img[2], a.img[3], xr0, xr1, acc);
+        acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
+        barrier_lds();
+        {
+            float gam[8], bet[8], b2[8];
+            lds8(b2, vecs + VF_BC2 * 256 + rl.slot * 8); lds8(gam, vecs + VF_G2 * 256 + rl.slot * 8); lds8(bet, vecs + VF_BE2 * 256 + rl.slot * 8);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
+                float v[8], xh[8], y[8], rstd;
+                lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = res[tt][e] + (v[e] + b2[e]);
+                layer_norm8(v, gam, bet, xh, y, rstd);
+                store8(a.x2 + off, y, ok[tt]);
+                store8(a.xhat2 + off, xh, ok[tt]);
+                if (ok[tt] && rl.slot == 0) a.rstd2[row0 + tt * 16 + rl.n16] = rstd;
+                if constexpr (NEXT == 2) {
+                    float gf[8], bf[8], xh2[8], y2[8], rstdf;
+                    lds8(gf, vecs + VF_GF * 256 + rl.slot * 8); lds8(bf, vecs + VF_BEF * 256 + rl.slot * 8);
+                    layer_norm8(y, gf, bf, xh2, y2, rstdf);
+                    store8(a.xf + off, y2, ok[tt]);
+                    store8(a.xhatf + off, xh2, ok[tt]);
+                    if (ok[tt] && rl.slot == 0) a.rstdf[row0 + tt * 16 + rl.n16] = rstdf;
+                    row_to_ximg(y2, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+                } else if constexpr (NEXT == 1) {
+                    row_to_ximg(y, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+                }
+            }
+        }
+        if constexpr (NEXT != 0) barrier_lds();
+    }
+    if constexpr (NEXT == 1) {
+        // ---- the next layer's q / k / v projections (attn.py:183-185): three GEMMs on the same row block, straight to global memory
+        acc.zero();
+        gemm<NTT, true>(ws, R, a.img[kFirstNext], a.img[kFirstNext + 1], xr0, xr1, acc);
+        acc_to_global<NTT>(acc, a.y0, vecs + VF_BN0 * 256, rscale, row0, a.rows, wave, lane);
+        acc.zero();
+        gemm<NTT, true>(ws, R, a.img[kFirstNext + 1], a.img[kFirstNext + 2], xr0, xr1, acc);
+        acc_to_global<NTT>(acc, a.y1, vecs + VF_BN1 * 256, rscale, row0, a.rows, wave, lane);
+        acc.zero();
+        gemm<NTT, false>(ws, R, a.img[kFirstNext + 2], 0, xr0, xr1, acc);
+        acc_to_global<NTT>(acc, a.y2, vecs + VF_BN2 * 256, rscale, row0, a.rows, wave, lane);
+    } else if constexpr (NEXT == 2) {
+        // ---- the output projection (transformer_net.py:129)
+        acc.zero();
+        gemm<NTT, false>(ws, R, a.img[kFirstNext], 0, xr0, xr1, acc);
+        acc_to_global<NTT>(acc, a.y0, vecs + VF_BN0 * 256, rscale, row0, a.rows, wave, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+enum { VB_G2 = 0, VB_G1, VB_GF };
+struct BwdArgs {
+    const void* wpack;
+    int64_t wbytes;
+    int img[6];
+    int rows;
+    const float *res, *dq, *dk, *dv;             // HEAD 1
+    const float *dmeta, *xhatf, *rstdf;          // HEAD 2
+    const float* gin;                            // HEAD 0
+    const float *xhat2, *rstd2, *pre, *xhat1, *rstd1;
+    const float* vec[3];
+    float *gs2, *dpre, *gs1, *dout, *gx;
+    float *partial_f, *partial2, *partial1;      // [workgroups][512]: sums over the workgroup's rows of g xhat | g
+};
+
+// the wave's LayerNorm parameter partials (lanes 0-31 after joining the two token halves) -> red[wave][512]
+DEV void partials_to_lds(float (&pg)[8], float (&pb)[8], float* red, int wave, int lane) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pg[e] += __shfl_xor(pg[e], 32); pb[e] += __shfl_xor(pb[e], 32); }
+    if (lane < 32) {
+        float* r = red + wave * 512 + lane * 8;
+        reinterpret_cast<f32x4*>(r)[0] = (f32x4){pg[0], pg[1], pg[2], pg[3]};
+        reinterpret_cast<f32x4*>(r)[1] = (f32x4){pg[4], pg[5], pg[6], pg[7]};
+        reinterpret_cast<f32x4*>(r + 256)[0] = (f32x4){pb[0], pb[1], pb[2], pb[3]};
+        reinterpret_cast<f32x4*>(r + 256)[1] = (f32x4){pb[4], pb[5], pb[6], pb[7]};
+    }
+}
+DEV void partials_to_global(const float* red, float* partial, int tid) {        // fixed order over the eight waves
+    float s = red[tid];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += red[w * 512 + tid];
+    partial[(int64_t)blockIdx.x * 512 + tid] = s;
+}
+
+template <int HEAD, bool BODY, int NTT>
+__global__ __launch_bounds__(kThreads) void dpn_enc_bwd_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ximg = smem + Lds<NTT>::kX;
+    float* Y = reinterpret_cast<float*>(smem + Lds<NTT>::kY);
+    float* vecs = reinterpret_cast<float*>(smem + Lds<NTT>::kVec);
+    float* rscale = reinterpret_cast<float*>(smem + Lds<NTT>::kRs);
+    float* red = reinterpret_cast<float*>(smem + Lds<NTT>::kRed);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * 16 * NTT;
+    WStream ws;
+    ws.init(a.wpack, a.wbytes, wave, lane);
+    Ring R;
+    if constexpr (HEAD != 0 || BODY) {
+#pragma unroll
+        for (int ks = 0; ks < kPF; ++ks) ws.load(R.a[ks], a.img[0], ks);
+    }
+    for (int i = tid; i < 3 * 64; i += kThreads) {
+        const float* src = a.vec[i >> 6];
+        if (src) reinterpret_cast<float4*>(vecs)[i] = reinterpret_cast<const float4*>(src)[i & 63];
+    }
+    const RowLane rl(wave, lane);
+    const int n_r = lane & 15, g_r = lane >> 4;
+    const char* xr0 = ximg + (g_r * 16 + (n_r ^ g_r)) * 16;
+    const char* xr1 = ximg + (g_r * 16 + (n_r ^ g_r ^ 12)) * 16;
+    bool ok[NTT];
+    int64_t off[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const int row = row0 + tt * 16 + rl.n16;
+        ok[tt] = row < a.rows;
+        off[tt] = (int64_t)row * kD + rl.slot * 8;
+    }
+    Acc<NTT> acc;
+    float g[NTT][8];                             // the cotangent of the layer output on the lane's rows
+    constexpr int kHeadImgs = HEAD == 1 ? 3 : HEAD == 2 ? 1 : 0;
+    if constexpr (HEAD == 1) {
+        // ---- d x = res + dq Wq + dk Wk + dv Wv (attn.py:183-185 backward): one K = 768 reduction, common row scale for the three operands
+        float res[NTT][8];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            float q[8], k[8], v[8];
+            load8(q, a.dq + off[tt], ok[tt]); load8(k, a.dk + off[tt], ok[tt]); load8(v, a.dv + off[tt], ok[tt]);
+            load8(res[tt], a.res + off[tt], ok[tt]);
+            const float m = fmaxf(row_absmax(q), fmaxf(row_absmax(k), row_absmax(v)));
+            row_to_ximg(q, m, rl, ximg + tt * kXImg, rscale + tt * 16);
+            row_to_ximg(k, m, rl, ximg + (NTT + tt) * kXImg, rscale + tt * 16);
+            row_to_ximg(v, m, rl, ximg + (2 * NTT + tt) * kXImg, rscale + tt * 16);
+        }
+        barrier_lds();
+        acc.zero();
+        gemm<NTT, true>(ws, R, a.img[0], a.img[1], xr0, xr1, acc);
+        gemm<NTT, true>(ws, R, a.img[1], a.img[2], xr0 + NTT * kXImg, xr1 + NTT * kXImg, acc);
+        gemm<NTT, BODY>(ws, R, a.img[2], a.img[3], xr0 + 2 * NTT * kXImg, xr1 + 2 * NTT * kXImg, acc);
+        acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
+        barrier_lds();
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            float v[8];
+            lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[tt][e] = v[e] + res[tt][e];
+        }
+    } else if constexpr (HEAD == 2) {
+        // ---- output projection and encoder.norm backward (transformer_net.py:129, :68)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            float v[8];
+            load8(v, a.dmeta + off[tt], ok[tt]);
+            row_to_ximg(v, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+        }
+        barrier_lds();
+        acc.zero();
+        gemm<NTT, BODY>(ws, R, a.img[0], a.img[1], xr0, xr1, acc);
+        acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
+        barrier_lds();
+        float gam[8], pg[8], pb[8];
+        lds8(gam, vecs + VB_GF * 256 + rl.slot * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pg[e] = 0.f; pb[e] = 0.f; }
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            float v[8], xh[8];
+            lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
+            load8(xh, a.xhatf + off[tt], ok[tt]);
+            const float rstd = ok[tt] ? a.rstdf[row0 + tt * 16 + rl.n16] : 0.f;
+            layer_norm_bwd8(v, xh, rstd, gam, g[tt], pg, pb);
+        }
+        partials_to_lds(pg, pb, red, wave, lane);
+        barrier_lds();
+        partials_to_global(red, a.partial_f, tid);
+        barrier_lds();                                               // red is reused by LayerNorm2's partials
+    } else {
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) load8(g[tt], a.gin + off[tt], ok[tt]);
+        barrier_lds();                                               // the parameter vectors are in LDS
+    }
+    if constexpr (!BODY) {
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) store8(a.gx + off[tt], g[tt], ok[tt]);
+        return;
+    } else {
+        // ---- LayerNorm2 backward (transformer_net.py:44): gs2 = d(x1 + ffn); it is both the conv2 cotangent and the residual branch
+        float res2[NTT][8];
+        {
+            float gam[8], pg[8], pb[8];
+            lds8(gam, vecs + VB_G2 * 256 + rl.slot * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pg[e] = 0.f; pb[e] = 0.f; }
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                float xh[8];
+                load8(xh, a.xhat2 + off[tt], ok[tt]);
+                const float rstd = ok[tt] ? a.rstd2[row0 + tt * 16 + rl.n16] : 0.f;
+                layer_norm_bwd8(g[tt], xh, rstd, gam, res2[tt], pg, pb);
+                store8(a.gs2 + off[tt], res2[tt], ok[tt]);
+                row_to_ximg(res2[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+            }
+            partials_to_lds(pg, pb, red, wave, lane);
+        }
+        barrier_lds();
+        partials_to_global(red, a.partial2, tid);
+        // ---- conv2^T and GELU' (transformer_net.py:41-42)
+        acc.zero();
+        gemm<NTT, true>(ws, R, a.img[kHeadImgs], a.img[kHeadImgs + 1], xr0, xr1, acc);
+        acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
+        barrier_lds();
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            float v[8], p[8];
+            lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
+            load8(p, a.pre + off[tt], ok[tt]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_exact_grad(p[e]);
+            store8(a.dpre + off[tt], v, ok[tt]);
+            row_to_ximg(v, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+        }
+        barrier_lds();
+        // ---- conv1^T + residual branch, LayerNorm1 backward (transformer_net.py:37-38)
+        acc.zero();
+        gemm<NTT, true>(ws, R, a.img[kHeadImgs + 1], a.img[kHeadImgs + 2], xr0, xr1, acc);
+        acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
+        barrier_lds();
+        {
+            float gam[8], pg[8], pb[8];
+            lds8(gam, vecs + VB_G1 * 256 + rl.slot * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pg[e] = 0.f; pb[e] = 0.f; }
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                float v[8], xh[8], gs1[8];
+                lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
+                load8(xh, a.xhat1 + off[tt], ok[tt]);
+                const float rstd = ok[tt] ? a.rstd1[row0 + tt * 16 + rl.n16] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += res2[tt][e];
+                layer_norm_bwd8(v, xh, rstd, gam, gs1, pg, pb);
+                store8(a.gs1 + off[tt], gs1, ok[tt]);
+                row_to_ximg(gs1, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+            }
+            partials_to_lds(pg, pb, red, wave, lane);                // red: read by partials_to_global(partial2) before the previous two barriers
+        }
+        barrier_lds();
+        partials_to_global(red, a.partial1, tid);
+        // ---- out-projection^T (attn.py:196): the attention backward's input
+        acc.zero();
+        gemm<NTT, false>(ws, R, a.img[kHeadImgs + 2], 0, xr0, xr1, acc);
+        acc_to_global<NTT>(acc, a.dout, nullptr, rscale, row0, a.rows, wave, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight images
+struct PackArgs {
+    const float* W[DPN_ENC_MAX_MATS];
+    int n;
+    char* out;
+    int* status;
+};
+// one thread = one 16-byte fragment slot of both planes: image 0 is W as stored ([out][in]: y = x W^T contracts over `in`), image 1 is W^T
+// (g W contracts over `out`).  Fragment (tile mt, k-step ks, lane (m, g)) holds A[16 mt + m][32 ks + 8 g .. + 7].
+__global__ __launch_bounds__(256) void dpn_enc_pack_kernel(PackArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = idx & 63, ks = (idx >> 6) & 7, mt = (idx >> 9) & 15, im = (idx >> 13) & 1, mat = idx >> 14;
+    if (mat >= a.n) return;
+    const float* W = a.W[mat];
+    const int r = 16 * mt + (lane & 15), c0 = 32 * ks + 8 * (lane >> 4);
+    float v[8];
+    if (im == 0) {
+        const float4 x0 = *reinterpret_cast<const float4*>(W + r * kD + c0), x1 = *reinterpret_cast<const float4*>(W + r * kD + c0 + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = W[(c0 + e) * kD + r];
+    }
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bad |= !(fabsf(v[e]) < 32768.f);
+    if (bad && a.status) atomicOr(a.status, 1);
+    u32x4 hi, lo;
+    split8(v, hi, lo);
+    char* dst = a.out + (int64_t)(mat * 2 + im) * kImgBytes + ((mt * 8 + ks) * 2) * 1024 + lane * 16;
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + 1024) = lo;
+}
+
+template <class K>
+int set_lds(K kernel, int bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+int img_off(int mat, int nn) { return (mat * 2 + nn) * kImgBytes; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t dpn_enc_pack_bytes(int n_mats) { return (int64_t)n_mats * 2 * kImgBytes; }
+
+int dpn_enc_pack(int n_mats, const float* const* weights, void* packed, int* status_dev, void* stream) {
+    if (n_mats <= 0 || n_mats > DPN_ENC_MAX_MATS || !weights || !packed) return -1;
+    PackArgs a{};
+    for (int i = 0; i < n_mats; ++i) {
+        if (!weights[i]) return -1;
+        a.W[i] = weights[i];
+    }
+    a.n = n_mats; a.out = static_cast<char*>(packed); a.status = status_dev;
+    hipLaunchKernelGGL(dpn_enc_pack_kernel, dim3(n_mats * 2 * 16 * 8 * 64 / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int dpn_enc_fwd(const DpnEncFwd* p, void* stream) {
+    if (!p || !p->wpack || p->rows <= 0 || p->n_mats <= 0 || p->n_mats > DPN_ENC_MAX_MATS || p->next < 0 || p->next > 2) return -1;
+    if (!p->tail && p->next != 1) return -1;
+    const bool wide = p->row_tiles == 2;
+    if (p->row_tiles != 1 && p->row_tiles != 2) return -1;
+    FwdArgs a{};
+    a.wpack = p->wpack; a.wbytes = dpn_enc_pack_bytes(p->n_mats); a.rows = p->rows;
+    auto mat_ok = [&](int m) { return m >= 0 && m < p->n_mats; };
+    int ni = 0;
+    if (p->tail) {
+        if (!mat_ok(p->m_o) || !mat_ok(p->m_c1) || !mat_ok(p->m_c2)) return -1;
+        if (!p->o || !p->x || !p->bo || !p->g1 || !p->be1 || !p->bc1 || !p->bc2 || !p->g2 || !p->be2) return -1;
+        if (!p->x1 || !p->xhat1 || !p->rstd1 || !p->pre || !p->act || !p->x2 || !p->xhat2 || !p->rstd2) return -1;
+        a.img[ni++] = img_off(p->m_o, 0); a.img[ni++] = img_off(p->m_c1, 0); a.img[ni++] = img_off(p->m_c2, 0);
+    } else if (!p->xin) return -1;
+    if (p->next == 1) {
+        if (!mat_ok(p->m_n0) || !mat_ok(p->m_n1) || !mat_ok(p->m_n2) || !p->y0 || !p->y1 || !p->y2) return -1;
+        a.img[ni++] = img_off(p->m_n0, 0); a.img[ni++] = img_off(p->m_n1, 0); a.img[ni++] = img_off(p->m_n2, 0);
+    } else if (p->next == 2) {
+        if (!mat_ok(p->m_n0) || !p->y0 || !p->gf || !p->bef || !p->xf || !p->xhatf || !p->rstdf) return -1;
+        a.img[ni++] = img_off(p->m_n0, 0);
+    }
+    a.o = p->o; a.x = p->x; a.xin = p->xin;
+    const float* vec[kNVecF] = {p->bo, p->g1, p->be1, p->bc1, p->bc2, p->g2, p->be2, p->gf, p->bef, p->bn0, p->bn1, p->bn2};
+    for (int i = 0; i < kNVecF; ++i) a.vec[i] = vec[i];
+    a.x1 = p->x1; a.xhat1 = p->xhat1; a.rstd1 = p->rstd1; a.pre = p->pre; a.act = p->act; a.x2 = p->x2; a.xhat2 = p->xhat2; a.rstd2 = p->rstd2;
+    a.xf = p->xf; a.xhatf = p->xhatf; a.rstdf = p->rstdf; a.y0 = p->y0; a.y1 = p->y1; a.y2 = p->y2;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rpw = wide ? 32 : 16;
+    const dim3 grid((p->rows + rpw - 1) / rpw), block(kThreads);
+    static bool once = false;
+#define DPN_ENC_FWD_CASES(X) X(true, 0) X(true, 1) X(true, 2) X(false, 1)
+    if (!once) {
+#define X(T, N) if (set_lds(dpn_enc_fwd_kernel<T, N, 1>, Lds<1>::kBytes) || set_lds(dpn_enc_fwd_kernel<T, N, 2>, Lds<2>::kBytes)) return -2;
+        DPN_ENC_FWD_CASES(X)
+#undef X
+        once = true;
+    }
+#define X(T, N) if ((p->tail != 0) == T && p->next == N) { \
+        if (wide) hipLaunchKernelGGL((dpn_enc_fwd_kernel<T, N, 2>), grid, block, Lds<2>::kBytes, s, a); \
+        else hipLaunchKernelGGL((dpn_enc_fwd_kernel<T, N, 1>), grid, block, Lds<1>::kBytes, s, a); }
+    DPN_ENC_FWD_CASES(X)
+#undef X
+    return (int)hipGetLastError();
+}
+
+int dpn_enc_bwd(const DpnEncBwd* p, void* stream) {
+    if (!p || p->rows <= 0 || p->head < 0 || p->head > 2 || (p->row_tiles != 1 && p->row_tiles != 2)) return -1;
+    if (p->head == 0 && !p->body) return -1;
+    if (!p->wpack || p->n_mats <= 0 || p->n_mats > DPN_ENC_MAX_MATS) return -1;
+    const bool wide = p->row_tiles == 2;
+    BwdArgs a{};
+    a.wpack = p->wpack; a.wbytes = dpn_enc_pack_bytes(p->n_mats); a.rows = p->rows;
+    auto mat_ok = [&](int m) { return m >= 0 && m < p->n_mats; };
+    int ni = 0;
+    if (p->head == 1) {
+        if (!mat_ok(p->m_h0) || !mat_ok(p->m_h1) || !mat_ok(p->m_h2) || !p->res || !p->dq || !p->dk || !p->dv) return -1;
+        a.img[ni++] = img_off(p->m_h0, 1); a.img[ni++] = img_off(p->m_h1, 1); a.img[ni++] = img_off(p->m_h2, 1);
+    } else if (p->head == 2) {
+        if (!mat_ok(p->m_h0) || !p->dmeta || !p->xhatf || !p->rstdf || !p->gf || !p->partial_f) return -1;
+        a.img[ni++] = img_off(p->m_h0, 1);
+    } else if (!p->gin) return -1;
+    if (p->body) {
+        if (!mat_ok(p->m_c2) || !mat_ok(p->m_c1) || !mat_ok(p->m_o)) return -1;
+        if (!p->xhat2 || !p->rstd2 || !p->pre || !p->xhat1 || !p->rstd1 || !p->g2 || !p->g1) return -1;
+        if (!p->gs2 || !p->dpre || !p->gs1 || !p->dout || !p->partial2 || !p->partial1) return -1;
+        a.img[ni++] = img_off(p->m_c2, 1); a.img[ni++] = img_off(p->m_c1, 1); a.img[ni++] = img_off(p->m_o, 1);
+    } else if (!p->gx) return -1;
+    a.res = p->res; a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.dmeta = p->dmeta; a.xhatf = p->xhatf; a.rstdf = p->rstdf; a.gin = p->gin;
+    a.xhat2 = p->xhat2; a.rstd2 = p->rstd2; a.pre = p->pre; a.xhat1 = p->xhat1; a.rstd1 = p->rstd1;
+    a.vec[VB_G2] = p->g2; a.vec[VB_G1] = p->g1; a.vec[VB_GF] = p->gf;
+    a.gs2 = p->gs2; a.dpre = p->dpre; a.gs1 = p->gs1; a.dout = p->dout; a.gx = p->gx;
+    a.partial_f = p->partial_f; a.partial2 = p->partial2; a.partial1 = p->partial1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rpw = wide ? 32 : 16;
+    const dim3 grid((p->rows + rpw - 1) / rpw), block(kThreads);
+    static bool once = false;
+#define DPN_ENC_BWD_CASES(X) X(0, true) X(1, true) X(2, true) X(1, false)
+    if (!once) {
+#define X(H, B) if (set_lds(dpn_enc_bwd_kernel<H, B, 1>, Lds<1>::kBytes) || set_lds(dpn_enc_bwd_kernel<H, B, 2>, Lds<2>::kBytes)) return -2;
+        DPN_ENC_BWD_CASES(X)
+#undef X
+        once = true;
+    }
+#define X(H, B) if (p->head == H && (p->body != 0) == B) { \
+        if (wide) hipLaunchKernelGGL((dpn_enc_bwd_kernel<H, B, 2>), grid, block, Lds<2>::kBytes, s, a); \
+        else hipLaunchKernelGGL((dpn_enc_bwd_kernel<H, B, 1>), grid, block, Lds<1>::kBytes, s, a); }
+    DPN_ENC_BWD_CASES(X)
+#undef X
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1769,7 +1769,7 @@ __global__ __launch_bounds__(256) void dpn_sgemm_reduce_kernel(SgemmArgs a, int 
 // Several independent small GEMMs in ONE launch (blockIdx.z = problem), each optionally a sum of up to 3 products
 // (C = sum_t op(A_t) op(B_t)): the three q/k/v projections of an attention layer, or the input- and weight-gradient
 // GEMMs of a linear layer, cost one launch instead of 2-6.  Two k-tiles are kept in flight in registers.
-constexpr int kBatchMaxProblems = 24, kBatchMaxTerms = 12, kBatchTermPool = 32;
+constexpr int kBatchMaxProblems = DPN_GEMM_MAX_PROBLEMS, kBatchMaxTerms = DPN_GEMM_MAX_TERMS, kBatchTermPool = 32, kBatchMaxJobs = DPN_GEMM_MAX_JOBS;
 struct SgemmTerm {
     const float* A;
     const float* B;
@@ -1793,7 +1793,7 @@ struct SgemmColsum { const float* partial; float* out_a; float* out_b; int nbloc
 struct SgemmBatch {
     SgemmProblem p[kBatchMaxProblems];
     SgemmTerm t[kBatchTermPool];          // the accumulated A.B terms of all problems (problem i owns t[term0 .. term0+nterms))
-    SgemmColsum job[2];                   // ride-along column sums (LayerNorm parameter gradients): blockIdx.z = n, n + 1
+    SgemmColsum job[kBatchMaxJobs];       // ride-along column sums (LayerNorm parameter gradients): blockIdx.z = n, n + 1, ...
     int n;
 };
 
@@ -2475,7 +2475,8 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
 constexpr int kSingleStageMaxTiles = 1;
 constexpr long kSingleStageMaxOutTiles = 512;      // one round of <256,1>; thresholds 256 ... 700 measure the same, none or 1024 worse
 static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream) {
-    if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems || n_jobs < 0 || n_jobs > 2 || (n_jobs && !jobs)) return -1;
+    if (n_problems <= 0 || n_problems > kBatchMaxProblems || !problems || n_jobs < 0 || n_jobs > kBatchMaxJobs || (n_jobs && !jobs)) return -1;
+    static_assert(sizeof(SgemmBatch) <= 4096, "kernel arguments");
     SgemmBatch b;
     b.n = n_problems;
     int gx = 0, gy = 0, pool = 0;

@@ -510,3 +510,245 @@ class _HeadsFn(torch.autograd.Function):
             problems.append(q)
         _launch(problems)
         return (d_meta, None, *dest)
+
+
+# ------------------------------------------------------------------------------------------------ row-local fused encoder (round 4)
+_enc_status = {}
+
+
+def enc_status(device):
+    """Device-side status word of dpn_enc_pack (bit 0: a weight entry outside the f16 split's range, |w| >= 32768)."""
+    key = (device.type, device.index)
+    if key not in _enc_status:
+        _enc_status[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _enc_status[key]
+
+
+def check_enc_status():
+    """Synchronising check of the status words (call where the step synchronises anyway: logging, checkpoints)."""
+    for t in _enc_status.values():
+        if int(t.item()) != 0:
+            raise RuntimeError('deepphysinet_amd: an encoder weight matrix holds an entry with |w| >= 32768 (or a non-finite one): outside the '
+                               'range of the f16 hi+lo operand split of dpn_enc_fwd / dpn_enc_bwd')
+
+
+def enc_pack(mats):
+    """MFMA-fragment images (x W^T and g W forms) of the [256, 256] fp32 matrices `mats` (dpn_enc_pack): one launch."""
+    lib = L.load()
+    n = len(mats)
+    if not 0 < n <= L.ENC_MAX_MATS:
+        raise ValueError('enc_pack takes 1..%d matrices' % L.ENC_MAX_MATS)
+    for m in mats:
+        if tuple(m.shape) != (256, 256) or m.dtype != torch.float32 or not m.is_contiguous():
+            raise ValueError('enc_pack: contiguous [256, 256] fp32 matrices only, got %s' % (tuple(m.shape),))
+    dev = mats[0].device
+    buf = torch.empty(int(lib.dpn_enc_pack_bytes(n)), dtype=torch.uint8, device=dev)
+    arr = (ctypes.c_void_p * n)(*[_p(m).value for m in mats])
+    L.check(lib.dpn_enc_pack(n, arr, _p(buf), _p(enc_status(dev)), _s()), 'dpn_enc_pack')
+    return buf
+
+
+_LAYER_PARAMS = 16     # wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, wc1, bc1, wc2, bc2, g2, be2
+
+
+class _EncoderStackFn(torch.autograd.Function):
+    """nl EncoderLayers (+ encoder.norm and the output projection when `final`) as ONE autograd node on the row-local fused kernels
+    (csrc/dpn_encoder_chain.hip): forward = pack + q/k/v + nl x (attention, layer tail with the next layer's q/k/v) launches, backward =
+    nl x (row-local chain, attention backward) + the first layer's q/k/v backward + ONE launch for all weight gradients and the
+    LayerNorm parameter sums.  Reference: model/transformer_net.py:28-44,54-72,129, model/attn.py:177-196.
+    x0: [B * Lt, 256]; parameters per layer: wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, wc1, bc1, wc2, bc2, g2, be2 (conv weights as [256, 256]),
+    then gf, bef, wp, bp when final."""
+
+    @staticmethod
+    def forward(ctx, x0, B, Lt, nl, final, *params):
+        lib = L.load()
+        x0 = _c(x0)
+        n, D = x0.shape
+        assert n == B * Lt and D == 256 and len(params) == _LAYER_PARAMS * nl + (4 if final else 0)
+        dev = x0.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        lay = [params[_LAYER_PARAMS * l:_LAYER_PARAMS * (l + 1)] for l in range(nl)]
+        fin = params[_LAYER_PARAMS * nl:] if final else None
+        mats = []
+        for p_ in lay:
+            mats += [_c(p_[0]), _c(p_[2]), _c(p_[4]), _c(p_[6]), _c(p_[10]), _c(p_[12])]       # 6 l + (q, k, v, o, c1, c2)
+        if final:
+            mats.append(_c(fin[2]))
+        n_mats = len(mats)
+        wpack = enc_pack(mats)
+        rt = 1 if n <= 2048 else 2
+        stream = _s()
+
+        def fwd(**kw):
+            f = L.DpnEncFwd()
+            f.wpack, f.n_mats, f.rows, f.row_tiles = _p(wpack), n_mats, n, rt
+            for k_, v_ in kw.items():
+                setattr(f, k_, _p(v_) if isinstance(v_, torch.Tensor) else v_)
+            L.check(lib.dpn_enc_fwd(ctypes.byref(f), stream), 'dpn_enc_fwd')
+        q, k, v = new(n, D), new(n, D), new(n, D)
+        fwd(tail=0, next=1, xin=x0, m_n0=0, m_n1=1, m_n2=2, bn0=lay[0][1], bn1=lay[0][3], bn2=lay[0][5], y0=q, y1=k, y2=v)
+        x, saved, out = x0, [], None
+        xf = xhatf = rstdf = None
+        for l in range(nl):
+            p_ = lay[l]
+            o, P = new(n, D), new(B * 8, 288, 288)
+            L.check(lib.dpn_attn_fwd(_p(q), _p(k), _p(v), Lt, B, _p(o), _p(P), stream), 'dpn_attn_fwd')
+            x1, xhat1, rstd1, pre, act, x2, xhat2, rstd2 = new(n, D), new(n, D), new(n), new(n, D), new(n, D), new(n, D), new(n, D), new(n)
+            kw = dict(tail=1, o=o, x=x, m_o=6 * l + 3, m_c1=6 * l + 4, m_c2=6 * l + 5, bo=p_[7], g1=p_[8], be1=p_[9], bc1=p_[11], bc2=p_[13],
+                      g2=p_[14], be2=p_[15], x1=x1, xhat1=xhat1, rstd1=rstd1, pre=pre, act=act, x2=x2, xhat2=xhat2, rstd2=rstd2)
+            qn = kn = vn = None
+            if l + 1 < nl:
+                qn, kn, vn = new(n, D), new(n, D), new(n, D)
+                pn = lay[l + 1]
+                kw.update(next=1, m_n0=6 * l + 6, m_n1=6 * l + 7, m_n2=6 * l + 8, bn0=pn[1], bn1=pn[3], bn2=pn[5], y0=qn, y1=kn, y2=vn)
+            elif final:
+                xf, xhatf, rstdf, out = new(n, D), new(n, D), new(n), new(n, D)
+                kw.update(next=2, m_n0=6 * nl, gf=fin[0], bef=fin[1], bn0=fin[3], xf=xf, xhatf=xhatf, rstdf=rstdf, y0=out)
+            else:
+                kw.update(next=0)
+                out = x2
+            fwd(**kw)
+            saved += [x, q, k, v, o, P, x1, xhat1, rstd1, pre, act, xhat2, rstd2]
+            x, q, k, v = x2, qn, kn, vn
+        ctx.save_for_backward(wpack, *saved, *([xf, xhatf, rstdf] if final else []), *[p_[8] for p_ in lay], *[p_[14] for p_ in lay],
+                              *([fin[0]] if final else []))
+        ctx.B, ctx.Lt, ctx.nl, ctx.final, ctx.rt, ctx.n_mats = B, Lt, nl, final, rt, n_mats
+        ctx.params = params                                          # identify the gradient slots (grad_arena); never read
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .linear import _launch
+        lib = L.load()
+        B, Lt, nl, final, rt, n_mats = ctx.B, ctx.Lt, ctx.nl, ctx.final, ctx.rt, ctx.n_mats
+        t = list(ctx.saved_tensors)
+        wpack, t = t[0], t[1:]
+        lsaved = [t[13 * l:13 * (l + 1)] for l in range(nl)]
+        t = t[13 * nl:]
+        if final:
+            xf, xhatf, rstdf = t[:3]
+            t = t[3:]
+        g1s, g2s, t = t[:nl], t[nl:2 * nl], t[2 * nl:]
+        gf = t[0] if final else None
+        g = _c(g)
+        n, D = g.shape
+        dev = g.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        nb = (n + 16 * rt - 1) // (16 * rt)
+        stream = _s()
+        lay = [ctx.params[_LAYER_PARAMS * l:_LAYER_PARAMS * (l + 1)] for l in range(nl)]
+        fin = ctx.params[_LAYER_PARAMS * nl:] if final else None
+
+        def bwd(**kw):
+            b = L.DpnEncBwd()
+            b.wpack, b.n_mats, b.rows, b.row_tiles = _p(wpack), n_mats, n, rt
+            for k_, v_ in kw.items():
+                setattr(b, k_, _p(v_) if isinstance(v_, torch.Tensor) else v_)
+            L.check(lib.dpn_enc_bwd(ctypes.byref(b), stream), 'dpn_enc_bwd')
+        batch, jobs = [], []
+        grads = [None] * len(ctx.params)
+
+        keep = []                                                    # the launch at the end reads these through raw pointers
+
+        def wgrad(slot_w, slot_b, N, gmat, xmat):                    # d W = gmat^T xmat, d b = column sums of gmat
+            keep.extend((gmat, xmat))
+            w = ctx.params[slot_w]
+            gw, gb = new_grad(w, (N, D)), new_grad(ctx.params[slot_b])
+            _wgrad(batch, N, D, n, gmat, D, xmat, D, gw, gb)
+            grads[slot_w], grads[slot_b] = gw.view(w.shape), gb
+
+        def lnjob(slot_g, slot_b, partial):
+            dg, db = new_grad(ctx.params[slot_g]), new_grad(ctx.params[slot_b])
+            keep.append(partial)
+            jobs.append((partial, n, dg, db, nb))
+            grads[slot_g], grads[slot_b] = dg, db
+        res = dq = dk = dv = None
+        for l in range(nl - 1, -1, -1):
+            x, q, k, v, o, P, x1, xhat1, rstd1, pre, act, xhat2, rstd2 = lsaved[l]
+            gs2, dpre, gs1, do = new(n, D), new(n, D), new(n, D), new(n, D)
+            p2, p1 = new(nb * 512), new(nb * 512)
+            kw = dict(body=1, m_c2=6 * l + 5, m_c1=6 * l + 4, m_o=6 * l + 3, xhat2=xhat2, rstd2=rstd2, pre=pre, xhat1=xhat1, rstd1=rstd1,
+                      g2=g2s[l], g1=g1s[l], gs2=gs2, dpre=dpre, gs1=gs1, dout=do, partial2=p2, partial1=p1)
+            base = _LAYER_PARAMS * l
+            if l == nl - 1:
+                if final:
+                    pf = new(nb * 512)
+                    kw.update(head=2, dmeta=g, m_h0=6 * nl, xhatf=xhatf, rstdf=rstdf, gf=gf, partial_f=pf)
+                    fb = _LAYER_PARAMS * nl
+                    lnjob(fb, fb + 1, pf)
+                    wgrad(fb + 2, fb + 3, D, g, xf)
+                else:
+                    kw.update(head=0, gin=g)
+            else:
+                kw.update(head=1, res=res, dq=dq, dk=dk, dv=dv, m_h0=6 * l + 6, m_h1=6 * l + 7, m_h2=6 * l + 8)
+            bwd(**kw)
+            lnjob(base + 14, base + 15, p2)
+            lnjob(base + 8, base + 9, p1)
+            wgrad(base + 12, base + 13, D, gs2, act)                 # conv2
+            wgrad(base + 10, base + 11, D, dpre, x1)                 # conv1
+            wgrad(base + 6, base + 7, D, gs1, o)                     # out projection
+            dq, dk, dv = new(n, D), new(n, D), new(n, D)
+            L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(do), Lt, B, _p(dq), _p(dk), _p(dv), stream), 'dpn_attn_bwd')
+            wgrad(base + 0, base + 1, D, dq, x)
+            wgrad(base + 2, base + 3, D, dk, x)
+            wgrad(base + 4, base + 5, D, dv, x)
+            res = gs1
+        dx0 = new(n, D)
+        bwd(head=1, body=0, res=res, dq=dq, dk=dk, dv=dv, m_h0=0, m_h1=1, m_h2=2, gx=dx0)
+        # every weight gradient of the stack and the LayerNorm parameter sums: one launch (two when a launch's limits are exceeded)
+        while batch or jobs:
+            b_, batch = batch[:L.GEMM_MAX_PROBLEMS], batch[L.GEMM_MAX_PROBLEMS:]
+            j_, jobs = jobs[:L.GEMM_MAX_JOBS], jobs[L.GEMM_MAX_JOBS:]
+            if b_:
+                _launch(b_, colsum_jobs=j_)
+            else:                                                    # batches of fields: the weight gradients went out as row-slice launches
+                for (partial, rows_, dg, db, nblk) in j_:
+                    joined = new(512)
+                    L.check(lib.dpn_sum_parts(_p(partial), nblk, 512, 0, _p(joined), stream), 'dpn_sum_parts')
+                    dg.copy_(joined[:256])
+                    db.copy_(joined[256:])
+        del keep
+        return (dx0, None, None, None, None, *grads)
+
+
+def _layer_params(layer):
+    att = layer.attention
+    return (att.query_projection.weight, att.query_projection.bias, att.key_projection.weight, att.key_projection.bias,
+            att.value_projection.weight, att.value_projection.bias, att.out_projection.weight, att.out_projection.bias,
+            layer.norm1.weight, layer.norm1.bias, layer.conv1.weight.squeeze(-1), layer.conv1.bias, layer.conv2.weight.squeeze(-1),
+            layer.conv2.bias, layer.norm2.weight, layer.norm2.bias)
+
+
+def _layer_fits(layer):
+    att = layer.attention
+    return (att.n_heads == 8 and not att.mix and layer.activation is F.gelu and layer.norm1.eps == 1e-5 and layer.norm2.eps == 1e-5
+            and layer.norm1.elementwise_affine and layer.norm2.elementwise_affine and tuple(layer.conv1.weight.shape) == (256, 256, 1)
+            and tuple(layer.conv2.weight.shape) == (256, 256, 1) and att.query_projection.weight.shape == (256, 256)
+            and all(m.bias is not None for m in (att.query_projection, att.key_projection, att.value_projection, att.out_projection,
+                                                 layer.conv1, layer.conv2)))
+
+
+def encoder_stack_fused(x, layers, norm=None, projection=None):
+    """[B, L, 256] -> the encoder layers (+ encoder.norm + output projection when both are given) as one autograd node, or None when the
+    modules do not fit the kernels (8 heads x 32, d_ff = 256, gelu, affine LayerNorms with eps 1e-5, L <= 288)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 256 and x.shape[1] <= 288 and len(layers) >= 1):
+        return None
+    if os.environ.get('DPN_ENCODER_FP8') in ('1', 'mx') or os.environ.get('DPN_ENCODER_UNFUSED') == '1':
+        return None
+    if not all(_layer_fits(l_) and not getattr(l_.attention.inner_attention, 'output_attention', False) for l_ in layers):
+        return None
+    final = norm is not None and projection is not None
+    if (norm is None) != (projection is None):
+        return None
+    if 6 * len(layers) + (1 if final else 0) > L.ENC_MAX_MATS:
+        return None
+    params = []
+    for l_ in layers:
+        params += list(_layer_params(l_))
+    if final:
+        if not (norm.elementwise_affine and norm.eps == 1e-5 and tuple(projection.weight.shape) == (256, 256) and projection.bias is not None):
+            return None
+        params += [norm.weight, norm.bias, projection.weight, projection.bias]
+    B, Lt = x.shape[0], x.shape[1]
+    out = _EncoderStackFn.apply(x.reshape(B * Lt, 256), B, Lt, len(layers), final, *params)
+    return out.view(B, Lt, 256)

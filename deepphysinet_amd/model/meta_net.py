@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..encoder_ops import add_layer_norm, attention, data_embedding_fused, encoder_layer_fused
+from ..encoder_ops import add_layer_norm, attention, data_embedding_fused, encoder_layer_fused, encoder_stack_fused
 from ..linear import linear, linear_multi
 from ..utils.position_encoding import SineCosPE
 
@@ -130,7 +130,9 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, attn_mask=None):
         if attn_mask is None and not getattr(self.attention.inner_attention, 'output_attention', False):
-            fused = encoder_layer_fused(x, self)            # whole layer = one autograd node (7 launches fwd, 9 bwd)
+            fused = encoder_stack_fused(x, [self])          # whole layer = one autograd node on the row-local fused kernels
+            if fused is None:
+                fused = encoder_layer_fused(x, self)        # (the per-GEMM node of rounds 1-3: DPN_ENCODER_UNFUSED=1, the fp8 experiments)
             if fused is not None:
                 return fused, None
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask)
@@ -175,6 +177,10 @@ class TransformerNet(nn.Module):
 
     def forward(self, x_enc, forecast_h, enc_self_mask=None):
         enc_out = self.enc_embedding(x_enc, forecast_h, self.learnable_token)
+        if enc_self_mask is None and self.encoder.conv_layers is None and self.encoder.norm is not None:
+            fused = encoder_stack_fused(enc_out, list(self.encoder.attn_layers), self.encoder.norm, self.projection)
+            if fused is not None:                          # all layers + encoder.norm + the projection: one node, 2 launches per layer
+                return fused
         enc_out, _ = self.encoder(enc_out, attn_mask=enc_self_mask)
         return linear(enc_out, self.projection.weight, self.projection.bias)
 

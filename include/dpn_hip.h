@@ -144,7 +144,7 @@ int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n_points, flo
 int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
               const float* bias, float* asum, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Up to 24 independent small fp32 GEMMs in one launch (exact-fp32 MFMA, fixed reduction order); each
+/* Up to 26 independent small fp32 GEMMs in one launch (exact-fp32 MFMA, fixed reduction order); each
  * C[M][N] = epilogue(sum_{t<nterms} op(A_t)[M][K_t] op(B_t)[K_t][N] + bias[N]); asum as in dpn_sgemm (single-term problems only).
  * Used for the q/k/v projections (attn.py:183-185), the paired input-/weight-gradient GEMMs of every encoder linear, and the
  * twelve hyper-network heads + six lead-time embeddings of the VariableNets (variable_net.py:59-65,75-78) and their backward. */
@@ -153,7 +153,8 @@ int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, cons
 #define DPN_EPI_MUL_GELU_GRAD 2   /* C = v * gelu'(aux): backward of the activation folded into the GEMM that feeds it                 */
 #define DPN_EPI_ADD 3             /* C = v + aux: the residual-branch gradient joins the input gradient without a separate add kernel  */
 #define DPN_GEMM_MAX_TERMS 12      /* per problem */
-#define DPN_GEMM_MAX_PROBLEMS 24   /* per launch; at most 32 terms per launch in total */
+#define DPN_GEMM_MAX_PROBLEMS 26   /* per launch; at most 32 terms per launch in total */
+#define DPN_GEMM_MAX_JOBS 10       /* ride-along column-sum jobs per launch */
 typedef struct DpnGemmProblem {
     const float* A[DPN_GEMM_MAX_TERMS]; const float* B[DPN_GEMM_MAX_TERMS]; int32_t lda[DPN_GEMM_MAX_TERMS], ldb[DPN_GEMM_MAX_TERMS];
     int32_t k_term[DPN_GEMM_MAX_TERMS];   /* reduction length of term t; 0 = K */
@@ -163,11 +164,11 @@ typedef struct DpnGemmProblem {
     int32_t epi;
 } DpnGemmProblem;
 int dpn_sgemm_batch(int n_problems, const DpnGemmProblem* problems /* host array */, void* stream);
-/* The same launch with up to two ride-along column-sum jobs: out_a[c] = sum_b partial[b][c], out_b[c] = sum_b partial[b][256 + c],
+/* The same launch with up to DPN_GEMM_MAX_JOBS ride-along column-sum jobs: out_a[c] = sum_b partial[b][c], out_b[c] = sum_b partial[b][256 + c],
  * c < 256, b < n_blocks (fixed order) -- the LayerNorm parameter gradients from dpn_add_ln_bwd's scratch (n_blocks = ceil(rows/4)),
  * finished inside a GEMM launch that follows it instead of in a launch of their own. */
 typedef struct DpnColsumJob { const float* partial; float* out_a; float* out_b; int32_t n_blocks; } DpnColsumJob;
-int dpn_sgemm_batch_jobs(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs /* host array, <= 2 */, void* stream);
+int dpn_sgemm_batch_jobs(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs /* host array */, void* stream);
 
 /* LayerNorm folded into the A operand of the GEMM that consumes it (d_model = 256: the GEMM's K is the LayerNorm's row):
  *   mode 1:  C = epilogue((LN(x + r) * gamma + beta) . op(B) + bias); also writes y = LN(..)*gamma+beta [M][256], xhat [M][256], rstd [M]
@@ -194,6 +195,53 @@ int dpn_sgemm_ln(const DpnLnGemm* problem, void* stream);
 int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, int batch, float* out, float* P, void* stream);
 int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L, int batch,
                  float* dq, float* dk, float* dv, void* stream);
+
+/* ---------------------------------------------------------------- row-local fused encoder nodes (csrc/dpn_encoder_chain.hip)
+ * Everything of an EncoderLayer except the attention itself is row-wise (attn.py:183-185,196; transformer_net.py:33-44, :68, :129), so the
+ * whole stretch between two attention kernels is ONE launch (a workgroup carries 16 or 32 token rows through up to six 256 x 256 GEMMs).
+ * All matrices are [256][256] fp32 as the reference stores them ([out][in]; Conv1d k=1 weights with the last axis squeezed), all row
+ * tensors [rows][256] fp32, rows = batch * L.  The GEMMs run on f16 hi+lo split operands (three products, fp32 accumulate: fp32-class).
+ *
+ * dpn_enc_pack: MFMA-fragment images of n_mats matrices (dpn_enc_pack_bytes(n_mats) bytes: per matrix one image for x W^T and one for
+ * g W).  Once per step, after the optimiser changed the weights.  *status_dev (may be NULL) gets bit 0 set when an |entry| >= 32768. */
+#define DPN_ENC_MAX_MATS 32
+int64_t dpn_enc_pack_bytes(int n_mats);
+int dpn_enc_pack(int n_mats, const float* const* weights /* host array of device pointers */, void* packed, int* status_dev, void* stream);
+
+/* Forward.  tail = 1:  x1 = norm1(x + o Wo^T + bo);  pre = x1 Wc1^T + bc1;  act = gelu(pre);  x2 = norm2(x1 + act Wc2^T + bc2)
+ *                      (o = the attention output, x = the layer input; x1, xhat1, rstd1, pre, act, x2, xhat2, rstd2 are written);
+ *           next = 1:  y0, y1, y2 = t Wn0^T + bn0, ...   the NEXT layer's q / k / v projections of t = x2 (tail = 1) or t = xin (tail = 0);
+ *           next = 2:  xf = encoder.norm(x2) (xf, xhatf, rstdf written);  y0 = xf Wn0^T + bn0   (the output projection);
+ *           next = 0:  nothing behind norm2.
+ * m_*: indices of the matrices in `wpack`.  row_tiles: 1 or 2 sixteen-row tiles per workgroup (2 for batches of fields). */
+typedef struct DpnEncFwd {
+    const void* wpack; int32_t n_mats, rows, row_tiles, tail, next;
+    int32_t m_o, m_c1, m_c2, m_n0, m_n1, m_n2;
+    const float *o, *x, *xin;
+    const float *bo, *g1, *be1, *bc1, *bc2, *g2, *be2, *gf, *bef, *bn0, *bn1, *bn2;
+    float *x1, *xhat1, *rstd1, *pre, *act, *x2, *xhat2, *rstd2, *xf, *xhatf, *rstdf, *y0, *y1, *y2;
+} DpnEncFwd;
+int dpn_enc_fwd(const DpnEncFwd* p, void* stream);
+
+/* Backward of the same stretch, in the order the cotangent travels.
+ *   head = 1:  g = res + dq Wh0 + dk Wh1 + dv Wh2      (the q / k / v projections of the layer ABOVE: its attention backward's outputs and
+ *                                                      its residual-branch cotangent gs1)
+ *   head = 2:  g = encoder.norm backward of (dmeta Wh0) (output projection; partial_f receives the norm's parameter partial sums)
+ *   head = 0:  g = gin
+ *   body = 1:  gs2 = norm2 backward of g;  dpre = (gs2 Wc2) * gelu'(pre);  gs1 = norm1 backward of (dpre Wc1 + gs2);  dout = gs1 Wo
+ *              (gs2, dpre, gs1: the operands of the weight-gradient GEMMs dWc2 = gs2^T act, dWc1 = dpre^T x1, dWo = gs1^T o; dout: the
+ *              attention backward's input; gs1 is also the residual-branch cotangent the next launch takes as `res`)
+ *   body = 0:  gx = g   (the cotangent of the first layer's input)
+ * partial_f / partial2 / partial1: [workgroups][512] = per-workgroup sums of (g * xhat | g) of the three LayerNorms, reduced in a fixed order by a
+ * DpnColsumJob with n_blocks = ceil(rows / (16 row_tiles)). */
+typedef struct DpnEncBwd {
+    const void* wpack; int32_t n_mats, rows, row_tiles, head, body;
+    int32_t m_h0, m_h1, m_h2, m_c2, m_c1, m_o;
+    const float *res, *dq, *dk, *dv, *dmeta, *xhatf, *rstdf, *gin;
+    const float *xhat2, *rstd2, *pre, *xhat1, *rstd1, *g2, *g1, *gf;
+    float *gs2, *dpre, *gs1, *dout, *gx, *partial_f, *partial2, *partial1;
+} DpnEncBwd;
+int dpn_enc_bwd(const DpnEncBwd* p, void* stream);
 
 /* out = LayerNorm_256(x + r) * gamma + beta (eps 1e-5), r may be NULL (transformer_net.py:37,44,68); saves xhat [rows][256] and rstd [rows].
  * Backward: gx = d/d(x + r) (the same tensor is the gradient of x and of r), dgamma, dbeta [256].  With dgamma = dbeta = NULL only gx and the
