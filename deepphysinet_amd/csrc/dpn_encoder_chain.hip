@@ -44,10 +44,26 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kD = 256;
 constexpr int kThreads = 512, kWaves = 8;
 constexpr int kImgBytes = 256 * 1024;            // one packed 256 x 256 image: [tile 16][k-step 8][hi | lo][lane 64][16 B]
-constexpr int kPF = 4;                           // weight fragments in flight: k-steps ahead (4 KB per wave and k-step)
+#ifndef DPN_ENC_PF
+#define DPN_ENC_PF 8
+#endif
+// weight fragments in flight: k-steps ahead (4 KB per wave and k-step); 8 = a whole GEMM (16-row workgroups; the 32-row form has the registers for 4)
+template <int NTT> constexpr int pf_of() { return NTT == 1 ? DPN_ENC_PF : 4; }
 constexpr int kYS = 260;                         // row stride (floats) of the fp32 staging block
 constexpr int kXImg = 16384;                     // X image of 16 tokens: [hi | lo][slot 32][position 16][16 B]
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+// Experiment build (-DDPN_ENC_TIMELINE, tools/enc_timeline.py): lane 0 of every wave writes the shader clock at the phase boundaries.
+#ifdef DPN_ENC_TIMELINE
+unsigned* g_enc_timeline = nullptr;
+#define ENC_STAMP(I) do { if (a.tl && lane == 0) a.tl[((size_t)blockIdx.x * kWaves + wave) * 32 + (I)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#define ENC_TL_ARG unsigned* tl;
+#define ENC_TL_SET(A) (A).tl = g_enc_timeline
+#else
+#define ENC_STAMP(I) do { } while (0)
+#define ENC_TL_ARG
+#define ENC_TL_SET(A) do { } while (0)
+#endif
 
 DEV void barrier_lds() {                         // LDS-only workgroup barrier: global loads (weight prefetch) and stores stay in flight
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -196,7 +212,7 @@ struct WStream {
                 dst[t][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + p * 1024, img_off + tile_off + t * 16384 + ks * 2048, 0));
     }
 };
-struct Ring { u32x4 a[kPF][2][2]; };
+template <int PF> struct Ring { u32x4 a[PF][2][2]; };
 
 DEV f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -216,7 +232,7 @@ struct Acc {
 // acc += W[wave's 32 channels][256] . X^T[256][16 NTT tokens]: eight k-steps; the ring holds this image's k-steps 0 .. kPF-1 on entry and the next
 // image's on exit (HAS_NEXT).  xr0 / xr1: the lane's read bases in the X image for even / odd k-steps.
 template <int NTT, bool HAS_NEXT>
-DEV void gemm(const WStream& ws, Ring& R, const int cur_off, const int next_off, const char* xr0, const char* xr1, Acc<NTT>& acc) {
+DEV void gemm(const WStream& ws, Ring<pf_of<NTT>()>& R, const int cur_off, const int next_off, const char* xr0, const char* xr1, Acc<NTT>& acc) {
     u32x4 B[2][NTT][2];
     auto loadB = [&](const int ks, const int buf) __attribute__((always_inline)) {
         const char* base = ((ks & 1) ? xr1 : xr0) + ks * 1024;
@@ -226,6 +242,7 @@ DEV void gemm(const WStream& ws, Ring& R, const int cur_off, const int next_off,
             B[buf][tt][1] = *reinterpret_cast<const u32x4*>(base + tt * kXImg + kXImg / 2);
         }
     };
+    constexpr int kPF = pf_of<NTT>();
     loadB(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -293,6 +310,7 @@ struct FwdArgs {
     const float *o, *x, *xin;
     const float* vec[kNVecF];
     float *x1, *xhat1, *rstd1, *pre, *act, *x2, *xhat2, *rstd2, *xf, *xhatf, *rstdf, *y0, *y1, *y2;
+    ENC_TL_ARG
 };
 template <int NTT>
 struct Lds {
@@ -313,125 +331,166 @@ __global__ __launch_bounds__(kThreads) void dpn_enc_fwd_kernel(FwdArgs a) {
     float* rscale = reinterpret_cast<float*>(smem + Lds<NTT>::kRs);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * 16 * NTT;
-    WStream ws;
-    ws.init(a.wpack, a.wbytes, wave, lane);
-    Ring R;
-#pragma unroll
-    for (int ks = 0; ks < kPF; ++ks) ws.load(R.a[ks], a.img[0], ks);
-    for (int i = tid; i < kNVecF * 64; i += kThreads) {
-        const float* src = a.vec[i >> 6];
-        if (src) reinterpret_cast<float4*>(vecs)[i] = reinterpret_cast<const float4*>(src)[i & 63];
-    }
+    ENC_STAMP(0);
     const RowLane rl(wave, lane);
     const int n_r = lane & 15, g_r = lane >> 4;
     const char* xr0 = ximg + (g_r * 16 + (n_r ^ g_r)) * 16;
     const char* xr1 = ximg + (g_r * 16 + (n_r ^ g_r ^ 12)) * 16;
-    float res[NTT][8];
+    // order of the first loads: the input rows (the first GEMM waits for them), the parameter vectors, THEN the weight stream -- vector memory
+    // returns in order, a row load issued behind the ring's 32 KB would wait for all of it
+    float res[NTT][8], vin[NTT][8];
     bool ok[NTT];
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
         const int row = row0 + tt * 16 + rl.n16;
         ok[tt] = row < a.rows;
-        float v[8];
-        load8(v, (TAIL ? a.o : a.xin) + (int64_t)row * kD + rl.slot * 8, ok[tt]);
+        load8(vin[tt], (TAIL ? a.o : a.xin) + (int64_t)row * kD + rl.slot * 8, ok[tt]);
         if constexpr (TAIL) load8(res[tt], a.x + (int64_t)row * kD + rl.slot * 8, ok[tt]);
-        row_to_ximg(v, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
     }
+    constexpr int kVecLoads = (kNVecF * 64 + kThreads - 1) / kThreads;
+    float4 pv[kVecLoads];
+#pragma unroll
+    for (int q = 0; q < kVecLoads; ++q) {
+        const int i = tid + q * kThreads;
+        const float* src = i < kNVecF * 64 ? a.vec[i >> 6] : nullptr;
+        pv[q] = src ? reinterpret_cast<const float4*>(src)[i & 63] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    WStream ws;
+    ws.init(a.wpack, a.wbytes, wave, lane);
+    constexpr int kPF = pf_of<NTT>();
+    Ring<kPF> R;
+#pragma unroll
+    for (int ks = 0; ks < kPF; ++ks) ws.load(R.a[ks], a.img[0], ks);
+#pragma unroll
+    for (int q = 0; q < kVecLoads; ++q) {
+        const int i = tid + q * kThreads;
+        if (i < kNVecF * 64) reinterpret_cast<float4*>(vecs)[i] = pv[q];
+    }
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) row_to_ximg(vin[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+    ENC_STAMP(1);
     barrier_lds();
+    ENC_STAMP(2);
     Acc<NTT> acc;
     constexpr int kFirstNext = TAIL ? 3 : 0;
     if constexpr (TAIL) {
         // ---- out-projection, residual, LayerNorm1 (attn.py:196, transformer_net.py:33-37)
         acc.zero();
         gemm<NTT, true>(ws, R, a.img[0], a.img[1], xr0, xr1, acc);
+        ENC_STAMP(3);
         acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
         barrier_lds();
+        ENC_STAMP(4);
+        // (every row pass: arithmetic and the X image first, barrier, and only then the saved-state stores -- nobody on the chain waits for them)
+        float sa[NTT][8], sb[NTT][8], sr[NTT];
         {
             float gam[8], bet[8], bo[8];
             lds8(bo, vecs + VF_BO * 256 + rl.slot * 8); lds8(gam, vecs + VF_G1 * 256 + rl.slot * 8); lds8(bet, vecs + VF_BE1 * 256 + rl.slot * 8);
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
-                const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
-                float v[8], xh[8], y[8], rstd;
+                float v[8];
                 lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = res[tt][e] + (v[e] + bo[e]);
-                layer_norm8(v, gam, bet, xh, y, rstd);
-                store8(a.x1 + off, y, ok[tt]);
-                store8(a.xhat1 + off, xh, ok[tt]);
-                if (ok[tt] && rl.slot == 0) a.rstd1[row0 + tt * 16 + rl.n16] = rstd;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) res[tt][e] = y[e];
-                row_to_ximg(y, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+                layer_norm8(v, gam, bet, sb[tt], res[tt], sr[tt]);           // res <- x1: the residual of the feed-forward block
+                row_to_ximg(res[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
             }
         }
+        ENC_STAMP(5);
         barrier_lds();
+        ENC_STAMP(6);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
+            store8(a.x1 + off, res[tt], ok[tt]);
+            store8(a.xhat1 + off, sb[tt], ok[tt]);
+            if (ok[tt] && rl.slot == 0) a.rstd1[row0 + tt * 16 + rl.n16] = sr[tt];
+        }
         // ---- conv1 + GELU (transformer_net.py:38-41)
         acc.zero();
         gemm<NTT, true>(ws, R, a.img[1], a.img[2], xr0, xr1, acc);
+        ENC_STAMP(7);
         acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
         barrier_lds();
+        ENC_STAMP(8);
         {
             float b1[8];
             lds8(b1, vecs + VF_BC1 * 256 + rl.slot * 8);
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
-                const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
-                float v[8], h[8];
-                lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
+                lds8(sa[tt], Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] += b1[e]; h[e] = gelu_exact(v[e]); }
-                store8(a.pre + off, v, ok[tt]);
-                store8(a.act + off, h, ok[tt]);
-                row_to_ximg(h, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+                for (int e = 0; e < 8; ++e) { sa[tt][e] += b1[e]; sb[tt][e] = gelu_exact(sa[tt][e]); }
+                row_to_ximg(sb[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
             }
         }
+        ENC_STAMP(9);
         barrier_lds();
+        ENC_STAMP(10);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
+            store8(a.pre + off, sa[tt], ok[tt]);
+            store8(a.act + off, sb[tt], ok[tt]);
+        }
         // ---- conv2, residual, LayerNorm2 (transformer_net.py:42-44) (+ encoder.norm behind the last layer, :68)
         acc.zero();
         gemm<NTT, NEXT != 0>(ws, R, a.img[2], a.img[3], xr0, xr1, acc);
+        ENC_STAMP(11);
         acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
         barrier_lds();
+        ENC_STAMP(12);
+        float sc[NEXT == 2 ? NTT : 1][8], sd[NEXT == 2 ? NTT : 1][8], sq[NEXT == 2 ? NTT : 1];
         {
             float gam[8], bet[8], b2[8];
             lds8(b2, vecs + VF_BC2 * 256 + rl.slot * 8); lds8(gam, vecs + VF_G2 * 256 + rl.slot * 8); lds8(bet, vecs + VF_BE2 * 256 + rl.slot * 8);
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
-                const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
-                float v[8], xh[8], y[8], rstd;
+                float v[8];
                 lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = res[tt][e] + (v[e] + b2[e]);
-                layer_norm8(v, gam, bet, xh, y, rstd);
-                store8(a.x2 + off, y, ok[tt]);
-                store8(a.xhat2 + off, xh, ok[tt]);
-                if (ok[tt] && rl.slot == 0) a.rstd2[row0 + tt * 16 + rl.n16] = rstd;
+                layer_norm8(v, gam, bet, sb[tt], sa[tt], sr[tt]);            // sa <- x2, the layer output
                 if constexpr (NEXT == 2) {
-                    float gf[8], bf[8], xh2[8], y2[8], rstdf;
+                    float gf[8], bf[8];
                     lds8(gf, vecs + VF_GF * 256 + rl.slot * 8); lds8(bf, vecs + VF_BEF * 256 + rl.slot * 8);
-                    layer_norm8(y, gf, bf, xh2, y2, rstdf);
-                    store8(a.xf + off, y2, ok[tt]);
-                    store8(a.xhatf + off, xh2, ok[tt]);
-                    if (ok[tt] && rl.slot == 0) a.rstdf[row0 + tt * 16 + rl.n16] = rstdf;
-                    row_to_ximg(y2, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+                    layer_norm8(sa[tt], gf, bf, sd[tt], sc[tt], sq[tt]);
+                    row_to_ximg(sc[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
                 } else if constexpr (NEXT == 1) {
-                    row_to_ximg(y, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+                    row_to_ximg(sa[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
                 }
             }
         }
+        ENC_STAMP(13);
         if constexpr (NEXT != 0) barrier_lds();
+        ENC_STAMP(14);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            const int64_t off = (int64_t)(row0 + tt * 16 + rl.n16) * kD + rl.slot * 8;
+            store8(a.x2 + off, sa[tt], ok[tt]);
+            store8(a.xhat2 + off, sb[tt], ok[tt]);
+            if (ok[tt] && rl.slot == 0) a.rstd2[row0 + tt * 16 + rl.n16] = sr[tt];
+            if constexpr (NEXT == 2) {
+                store8(a.xf + off, sc[tt], ok[tt]);
+                store8(a.xhatf + off, sd[tt], ok[tt]);
+                if (ok[tt] && rl.slot == 0) a.rstdf[row0 + tt * 16 + rl.n16] = sq[tt];
+            }
+        }
     }
     if constexpr (NEXT == 1) {
         // ---- the next layer's q / k / v projections (attn.py:183-185): three GEMMs on the same row block, straight to global memory
         acc.zero();
         gemm<NTT, true>(ws, R, a.img[kFirstNext], a.img[kFirstNext + 1], xr0, xr1, acc);
         acc_to_global<NTT>(acc, a.y0, vecs + VF_BN0 * 256, rscale, row0, a.rows, wave, lane);
+        ENC_STAMP(15);
         acc.zero();
         gemm<NTT, true>(ws, R, a.img[kFirstNext + 1], a.img[kFirstNext + 2], xr0, xr1, acc);
         acc_to_global<NTT>(acc, a.y1, vecs + VF_BN1 * 256, rscale, row0, a.rows, wave, lane);
+        ENC_STAMP(16);
         acc.zero();
         gemm<NTT, false>(ws, R, a.img[kFirstNext + 2], 0, xr0, xr1, acc);
         acc_to_global<NTT>(acc, a.y2, vecs + VF_BN2 * 256, rscale, row0, a.rows, wave, lane);
+        ENC_STAMP(17);
     } else if constexpr (NEXT == 2) {
         // ---- the output projection (transformer_net.py:129)
         acc.zero();
@@ -454,6 +513,7 @@ struct BwdArgs {
     const float* vec[3];
     float *gs2, *dpre, *gs1, *dout, *gx;
     float *partial_f, *partial2, *partial1;      // [workgroups][512]: sums over the workgroup's rows of g xhat | g
+    ENC_TL_ARG
 };
 
 // the wave's LayerNorm parameter partials (lanes 0-31 after joining the two token halves) -> red[wave][512]
@@ -485,17 +545,7 @@ __global__ __launch_bounds__(kThreads) void dpn_enc_bwd_kernel(BwdArgs a) {
     float* red = reinterpret_cast<float*>(smem + Lds<NTT>::kRed);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * 16 * NTT;
-    WStream ws;
-    ws.init(a.wpack, a.wbytes, wave, lane);
-    Ring R;
-    if constexpr (HEAD != 0 || BODY) {
-#pragma unroll
-        for (int ks = 0; ks < kPF; ++ks) ws.load(R.a[ks], a.img[0], ks);
-    }
-    for (int i = tid; i < 3 * 64; i += kThreads) {
-        const float* src = a.vec[i >> 6];
-        if (src) reinterpret_cast<float4*>(vecs)[i] = reinterpret_cast<const float4*>(src)[i & 63];
-    }
+    ENC_STAMP(0);
     const RowLane rl(wave, lane);
     const int n_r = lane & 15, g_r = lane >> 4;
     const char* xr0 = ximg + (g_r * 16 + (n_r ^ g_r)) * 16;
@@ -508,68 +558,106 @@ __global__ __launch_bounds__(kThreads) void dpn_enc_bwd_kernel(BwdArgs a) {
         ok[tt] = row < a.rows;
         off[tt] = (int64_t)row * kD + rl.slot * 8;
     }
+    // Order of the first loads (vector memory returns in order): the head's input rows, the parameter vectors, the weight stream's first
+    // k-steps, and last the saved rows the later row passes need -- in flight from the start, each would otherwise be a cold round trip on
+    // the chain, but nothing before the first GEMM waits for them.
+    float hq[HEAD == 1 ? NTT : 1][8], hk[HEAD == 1 ? NTT : 1][8], hv[NTT][8], g[NTT][8];
+    float xhf[HEAD == 2 ? NTT : 1][8], rsf[HEAD == 2 ? NTT : 1];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        if constexpr (HEAD == 1) {
+            load8(hq[tt], a.dq + off[tt], ok[tt]); load8(hk[tt], a.dk + off[tt], ok[tt]); load8(hv[tt], a.dv + off[tt], ok[tt]);
+        } else if constexpr (HEAD == 2) {
+            load8(hv[tt], a.dmeta + off[tt], ok[tt]);
+        } else {
+            load8(g[tt], a.gin + off[tt], ok[tt]);
+        }
+    }
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 3 * 64) {
+        const float* src = a.vec[tid >> 6];
+        if (src) pv = reinterpret_cast<const float4*>(src)[tid & 63];
+    }
+    WStream ws;
+    ws.init(a.wpack, a.wbytes, wave, lane);
+    constexpr int kPF = pf_of<NTT>();
+    Ring<kPF> R;
+#pragma unroll
+    for (int ks = 0; ks < kPF; ++ks) ws.load(R.a[ks], a.img[0], ks);
+    float xh2[BODY ? NTT : 1][8], prv[BODY ? NTT : 1][8], xh1[BODY ? NTT : 1][8], rs2[BODY ? NTT : 1], rs1[BODY ? NTT : 1];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        if constexpr (HEAD == 1) load8(g[tt], a.res + off[tt], ok[tt]);                 // g <- the residual-branch cotangent; the GEMM is added to it
+        if constexpr (HEAD == 2) {
+            load8(xhf[tt], a.xhatf + off[tt], ok[tt]);
+            rsf[tt] = ok[tt] ? a.rstdf[row0 + tt * 16 + rl.n16] : 0.f;
+        }
+        if constexpr (BODY) {
+            load8(xh2[tt], a.xhat2 + off[tt], ok[tt]);
+            load8(prv[tt], a.pre + off[tt], ok[tt]);
+            load8(xh1[tt], a.xhat1 + off[tt], ok[tt]);
+            rs2[tt] = ok[tt] ? a.rstd2[row0 + tt * 16 + rl.n16] : 0.f;
+            rs1[tt] = ok[tt] ? a.rstd1[row0 + tt * 16 + rl.n16] : 0.f;
+        }
+    }
+    if (tid < 3 * 64) reinterpret_cast<float4*>(vecs)[tid] = pv;
     Acc<NTT> acc;
-    float g[NTT][8];                             // the cotangent of the layer output on the lane's rows
     constexpr int kHeadImgs = HEAD == 1 ? 3 : HEAD == 2 ? 1 : 0;
     if constexpr (HEAD == 1) {
         // ---- d x = res + dq Wq + dk Wk + dv Wv (attn.py:183-185 backward): one K = 768 reduction, common row scale for the three operands
-        float res[NTT][8];
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
-            float q[8], k[8], v[8];
-            load8(q, a.dq + off[tt], ok[tt]); load8(k, a.dk + off[tt], ok[tt]); load8(v, a.dv + off[tt], ok[tt]);
-            load8(res[tt], a.res + off[tt], ok[tt]);
-            const float m = fmaxf(row_absmax(q), fmaxf(row_absmax(k), row_absmax(v)));
-            row_to_ximg(q, m, rl, ximg + tt * kXImg, rscale + tt * 16);
-            row_to_ximg(k, m, rl, ximg + (NTT + tt) * kXImg, rscale + tt * 16);
-            row_to_ximg(v, m, rl, ximg + (2 * NTT + tt) * kXImg, rscale + tt * 16);
+            const float m = fmaxf(row_absmax(hq[tt]), fmaxf(row_absmax(hk[tt]), row_absmax(hv[tt])));
+            row_to_ximg(hq[tt], m, rl, ximg + tt * kXImg, rscale + tt * 16);
+            row_to_ximg(hk[tt], m, rl, ximg + (NTT + tt) * kXImg, rscale + tt * 16);
+            row_to_ximg(hv[tt], m, rl, ximg + (2 * NTT + tt) * kXImg, rscale + tt * 16);
         }
+        ENC_STAMP(1);
         barrier_lds();
+        ENC_STAMP(2);
         acc.zero();
         gemm<NTT, true>(ws, R, a.img[0], a.img[1], xr0, xr1, acc);
         gemm<NTT, true>(ws, R, a.img[1], a.img[2], xr0 + NTT * kXImg, xr1 + NTT * kXImg, acc);
         gemm<NTT, BODY>(ws, R, a.img[2], a.img[3], xr0 + 2 * NTT * kXImg, xr1 + 2 * NTT * kXImg, acc);
+        ENC_STAMP(3);
         acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
         barrier_lds();
+        ENC_STAMP(4);
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             float v[8];
             lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) g[tt][e] = v[e] + res[tt][e];
+            for (int e = 0; e < 8; ++e) g[tt][e] += v[e];
         }
     } else if constexpr (HEAD == 2) {
         // ---- output projection and encoder.norm backward (transformer_net.py:129, :68)
 #pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            float v[8];
-            load8(v, a.dmeta + off[tt], ok[tt]);
-            row_to_ximg(v, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
-        }
+        for (int tt = 0; tt < NTT; ++tt) row_to_ximg(hv[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+        ENC_STAMP(1);
         barrier_lds();
+        ENC_STAMP(2);
         acc.zero();
         gemm<NTT, BODY>(ws, R, a.img[0], a.img[1], xr0, xr1, acc);
+        ENC_STAMP(3);
         acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
         barrier_lds();
+        ENC_STAMP(4);
         float gam[8], pg[8], pb[8];
         lds8(gam, vecs + VB_GF * 256 + rl.slot * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { pg[e] = 0.f; pb[e] = 0.f; }
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
-            float v[8], xh[8];
+            float v[8];
             lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
-            load8(xh, a.xhatf + off[tt], ok[tt]);
-            const float rstd = ok[tt] ? a.rstdf[row0 + tt * 16 + rl.n16] : 0.f;
-            layer_norm_bwd8(v, xh, rstd, gam, g[tt], pg, pb);
+            layer_norm_bwd8(v, xhf[tt], rsf[tt], gam, g[tt], pg, pb);
         }
         partials_to_lds(pg, pb, red, wave, lane);
         barrier_lds();
         partials_to_global(red, a.partial_f, tid);
         barrier_lds();                                               // red is reused by LayerNorm2's partials
     } else {
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) load8(g[tt], a.gin + off[tt], ok[tt]);
         barrier_lds();                                               // the parameter vectors are in LDS
     }
     if constexpr (!BODY) {
@@ -577,8 +665,9 @@ __global__ __launch_bounds__(kThreads) void dpn_enc_bwd_kernel(BwdArgs a) {
         for (int tt = 0; tt < NTT; ++tt) store8(a.gx + off[tt], g[tt], ok[tt]);
         return;
     } else {
+        // (every row pass: arithmetic and the X image first, barrier, and only then the stores of the weight-gradient operands)
         // ---- LayerNorm2 backward (transformer_net.py:44): gs2 = d(x1 + ffn); it is both the conv2 cotangent and the residual branch
-        float res2[NTT][8];
+        float res2[NTT][8], sv[NTT][8];
         {
             float gam[8], pg[8], pb[8];
             lds8(gam, vecs + VB_G2 * 256 + rl.slot * 8);
@@ -586,38 +675,43 @@ __global__ __launch_bounds__(kThreads) void dpn_enc_bwd_kernel(BwdArgs a) {
             for (int e = 0; e < 8; ++e) { pg[e] = 0.f; pb[e] = 0.f; }
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
-                float xh[8];
-                load8(xh, a.xhat2 + off[tt], ok[tt]);
-                const float rstd = ok[tt] ? a.rstd2[row0 + tt * 16 + rl.n16] : 0.f;
-                layer_norm_bwd8(g[tt], xh, rstd, gam, res2[tt], pg, pb);
-                store8(a.gs2 + off[tt], res2[tt], ok[tt]);
+                layer_norm_bwd8(g[tt], xh2[tt], rs2[tt], gam, res2[tt], pg, pb);
                 row_to_ximg(res2[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
             }
             partials_to_lds(pg, pb, red, wave, lane);
         }
+        ENC_STAMP(5);
         barrier_lds();
+        ENC_STAMP(6);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) store8(a.gs2 + off[tt], res2[tt], ok[tt]);
         partials_to_global(red, a.partial2, tid);
         // ---- conv2^T and GELU' (transformer_net.py:41-42)
         acc.zero();
         gemm<NTT, true>(ws, R, a.img[kHeadImgs], a.img[kHeadImgs + 1], xr0, xr1, acc);
+        ENC_STAMP(7);
         acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
         barrier_lds();
+        ENC_STAMP(8);
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
-            float v[8], p[8];
-            lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
-            load8(p, a.pre + off[tt], ok[tt]);
+            lds8(sv[tt], Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= gelu_exact_grad(p[e]);
-            store8(a.dpre + off[tt], v, ok[tt]);
-            row_to_ximg(v, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+            for (int e = 0; e < 8; ++e) sv[tt][e] *= gelu_exact_grad(prv[tt][e]);
+            row_to_ximg(sv[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
         }
+        ENC_STAMP(9);
         barrier_lds();
+        ENC_STAMP(10);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) store8(a.dpre + off[tt], sv[tt], ok[tt]);
         // ---- conv1^T + residual branch, LayerNorm1 backward (transformer_net.py:37-38)
         acc.zero();
         gemm<NTT, true>(ws, R, a.img[kHeadImgs + 1], a.img[kHeadImgs + 2], xr0, xr1, acc);
+        ENC_STAMP(11);
         acc_to_staging<NTT>(acc, Y, rscale, wave, lane);
         barrier_lds();
+        ENC_STAMP(12);
         {
             float gam[8], pg[8], pb[8];
             lds8(gam, vecs + VB_G1 * 256 + rl.slot * 8);
@@ -625,24 +719,26 @@ __global__ __launch_bounds__(kThreads) void dpn_enc_bwd_kernel(BwdArgs a) {
             for (int e = 0; e < 8; ++e) { pg[e] = 0.f; pb[e] = 0.f; }
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
-                float v[8], xh[8], gs1[8];
+                float v[8];
                 lds8(v, Y + (tt * 16 + rl.n16) * kYS + rl.slot * 8);
-                load8(xh, a.xhat1 + off[tt], ok[tt]);
-                const float rstd = ok[tt] ? a.rstd1[row0 + tt * 16 + rl.n16] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += res2[tt][e];
-                layer_norm_bwd8(v, xh, rstd, gam, gs1, pg, pb);
-                store8(a.gs1 + off[tt], gs1, ok[tt]);
-                row_to_ximg(gs1, 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
+                layer_norm_bwd8(v, xh1[tt], rs1[tt], gam, sv[tt], pg, pb);
+                row_to_ximg(sv[tt], 0.f, rl, ximg + tt * kXImg, rscale + tt * 16);
             }
-            partials_to_lds(pg, pb, red, wave, lane);                // red: read by partials_to_global(partial2) before the previous two barriers
+            partials_to_lds(pg, pb, red, wave, lane);                // red: read by partials_to_global(partial2) two barriers ago
         }
+        ENC_STAMP(13);
         barrier_lds();
+        ENC_STAMP(14);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) store8(a.gs1 + off[tt], sv[tt], ok[tt]);
         partials_to_global(red, a.partial1, tid);
         // ---- out-projection^T (attn.py:196): the attention backward's input
         acc.zero();
         gemm<NTT, false>(ws, R, a.img[kHeadImgs + 2], 0, xr0, xr1, acc);
         acc_to_global<NTT>(acc, a.dout, nullptr, rscale, row0, a.rows, wave, lane);
+        ENC_STAMP(15);
     }
 }
 
@@ -690,6 +786,10 @@ int img_off(int mat, int nn) { return (mat * 2 + nn) * kImgBytes; }
 
 extern "C" {
 
+#ifdef DPN_ENC_TIMELINE
+void dpn_enc_debug_set_timeline(void* buf) { g_enc_timeline = static_cast<unsigned*>(buf); }
+#endif
+
 int64_t dpn_enc_pack_bytes(int n_mats) { return (int64_t)n_mats * 2 * kImgBytes; }
 
 int dpn_enc_pack(int n_mats, const float* const* weights, void* packed, int* status_dev, void* stream) {
@@ -731,6 +831,7 @@ int dpn_enc_fwd(const DpnEncFwd* p, void* stream) {
     for (int i = 0; i < kNVecF; ++i) a.vec[i] = vec[i];
     a.x1 = p->x1; a.xhat1 = p->xhat1; a.rstd1 = p->rstd1; a.pre = p->pre; a.act = p->act; a.x2 = p->x2; a.xhat2 = p->xhat2; a.rstd2 = p->rstd2;
     a.xf = p->xf; a.xhatf = p->xhatf; a.rstdf = p->rstdf; a.y0 = p->y0; a.y1 = p->y1; a.y2 = p->y2;
+    ENC_TL_SET(a);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rpw = wide ? 32 : 16;
     const dim3 grid((p->rows + rpw - 1) / rpw), block(kThreads);
@@ -777,6 +878,7 @@ int dpn_enc_bwd(const DpnEncBwd* p, void* stream) {
     a.vec[VB_G2] = p->g2; a.vec[VB_G1] = p->g1; a.vec[VB_GF] = p->gf;
     a.gs2 = p->gs2; a.dpre = p->dpre; a.gs1 = p->gs1; a.dout = p->dout; a.gx = p->gx;
     a.partial_f = p->partial_f; a.partial2 = p->partial2; a.partial1 = p->partial1;
+    ENC_TL_SET(a);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rpw = wide ? 32 : 16;
     const dim3 grid((p->rows + rpw - 1) / rpw), block(kThreads);

@@ -586,7 +586,10 @@ DPN_HD int64_t feature_bytes(int64_t n_pad, int ns) { return (n_pad / 64) * (int
 // by 19 us -- no net gain at six nets per point; without it the features are evaluated inside the kernels, hidden behind the partner wave.
 // DPN_FEATURES_PREPASS=2: only the d pe3 / d xi table of the Jacobian contraction (29 MB; that phase is 9 % of a wave's lifetime in the
 // timeline): same-box steps 1.618-1.623 ms against 1.624 ms without -- nothing either, the phase overlaps the partner workgroup's MFMAs
-static int features_prepass() { const char* e = getenv("DPN_FEATURES_PREPASS"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
+static int features_prepass() {        // latched at the first call: dpn_sizes and dpn_fwd must agree on the size of the saved buffer
+    static const int mode = [] { const char* e = getenv("DPN_FEATURES_PREPASS"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+    return mode;
+}
 static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_pad, ns) + (features_prepass() ? feature_bytes(n_pad, ns) : 0); }
 
 struct OperandView {     // written by dpn_bwd_points

@@ -434,6 +434,8 @@ class _HeadsFn(torch.autograd.Function):
         # the 6 outer products exactly the 24 problems a launch takes).  Same box, 300-step runs, three times each: NP = 2 1.614 ms per
         # step, 3 1.591, 4 1.614 (rounds 1-3), 6 1.580
         NP = int(os.environ.get('DPN_HEADS_DMETA_PARTS', '6'))
+        if NP not in (1, 2, 3, 4, 6, 12):
+            raise ValueError('DPN_HEADS_DMETA_PARTS must divide the twelve heads (1, 2, 3, 4, 6 or 12), got %d' % NP)
         parts = torch.empty((NP, 256, 256), dtype=torch.float32, device=dev)
         n_tail = (Lt - 256) * 256                                # tokens >= 256 feed no VariableNet: their gradient rows are zero
         for f in range(B):

@@ -275,11 +275,19 @@ class InterfacePhysics(nn.Module):
         staged = (grad_sync is not None and hasattr(grad_sync, 'reduce_bucket') and grad_sync.active() and isinstance(optimizer, FusedClipAdam)
                   and heads is not None)
         if staged:
+            # the staged form needs THIS optimiser's flat buffer laid out in the three buckets of gradient_buckets() and every parameter
+            # trainable; anything else (an optimiser built without `layout`, a reducer bound to another optimiser or to none, frozen
+            # parameters) takes the plain backward + grad_sync(parameters) below
+            buckets = self.physics_net.gradient_buckets()
+            lay = getattr(optimizer, 'layout_ids', None)
+            staged = (getattr(grad_sync, 'opt', None) is optimizer and len(getattr(optimizer, 'bucket_bounds', ())) == 3
+                      and lay == [[id(p) for p in b_] for b_ in buckets]
+                      and all(p.requires_grad for b_ in buckets for p in b_))
+        if staged:
             # data-parallel step: the backward pass is cut where a bucket of gradients is complete and that bucket's all-reduce is queued at
             # once, so it travels under the rest of the backward (what DistributedDataParallel's bucket hooks do in the reference, :903-907,
             # :1056).  Layout buckets (PhysicsNet.gradient_buckets): point statics | hyper-network heads | encoder; the first two travel as
             # ONE all-reduce (the heads' backward is two launches: a collective of its own costs more than the 40 us it could start earlier)
-            buckets = self.physics_net.gradient_buckets()
             g = torch.autograd.grad(train_loss, [heads, evec] + list(statics), grad_outputs=self._seed)
             optimizer.place_gradients(list(statics), g[2:])
             g2 = torch.autograd.grad([heads, evec], [meta_out] + buckets[1], grad_outputs=[g[0], g[1]], allow_unused=True)
@@ -330,16 +338,21 @@ class InterfacePhysics(nn.Module):
         src = kwargs.get('samples', self.train_cfg.get('train_data', {}).get('samples'))
         if src is None:
             # the reference's PhysicsDataset reads GeoTIFF / xarray files (dataset/physics_dataset.py: file I/O outside this build, SURVEY.md
-            # section 2 row 10; no data exists offline): without a `samples` source the loop draws synthetic field samples and collocation
-            # batches of the configured sizes on the device, so that train.py's two-keyword call runs end to end
+            # section 2 row 10) and fails when they are missing; so does this loop.  Synthetic data is an explicit choice.
+            raise RuntimeError("run_train_interface: no `samples` source (a sequence / callable of training batches, as keyword or as "
+                               "train_cfg['train_data']['samples']).  samples='synthetic' (train.py --synthetic) draws random field samples "
+                               "and on-device collocation batches instead -- noise, for smoke runs only")
+        if isinstance(src, str):
+            if src != 'synthetic':
+                raise ValueError("samples=%r: the only named source is 'synthetic'" % src)
             if getattr(self, '_synthetic_samples', None) is None:
                 from ..sampler import SyntheticSamples
                 td = self.train_cfg.get('train_data', {})
                 dev = next(self.physics_net.parameters()).device
                 self._synthetic_samples = SyntheticSamples(dev, n_margin=td.get('label_batch_size', 20480), n_inter=td.get('batch_size_inter', 4096),
                                                            leads=int(kwargs.get('samples_per_epoch', 61)), lat=self.lat_size, lon=self.lon_size)
-                print('run_train_interface: no `samples` source configured -- synthetic field samples (%d per epoch) and on-device collocation '
-                      'batches are used' % len(self._synthetic_samples))
+                print("run_train_interface: samples='synthetic' -- random field samples (%d per epoch) and on-device collocation batches; "
+                      "the checkpoints of this run are trained on noise" % len(self._synthetic_samples))
             return self._synthetic_samples
         return src(epoch) if callable(src) else src
 
@@ -372,18 +385,14 @@ class InterfacePhysics(nn.Module):
             yield buf[rank]
 
     def _epoch_samples(self, kwargs, epoch, rank, world):
-        """The epoch's samples of this rank.  `samples` may be a callable: samples(epoch) -> all samples (sharded here), or
+        """The epoch's samples of this rank.  `samples` may be a callable samples(epoch) -> all samples, sharded here like DistributedSampler
+        WITHOUT its shuffle (:936 shuffles a seed-0 permutation per epoch; here rank r takes samples r, r + world, ... in the given order:
+        shuffle in the source if wanted).  With samples_per_rank=True (keyword, or attribute `samples.per_rank = True`) the callable is
         samples(epoch, rank, world) -> this rank's samples only (nothing is drawn for the other ranks)."""
         src = kwargs.get('samples', self.train_cfg.get('train_data', {}).get('samples'))
-        if callable(src):
-            import inspect
-            try:
-                n_args = len([q for q in inspect.signature(src).parameters.values()
-                              if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
-            except (TypeError, ValueError):
-                n_args = 1
-            if n_args >= 3:
-                return src(epoch, rank, world)
+        per_rank = kwargs.get('samples_per_rank', getattr(src, 'per_rank', False))
+        if callable(src) and per_rank:                   # explicit protocol (keyword samples_per_rank=True or attribute samples.per_rank)
+            return src(epoch, rank, world)
         return self._shard_samples(self._train_samples(kwargs, epoch), rank, world)
 
     def _run_train(self, dist_mode, **kwargs):

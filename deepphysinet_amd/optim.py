@@ -56,6 +56,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         for p in self.params:
             self._offsets.append(off)
             off += ((p.numel() + _CHUNK - 1) // _CHUNK) * _CHUNK
+        self.layout_ids = [[id(p) for p in b] for b in layout]       # which parameters each bucket of the flat buffers holds
         self.bucket_bounds, pos, k = [], 0, 0                       # [(start, end)] float offsets of each layout bucket in the flat buffers
         for b in layout:
             end = self._offsets[k + len(b)] if k + len(b) < n else total

@@ -339,7 +339,7 @@ class _PdeLossBatchFn(torch.autograd.Function):
         return starts
 
     @staticmethod
-    def forward(ctx, cfg, x, y, t, f, coord_data, heads, evec, *statics):
+    def forward(ctx, cfg, grad_enabled, x, y, t, f, coord_data, heads, evec, *statics):
         for nm, v in (('x', x), ('coord_data', coord_data), ('heads', heads)):
             _require_gpu(v, nm)
         lib = L.load()
@@ -348,7 +348,9 @@ class _PdeLossBatchFn(torch.autograd.Function):
         cd_, hd_, ev_ = _f32c(coord_data), _f32c(heads), _f32c(evec)
         st = [_f32c(s) for s in statics]
         dev = cd_.device
-        need_grad = any(v.requires_grad for v in (heads, evec) + tuple(statics))
+        # Function.forward always runs with grad mode off: the caller's mode arrives as an argument (pde_losses_batch), so that a no-grad
+        # evaluation (validation, place_lead_batch scoring) neither saves state nor runs each field's point backward
+        need_grad = bool(grad_enabled) and any(v.requires_grad for v in (heads, evec) + tuple(statics))
         eager = need_grad and _PdeLossBatchFn.EAGER
         losses7 = torch.empty((B, 7), dtype=torch.float32, device=dev)
         sums = torch.empty(((n + 255) // 256) * 6, dtype=torch.float64, device=dev)
@@ -393,7 +395,7 @@ class _PdeLossBatchFn(torch.autograd.Function):
         B, n = cd_.shape[0], cd_.shape[1]
         dev = cd_.device
         if g_losses is None and g_total is None:
-            return (None,) * (8 + len(st))
+            return (None,) * (9 + len(st))
         starts = _PdeLossBatchFn._static_layout()
         if ctx.eager is not None and g_losses is None:
             # the gradients are there for unit cotangents of the B totals: scale them by the cotangents that arrived
@@ -434,7 +436,7 @@ class _PdeLossBatchFn(torch.autograd.Function):
         total = torch.empty(starts[-1], dtype=torch.float32, device=dev)
         L.check(lib.dpn_sum_parts(_ptr(flat), B, starts[-1], 0, _ptr(total), _stream()), 'dpn_sum_parts')
         gst = [total[starts[i]:starts[i + 1]].view(STATIC_SHAPES[i % 8]) for i in range(48)]
-        return (None, None, None, None, None, None, g_heads, g_evec, *gst)
+        return (None, None, None, None, None, None, None, g_heads, g_evec, *gst)
 
 
 class _StepLossFn(torch.autograd.Function):
@@ -513,7 +515,7 @@ def step_losses(cfg: PointConfig, n_inter, x, y, t, f, coord_data, labels, heads
 
 def pde_losses_batch(cfg: PointConfig, x, y, t, f, coord_data, heads, evec, statics):
     """(losses [B,6], totals [B]) for B field samples with N points each; tensors carry a leading B (see _PdeLossBatchFn)."""
-    return _PdeLossBatchFn.apply(cfg, x, y, t, f, coord_data, heads, evec, *statics)
+    return _PdeLossBatchFn.apply(cfg, torch.is_grad_enabled(), x, y, t, f, coord_data, heads, evec, *statics)
 
 
 def point_fields(cfg: PointConfig, coord_data, heads, evec, statics, x=None, y=None, t=None, pe_in=None):

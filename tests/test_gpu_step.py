@@ -462,15 +462,15 @@ def test_data_parallel_training_step_overlaps_buckets_and_matches_the_plain_step
 def test_train_py_two_keyword_call_runs_end_to_end(tmp_path):
     """SURVEY section 2 row 18 / VERDICT r2 J3: `python train.py --checkpoint_path D --log_path L` (the reference's launcher flags,
     train.py:17-19) builds the interface from the NCEP configuration and calls run_train_interface(checkpoint_path=, log_path=) exactly as
-    the reference does (train.py:47); with no `samples` source configured the loop draws synthetic field samples and on-device collocation
-    batches.  Two steps, then a resume."""
+    the reference does (train.py:47); --synthetic opts in to random field samples and on-device collocation batches (without a `samples`
+    source the loop raises, test_host_logic_cpu).  Two steps, then a resume."""
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
     ck = str(tmp_path / 'ck')
     for want in ('global_step 2', 'global_step 3'):
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '--checkpoint_path', ck, '--log_path', str(tmp_path / 'log'),
-                            '--max_steps', want.split()[-1]], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                            '--max_steps', want.split()[-1], '--synthetic'], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         assert want in r.stdout, r.stdout[-2000:]
         # the checkpoint is written at epoch end only; a run cut by --max_steps inside epoch 0 writes it when the epoch loop leaves

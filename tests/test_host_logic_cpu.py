@@ -246,3 +246,39 @@ def test_resmlp_and_min_max_inverse_norm_follow_the_reference(model):
     out = model.inverse_norm(*v, cfg)
     assert torch.allclose(out[3], torch.full((3, 1), 260.0)) and torch.allclose(out[4], torch.full((3, 1), 0.1 ** 2 + 1e-5))
     assert torch.allclose(out[0], torch.full((3, 1), 0.5 * 3.0050219075895894 + 0.14507186950562942))
+
+
+# ------------------------------------------------------------------------------------------------ round 4: ADVICE r3
+def test_training_samples_are_never_synthetic_by_default_and_the_per_rank_protocol_is_explicit(model):
+    """ADVICE r3 (medium / low): (a) a loop without a `samples` source raises like the reference does without its data files -- synthetic
+    data needs samples='synthetic' (train.py --synthetic); (b) a `samples` callable is called as samples(epoch) and sharded here unless the
+    per-rank protocol is selected explicitly (keyword samples_per_rank=True or attribute .per_rank), whatever its signature."""
+    with pytest.raises(RuntimeError, match="samples='synthetic'"):
+        model._train_samples({}, 0)
+    with pytest.raises(ValueError, match='synthetic'):
+        model._train_samples({'samples': 'random'}, 0)
+    calls = []
+
+    def all_samples(epoch, shuffle=True, seed=0):                     # three positional parameters, but NOT the per-rank protocol
+        calls.append((epoch, shuffle, seed))
+        return list(range(5))
+    assert list(model._epoch_samples({'samples': all_samples}, 7, 1, 2)) == [1, 3, 0]       # sharded here: 1, 3, then the wrapped tail
+    assert calls == [(7, True, 0)]
+
+    def mine(epoch, rank, world):
+        return ['e%d r%d/%d' % (epoch, rank, world)]
+    assert list(model._epoch_samples({'samples': mine, 'samples_per_rank': True}, 2, 1, 4)) == ['e2 r1/4']
+    mine.per_rank = True
+    assert list(model._epoch_samples({'samples': mine}, 3, 0, 2)) == ['e3 r0/2']
+
+
+def test_staged_data_parallel_step_is_only_taken_with_the_matching_optimiser_layout():
+    """FusedClipAdam records which parameters each bucket of its flat buffers holds (`layout_ids`), so that
+    training_step can tell an optimiser laid out like PhysicsNet.gradient_buckets() (staged backward + per-bucket all-reduce) from one
+    built without a layout (plain backward + grad_sync(parameters))."""
+    import inspect
+    from deepphysinet_amd.interface import interface_physics
+    src = inspect.getsource(interface_physics.InterfacePhysics.training_step)
+    assert "getattr(grad_sync, 'opt', None) is optimizer" in src and 'layout_ids' in src and 'requires_grad' in src
+    from deepphysinet_amd import optim
+    assert 'self.layout_ids' in inspect.getsource(optim.FusedClipAdam.__init__)

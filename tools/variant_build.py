@@ -1,6 +1,8 @@
-"""Experiment builds of the library: only the point unit is recompiled with extra -D flags, the other objects come from the product build.
+"""Experiment builds of the library: only ONE unit (default: the point unit) is recompiled with extra -D flags, the other objects come from
+the product build.
 
-    python tools/variant_build.py NAME [-DFLAG ...]      ->  deepphysinet_amd/libdpn_hip_NAME.so   (select it with DPN_LIB=<path>)
+    python tools/variant_build.py NAME [--unit=I] [-DFLAG ...]      ->  deepphysinet_amd/libdpn_hip_NAME.so   (select it with DPN_LIB=<path>)
+    (--unit=I: index into deepphysinet_amd.build.UNITS; 5 = the row-local encoder nodes, csrc/dpn_encoder_chain.hip)
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,19 +10,26 @@ sys.path.insert(0, ROOT)
 from deepphysinet_amd import build as B
 
 
-def build(name, extra):
+def build(name, extra, unit=0):
     obj = os.path.join(B.HERE, 'csrc', '_obj')
     # the product library is NOT rebuilt here: an experiment that edits a header must not leak into libdpn_hip.so (it did once: a timing
     # ablation with wrong arithmetic sat in the product library until the next build).  Only the objects of the other units are needed.
-    if not all(os.path.exists(os.path.join(obj, u[2])) for u in B.UNITS[1:]):
+    others = [u for i, u in enumerate(B.UNITS) if i != unit]
+    if not all(os.path.exists(os.path.join(obj, u[2])) for u in others):
         B.build_library()
-    src, flags, base = B.UNITS[0]
+    src, flags, base = B.UNITS[unit]
     o = os.path.join(obj, 'var_%s_%s' % (name, base))
     subprocess.run(['hipcc', *B.COMMON, *flags, *extra, '-I' + os.path.join(ROOT, 'include'), '-c', src, '-o', o], check=True)
     lib = os.path.join(B.HERE, 'libdpn_hip_%s.so' % name)
-    subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', o, *[os.path.join(obj, u[2]) for u in B.UNITS[1:]], '-o', lib], check=True)
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', o, *[os.path.join(obj, u[2]) for u in others], '-o', lib], check=True)
     return lib
 
 
 if __name__ == '__main__':
-    print(build(sys.argv[1], sys.argv[2:]))
+    args = sys.argv[2:]
+    unit = 0
+    for a in list(args):
+        if a.startswith('--unit='):
+            unit = int(a.split('=')[1])
+            args.remove(a)
+    print(build(sys.argv[1], args, unit))

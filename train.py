@@ -1,15 +1,15 @@
 #!/usr/bin/env python
 """Launcher with the reference's three flags (reference train.py:17-19, :34-48): --config_file, --checkpoint_path, --log_path.
 
-    python train.py [--config_file cfg.py] [--checkpoint_path DIR] [--log_path DIR] [--dist] [--max_steps N]
+    python train.py [--config_file cfg.py] [--checkpoint_path DIR] [--log_path DIR] [--dist] [--max_steps N] [--synthetic]
 
 The reference reads the config with mmcv.Config.fromfile (absent here, and moved to mmengine in the pinned mmcv: SURVEY section 0, defect
 3), builds the interface with `builder_models(**cfg['config'])` and calls `run_train_interface(checkpoint_path=..., log_path=...)`.  The
 same happens here: a python config file that defines `config = dict(...)` is exec'd (the format of configs/DeepPhysiNet_NCEP_cfg.py);
 without --config_file the built-in copy of that config (deepphysinet_amd.configs.ncep_config) is used.  The reference's PhysicsDataset
-reads GeoTIFF / xarray files that do not exist offline (out of scope); when the config names no `samples`
-source, the loop draws its batches from the on-device CollocationSampler over synthetic coarse / label cubes of the configured shapes, so
-the two-keyword call of the reference runs end to end.  --dist selects run_train_interface_dist (start with torchrun)."""
+reads GeoTIFF / xarray files that do not exist offline (out of scope); a config that names no `samples`
+source therefore FAILS like the reference without its files, unless --synthetic asks for random field samples and batches from the
+on-device CollocationSampler (smoke runs: the checkpoints are trained on noise).  --dist selects run_train_interface_dist (torchrun)."""
 import argparse
 import os
 import runpy
@@ -26,6 +26,9 @@ parse.add_argument('--checkpoint_path', default=None, type=str)
 parse.add_argument('--log_path', default=None, type=str)
 parse.add_argument('--dist', action='store_true', help='data-parallel loop (run_train_interface_dist); start with torchrun')
 parse.add_argument('--max_steps', default=None, type=int)
+parse.add_argument('--synthetic', action='store_true', help="samples='synthetic': random field samples and on-device collocation batches "
+                   '(the reference dataset is file I/O that does not exist offline); without it a config with no `samples` source fails, '
+                   'as the reference does without its data files')
 
 
 def load_config(path):
@@ -51,6 +54,8 @@ if __name__ == '__main__':
     kwargs = dict(checkpoint_path=args.checkpoint_path, log_path=args.log_path)
     if args.max_steps is not None:
         kwargs['max_steps'] = args.max_steps
+    if args.synthetic:
+        kwargs['samples'] = 'synthetic'
     run = model.run_train_interface_dist if args.dist else model.run_train_interface
     out = run(**kwargs)
     print('done: epoch %d, global_step %d, lr %.3e' % (out['epoch'], out['global_step'], out['lr']))
