@@ -355,6 +355,14 @@ def main():
             terms = m.pde_loss_terms(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'], batch['forecast_h'])
         out['pde_losses'] = dict(zip(('motion_u', 'motion_v', 'continuous', 'energy', 'vapor', 'gas'), [float(v) for v in terms.cpu()]))
 
+    if rank == 0 and args.leads > 1:               # configs[2]: the six scalars averaged over the fields, and whether the run stayed finite
+        with torch.no_grad():
+            _, terms = m.place_lead_batch(lead['x'], lead['y'], lead['t'], lead['f'], lead['field_data'], lead['coord_data'], lead['forecast_h'], crit,
+                                          m.train_cfg['losses']['loss_factor'])
+        tm = terms.float().mean(dim=0).cpu()
+        out['pde_losses'] = dict(zip(('motion_u', 'motion_v', 'continuous', 'energy', 'vapor', 'gas'), [float(v) for v in tm]))
+        out['parameters_finite'] = bool(all(bool(torch.isfinite(p_).all()) for p_ in m.physics_net.parameters()))
+
     def kernel_rooflines(m, prec):
         """`roofline` (dpn_fwd_kernel, MFMA-bound: the dominant kernel) and `roofline_hbm_kernel` (dpn_wgrad_kernel) of the workload in
         precision mode `prec`, durations measured live with a HIP event pair around every launch inside a pre-queued replay of the point path."""

@@ -64,7 +64,12 @@ class DpnEncBwd(Structure):
                                         'gs2', 'dpre', 'gs1', 'dout', 'gx', 'partial_f', 'partial2', 'partial1')]
 
 
+class DpnWgradProblem(Structure):
+    _fields_ = [('G', c_void_p), ('X', c_void_p), ('dW', c_void_p), ('db', c_void_p)] + [(n, c_int32) for n in ('M', 'N', 'rows', 'ldg', 'ldx', 'ldw')]
+
+
 ENC_MAX_MATS = 32
+WGRAD_MAX_PROBLEMS = 32
 GEMM_MAX_PROBLEMS, GEMM_MAX_JOBS = 26, 10
 
 
@@ -108,6 +113,8 @@ EXPORTS = {
     'dpn_attn_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_enc_pack_bytes': (c_int64, [c_int]),
     'dpn_enc_pack': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_wgrad16_partial_floats': (c_int64, [c_int, c_void_p, c_int]),
+    'dpn_wgrad16': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'dpn_enc_fwd': (c_int, [POINTER(DpnEncFwd), c_void_p]),
     'dpn_enc_bwd': (c_int, [POINTER(DpnEncBwd), c_void_p]),
     'dpn_add_ln_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

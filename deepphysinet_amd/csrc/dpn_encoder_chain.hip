@@ -776,6 +776,162 @@ __global__ __launch_bounds__(256) void dpn_enc_pack_kernel(PackArgs a) {
     *reinterpret_cast<u32x4*>(dst + 1024) = lo;
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+// d W[M][N] = G^T X over the token rows (G: the cotangent [rows][M] of a linear's output, X: its input [rows][N]); d b = column sums of G.
+// (attn.py:183-196, transformer_net.py:38-42, :129 backward; embed.py:45-47: the token convolution's weight gradient with X = the im2col rows.)
+// One launch for all linears of the encoder stack: a workgroup owns a 64 x 64 tile of one d W and walks the rows 32 at a time.  The operand
+// layouts need no transposition: a lane that loads eight consecutive rows of ONE column holds exactly an MFMA fragment slot (k = row).  The
+// G columns of a wave are private (its own 16 x 64 strip of the tile), the X fragments are shared through LDS (double-buffered, one barrier
+// per 32 rows).  Same f16 hi+lo split as the GEMMs above; the range is handled like a running softmax maximum: every 32-row block is scaled
+// by a power of two taken from the largest magnitude seen SO FAR in that operand strip, and when a block raises it the accumulators are
+// rescaled (exact: powers of two) -- cotangent rows that differ by many decades (a field whose loss is 100 x the median's) cost nothing.
+// Long reductions (batches of fields) are cut into row slices whose partial tiles dpn_wgrad16_reduce adds in a fixed order.
+struct WgProblem {
+    const float *G, *X;
+    float *dW, *db;
+    int M, N, rows, ldg, ldx, ldw;
+    int64_t part_off;                            // floats: this problem's partials [slices][M * N + M]
+};
+constexpr int kWgMaxProblems = DPN_WGRAD_MAX_PROBLEMS, kWgMaxJobs = DPN_GEMM_MAX_JOBS;
+struct WgJob { const float* partial; float* out_a; float* out_b; int nblocks, pad; };
+struct WgArgs {
+    WgProblem p[kWgMaxProblems];
+    WgJob job[kWgMaxJobs];
+    int n, slices, rows_per_slice;
+    float* partials;
+};
+static_assert(sizeof(WgArgs) <= 4096, "kernel arguments");
+
+DEV float wave_absmax_uniform(float m) {         // maximum over the 64 lanes as a wave-uniform value
+    m = half_max(m);
+    return fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 32)));
+}
+DEV int exp_bits(float m) { const int e = (__builtin_bit_cast(int, m) >> 23) & 0xff; return e < 13 ? 13 : e; }
+
+__global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) char xf[2][4][2][1024];          // [buffer][n-tile][hi | lo][lane x 16 B]
+    __shared__ int xe[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.z;
+    if (z >= a.n * a.slices) {                   // ride-along job: LayerNorm parameter sums (fixed order over the row blocks)
+        if (blockIdx.x || blockIdx.y) return;
+        const WgJob& j = a.job[z - a.n * a.slices];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < j.nblocks; ++b) { s1 += j.partial[(int64_t)b * 512 + tid]; s2 += j.partial[(int64_t)b * 512 + 256 + tid]; }
+        j.out_a[tid] = s1;
+        j.out_b[tid] = s2;
+        return;
+    }
+    const int pi = z / a.slices, sl = z - pi * a.slices;
+    const WgProblem& p = a.p[pi];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    if (m0 >= p.M || n0 >= p.N) return;
+    const int r_begin = sl * a.rows_per_slice, r_end = min(p.rows, r_begin + a.rows_per_slice);
+    const int nk = r_end > r_begin ? (r_end - r_begin + 31) / 32 : 0;
+    const int c = lane & 15, g = lane >> 4;
+    const int gm = m0 + wave * 16 + c, xn = n0 + wave * 16 + c;              // this lane's column of G (its A strip) and of X (the tile it stages)
+    const bool gok = gm < p.M, xok = xn < p.N;
+    const float* gp = p.G + gm;
+    const float* xp = p.X + xn;
+    float gv[8], xv[8];
+    auto fetch = [&](int ks) __attribute__((always_inline)) {
+        const int r0 = r_begin + ks * 32 + g * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool rok = r0 + e < r_end;
+            gv[e] = (rok && gok) ? gp[(int64_t)(r0 + e) * p.ldg] : 0.f;
+            xv[e] = (rok && xok) ? xp[(int64_t)(r0 + e) * p.ldx] : 0.f;
+        }
+    };
+    f32x4 am[4], ac[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { am[t] = (f32x4)0.f; ac[t] = (f32x4)0.f; }
+    int eg_cur = 13, ex_mine = 13, ex_seen[4] = {13, 13, 13, 13};
+    float bsum = 0.f;
+    const bool want_b = blockIdx.x == 0 && p.db != nullptr;
+    if (nk > 0) fetch(0);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        // ---- this wave's G strip: running scale, split (registers only)
+        float mg = 0.f, mx = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mg = fmaxf(mg, fabsf(gv[e])); mx = fmaxf(mx, fabsf(xv[e])); bsum += gv[e]; }
+        const int eg = exp_bits(wave_absmax_uniform(mg)), ex = exp_bits(wave_absmax_uniform(mx));
+        if (eg > eg_cur) {
+            const int d = max(eg_cur - eg, -200);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { am[t][j] = __builtin_ldexpf(am[t][j], d); ac[t][j] = __builtin_ldexpf(ac[t][j], d); }
+            eg_cur = eg;
+        }
+        if (ex > ex_mine) ex_mine = ex;
+        float gs[8], xs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e] = __builtin_ldexpf(gv[e], 140 - eg_cur); xs[e] = __builtin_ldexpf(xv[e], 140 - ex_mine); }      // maximum into [2^13, 2^14)
+        u32x4 ahi, alo, bhi, blo;
+        split8(gs, ahi, alo);
+        split8(xs, bhi, blo);
+        *reinterpret_cast<u32x4*>(&xf[buf][wave][0][lane * 16]) = bhi;
+        *reinterpret_cast<u32x4*>(&xf[buf][wave][1][lane * 16]) = blo;
+        if (lane == 0) xe[buf][wave] = ex_mine;
+        if (ks + 1 < nk) fetch(ks + 1);                                      // the next 32 rows fly under the barrier and the MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int et = xe[buf][t];
+            if (et > ex_seen[t]) {
+                const int d = max(ex_seen[t] - et, -200);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { am[t][j] = __builtin_ldexpf(am[t][j], d); ac[t][j] = __builtin_ldexpf(ac[t][j], d); }
+                ex_seen[t] = et;
+            }
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(&xf[buf][t][0][lane * 16]);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(&xf[buf][t][1][lane * 16]);
+            am[t] = mfma(ahi, b0, am[t]);
+            ac[t] = mfma(ahi, b1, ac[t]);
+            ac[t] = mfma(alo, b0, ac[t]);
+        }
+        // (double-buffered X fragments: the next block's stores go to the other buffer; the barrier of that block orders them against this
+        // block's reads of THIS buffer two blocks later)
+    }
+    // ---- epilogue: undo the scales, write the tile (or the slice's partial tile)
+    const bool direct = a.slices == 1;
+    float* out = direct ? p.dW : a.partials + p.part_off + (int64_t)sl * ((int64_t)p.M * p.N + p.M);
+    const int ldo = direct ? p.ldw : p.N;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int sh = eg_cur + ex_seen[t] - 280;                            // (eg - 140) + (ex - 140)
+        const int col = n0 + t * 16 + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = m0 + wave * 16 + g * 4 + j;
+            if (row < p.M && col < p.N) out[(int64_t)row * ldo + col] = __builtin_ldexpf(fmaf(ac[t][j], kLoInv, am[t][j]), max(sh, -250));
+        }
+    }
+    if (want_b) {
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (lane < 16 && gok) (direct ? p.db : out + (int64_t)p.M * p.N)[gm] = bsum;
+    }
+}
+
+// partial tiles of the row slices -> d W, d b (fixed order)
+__global__ __launch_bounds__(256) void dpn_wgrad16_reduce_kernel(WgArgs a) {
+    const WgProblem& p = a.p[blockIdx.y];
+    const int64_t mn = (int64_t)p.M * p.N, per = mn + p.M;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per || (i >= mn && !p.db)) return;
+    const float* src = a.partials + p.part_off + i;
+    float v = src[0];
+    for (int s = 1; s < a.slices; ++s) v += src[(int64_t)s * per];
+    if (i < mn) p.dW[(i / p.N) * p.ldw + (i % p.N)] = v;
+    else p.db[i - mn] = v;
+}
+
 template <class K>
 int set_lds(K kernel, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -801,6 +957,44 @@ int dpn_enc_pack(int n_mats, const float* const* weights, void* packed, int* sta
     }
     a.n = n_mats; a.out = static_cast<char*>(packed); a.status = status_dev;
     hipLaunchKernelGGL(dpn_enc_pack_kernel, dim3(n_mats * 2 * 16 * 8 * 64 / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int64_t dpn_wgrad16_partial_floats(int n, const DpnWgradProblem* problems, int slices) {
+    if (n <= 0 || !problems || slices <= 1) return 0;
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) tot += (int64_t)slices * ((int64_t)problems[i].M * problems[i].N + problems[i].M);
+    return tot;
+}
+
+int dpn_wgrad16(int n, const DpnWgradProblem* problems, int n_jobs, const DpnColsumJob* jobs, int slices, float* partials, void* stream) {
+    if (n < 0 || n > kWgMaxProblems || n_jobs < 0 || n_jobs > kWgMaxJobs || (n && !problems) || (n_jobs && !jobs) || n + n_jobs == 0) return -1;
+    if (slices < 1 || (slices > 1 && !partials)) return -1;
+    WgArgs a{};
+    a.n = n; a.slices = slices; a.partials = partials;
+    int gx = 1, gy = 1, max_rows = 0;
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const DpnWgradProblem& q = problems[i];
+        if (!q.G || !q.X || !q.dW || q.M <= 0 || q.N <= 0 || q.rows <= 0 || q.ldg < q.M || q.ldx < q.N || q.ldw < q.N) return -1;
+        a.p[i] = WgProblem{q.G, q.X, q.dW, q.db, q.M, q.N, q.rows, q.ldg, q.ldx, q.ldw, off};
+        off += (int64_t)slices * ((int64_t)q.M * q.N + q.M);
+        gx = gx > (q.N + 63) / 64 ? gx : (q.N + 63) / 64;
+        gy = gy > (q.M + 63) / 64 ? gy : (q.M + 63) / 64;
+        max_rows = max_rows > q.rows ? max_rows : q.rows;
+    }
+    a.rows_per_slice = ((max_rows + slices - 1) / slices + 31) / 32 * 32;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!jobs[i].partial || !jobs[i].out_a || !jobs[i].out_b || jobs[i].n_blocks <= 0) return -1;
+        a.job[i] = WgJob{jobs[i].partial, jobs[i].out_a, jobs[i].out_b, jobs[i].n_blocks, 0};
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(dpn_wgrad16_kernel, dim3(gx, gy, n * slices + n_jobs), dim3(256), 0, s, a);
+    if (slices > 1 && n > 0) {
+        int64_t per = 0;
+        for (int i = 0; i < n; ++i) per = per > (int64_t)problems[i].M * problems[i].N + problems[i].M ? per : (int64_t)problems[i].M * problems[i].N + problems[i].M;
+        hipLaunchKernelGGL(dpn_wgrad16_reduce_kernel, dim3((unsigned)((per + 255) / 256), n), dim3(256), 0, s, a);
+    }
     return (int)hipGetLastError();
 }
 

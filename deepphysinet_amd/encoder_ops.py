@@ -309,11 +309,14 @@ class _DataEmbeddingFn(torch.autograd.Function):
         g3 = g.reshape(B, -1, D)
         g_emb = _c(g3[:, ctx.n_tok:]).reshape(n, D)              # one field: a contiguous row range (no copy)
         dw, db = new_grad(ctx.params[0], (D, K3)), new_grad(ctx.params[1])
-        batch = []
-        _wgrad(batch, D, K3, n, g_emb, D, xu, K3, dw, db)
-        if batch:
-            from .linear import _launch
-            _launch(batch)
+        if os.environ.get('DPN_ENCODER_UNFUSED') == '1':
+            batch = []
+            _wgrad(batch, D, K3, n, g_emb, D, xu, K3, dw, db)
+            if batch:
+                from .linear import _launch
+                _launch(batch)
+        else:
+            held = wgrad16([(g_emb, xu, dw, db)])                   # (the launch is queued; `held` may go: the stream orders the reuse)
         g_tok = g3[:, :ctx.n_tok]
         g_tok = g_tok.reshape(ctx.tok_shape) if B == 1 else g_tok.sum(dim=0).reshape(ctx.tok_shape)
         return None, dw.view(ctx.w_shape), db, g_tok, None, None, None
@@ -550,6 +553,30 @@ def enc_pack(mats):
     return buf
 
 
+def wgrad16(problems, jobs=(), rows=None):
+    """dpn_wgrad16: dW = G^T X (+ db = column sums of G) for a list of (G, X, dW, db) 2-D tensors (G [rows, M], X [rows, N], dW [M, N], db [M] or
+    None) in one launch, with the LayerNorm parameter-sum jobs (partial, dgamma, dbeta, n_blocks) riding along; long reductions (batches of
+    fields) are cut into row slices joined by the library's second launch.  Raw pointers: the caller keeps the tensors alive."""
+    lib = L.load()
+    n = len(problems)
+    arr = (L.DpnWgradProblem * max(n, 1))()
+    rows_max = 0
+    for i, (G, X, dW, db) in enumerate(problems):
+        q = arr[i]
+        q.G, q.X, q.dW, q.db = _p(G), _p(X), _p(dW), _p(db)
+        q.M, q.N, q.rows, q.ldg, q.ldx, q.ldw = G.shape[1], X.shape[1], G.shape[0], G.stride(0), X.stride(0), dW.stride(0)
+        assert X.shape[0] == G.shape[0] and tuple(dW.shape) == (G.shape[1], X.shape[1]) and G.stride(1) == 1 and X.stride(1) == 1 and dW.stride(1) == 1
+        rows_max = max(rows_max, G.shape[0])
+    slices = 1 if rows_max <= 2048 else min(32, (rows_max + 2047) // 2048)
+    partials = None
+    if slices > 1 and n:
+        dev = problems[0][0].device
+        partials = torch.empty(int(lib.dpn_wgrad16_partial_floats(n, arr, slices)), dtype=torch.float32, device=dev)
+    jarr = (L.DpnColsumJob * max(len(jobs), 1))(*[L.DpnColsumJob(j[0].data_ptr(), j[1].data_ptr(), j[2].data_ptr(), j[3]) for j in jobs])
+    L.check(lib.dpn_wgrad16(n, arr, len(jobs), jarr, slices, _p(partials), _s()), 'dpn_wgrad16')
+    return partials
+
+
 _LAYER_PARAMS = 16     # wq, bq, wk, bk, wv, bv, wo, bo, g1, be1, wc1, bc1, wc2, bc2, g2, be2
 
 
@@ -578,7 +605,7 @@ class _EncoderStackFn(torch.autograd.Function):
             mats.append(_c(fin[2]))
         n_mats = len(mats)
         wpack = enc_pack(mats)
-        rt = 1 if n <= 2048 else 2
+        rt = int(os.environ.get('DPN_ENC_ROW_TILES', '0')) or (1 if n <= 2048 else 2)
         stream = _s()
 
         def fwd(**kw):
@@ -649,20 +676,19 @@ class _EncoderStackFn(torch.autograd.Function):
             L.check(lib.dpn_enc_bwd(ctypes.byref(b), stream), 'dpn_enc_bwd')
         batch, jobs = [], []
         grads = [None] * len(ctx.params)
-
         keep = []                                                    # the launch at the end reads these through raw pointers
 
         def wgrad(slot_w, slot_b, N, gmat, xmat):                    # d W = gmat^T xmat, d b = column sums of gmat
             keep.extend((gmat, xmat))
             w = ctx.params[slot_w]
             gw, gb = new_grad(w, (N, D)), new_grad(ctx.params[slot_b])
-            _wgrad(batch, N, D, n, gmat, D, xmat, D, gw, gb)
+            batch.append((gmat, xmat, gw, gb))
             grads[slot_w], grads[slot_b] = gw.view(w.shape), gb
 
         def lnjob(slot_g, slot_b, partial):
             dg, db = new_grad(ctx.params[slot_g]), new_grad(ctx.params[slot_b])
             keep.append(partial)
-            jobs.append((partial, n, dg, db, nb))
+            jobs.append((partial, dg, db, nb))
             grads[slot_g], grads[slot_b] = dg, db
         res = dq = dk = dv = None
         for l in range(nl - 1, -1, -1):
@@ -697,18 +723,12 @@ class _EncoderStackFn(torch.autograd.Function):
             res = gs1
         dx0 = new(n, D)
         bwd(head=1, body=0, res=res, dq=dq, dk=dk, dv=dv, m_h0=0, m_h1=1, m_h2=2, gx=dx0)
-        # every weight gradient of the stack and the LayerNorm parameter sums: one launch (two when a launch's limits are exceeded)
+        # every weight gradient of the stack and the LayerNorm parameter sums: ONE launch (dpn_wgrad16; plus its slice reduction for batches
+        # of fields)
         while batch or jobs:
-            b_, batch = batch[:L.GEMM_MAX_PROBLEMS], batch[L.GEMM_MAX_PROBLEMS:]
+            b_, batch = batch[:L.WGRAD_MAX_PROBLEMS], batch[L.WGRAD_MAX_PROBLEMS:]
             j_, jobs = jobs[:L.GEMM_MAX_JOBS], jobs[L.GEMM_MAX_JOBS:]
-            if b_:
-                _launch(b_, colsum_jobs=j_)
-            else:                                                    # batches of fields: the weight gradients went out as row-slice launches
-                for (partial, rows_, dg, db, nblk) in j_:
-                    joined = new(512)
-                    L.check(lib.dpn_sum_parts(_p(partial), nblk, 512, 0, _p(joined), stream), 'dpn_sum_parts')
-                    dg.copy_(joined[:256])
-                    db.copy_(joined[256:])
+            keep.append(wgrad16(b_, j_))
         del keep
         return (dx0, None, None, None, None, *grads)
 

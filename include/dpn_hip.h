@@ -243,6 +243,18 @@ typedef struct DpnEncBwd {
 } DpnEncBwd;
 int dpn_enc_bwd(const DpnEncBwd* p, void* stream);
 
+/* Weight gradients of linears over token rows, up to DPN_WGRAD_MAX_PROBLEMS in one launch:  dW[M][N] = G^T X,  db[M] = column sums of G
+ * (db may be NULL), G [rows][M] (row stride ldg) the cotangent of the linear's output, X [rows][N] (ldx) its input, dW row stride ldw.
+ * f16 hi+lo split operands with a running power-of-two scale per operand strip (any magnitude), fp32 accumulate, fixed order.
+ * slices > 1 cuts the row reduction into that many slices (batches of fields): `partials` then needs dpn_wgrad16_partial_floats() floats and
+ * a second launch adds the slices in order.  Up to DPN_GEMM_MAX_JOBS DpnColsumJob ride along (the LayerNorm parameter sums of dpn_enc_bwd).
+ * Replaces dpn_sgemm_batch for the weight gradients of the encoder stack (attn.py:183-196, transformer_net.py:38-42,129, embed.py:45-47). */
+#define DPN_WGRAD_MAX_PROBLEMS 32
+typedef struct DpnWgradProblem { const float* G; const float* X; float* dW; float* db; int32_t M, N, rows, ldg, ldx, ldw; } DpnWgradProblem;
+int64_t dpn_wgrad16_partial_floats(int n, const DpnWgradProblem* problems, int slices);
+int dpn_wgrad16(int n, const DpnWgradProblem* problems /* host array */, int n_jobs, const DpnColsumJob* jobs, int slices, float* partials,
+                void* stream);
+
 /* out = LayerNorm_256(x + r) * gamma + beta (eps 1e-5), r may be NULL (transformer_net.py:37,44,68); saves xhat [rows][256] and rstd [rows].
  * Backward: gx = d/d(x + r) (the same tensor is the gradient of x and of r), dgamma, dbeta [256].  With dgamma = dbeta = NULL only gx and the
  * per-block partial sums in `scratch` ([ceil(rows/4)][512]) are produced, to be reduced by a DpnColsumJob of dpn_sgemm_batch_jobs. */

@@ -261,6 +261,9 @@ def test_rank_aware_sample_callable_is_used_as_is():
     d = Dummy()
     calls = []
     own = lambda epoch, rank, world: calls.append((epoch, rank, world)) or ['r%d' % rank]
-    assert list(d._epoch_samples({'samples': own}, 3, 1, 4)) == ['r1'] and calls == [(3, 1, 4)]
+    # the per-rank protocol is selected explicitly: by keyword, or by an attribute of the callable -- never by its arity
+    assert list(d._epoch_samples({'samples': own, 'samples_per_rank': True}, 3, 1, 4)) == ['r1'] and calls == [(3, 1, 4)]
+    own.per_rank = True
+    assert list(d._epoch_samples({'samples': own}, 5, 0, 2)) == ['r0'] and calls[-1] == (5, 0, 2)
     every = lambda epoch: ['a', 'b', 'c']
     assert list(d._epoch_samples({'samples': every}, 0, 1, 2)) == ['b', 'b'] or list(d._epoch_samples({'samples': every}, 0, 1, 2)) == ['b', 'a']
