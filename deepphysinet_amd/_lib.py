@@ -64,6 +64,12 @@ class DpnEncBwd(Structure):
                                         'gs2', 'dpre', 'gs1', 'dout', 'gx', 'partial_f', 'partial2', 'partial1')]
 
 
+class DpnEncPrep(Structure):
+    _fields_ = [('n_mats', c_int32), ('weights', c_void_p), ('packed', c_void_p), ('status_dev', c_void_p),
+                ('x', c_void_p), ('T', c_int32), ('C', c_int32), ('batch', c_int32), ('xu', c_void_p),
+                ('h', c_void_p), ('freqs_a', c_void_p), ('n_a', c_int32), ('out_a', c_void_p), ('freqs_b', c_void_p), ('n_b', c_int32), ('out_b', c_void_p)]
+
+
 class DpnWgradProblem(Structure):
     _fields_ = [('G', c_void_p), ('X', c_void_p), ('dW', c_void_p), ('db', c_void_p)] + [(n, c_int32) for n in ('M', 'N', 'rows', 'ldg', 'ldx', 'ldw')]
 
@@ -115,6 +121,7 @@ EXPORTS = {
     'dpn_enc_pack': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_wgrad16_partial_floats': (c_int64, [c_int, c_void_p, c_int]),
     'dpn_wgrad16': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    'dpn_enc_prep': (c_int, [POINTER(DpnEncPrep), c_void_p]),
     'dpn_enc_fwd': (c_int, [POINTER(DpnEncFwd), c_void_p]),
     'dpn_enc_bwd': (c_int, [POINTER(DpnEncBwd), c_void_p]),
     'dpn_add_ln_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

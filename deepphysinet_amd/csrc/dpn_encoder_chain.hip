@@ -751,8 +751,7 @@ struct PackArgs {
 };
 // one thread = one 16-byte fragment slot of both planes: image 0 is W as stored ([out][in]: y = x W^T contracts over `in`), image 1 is W^T
 // (g W contracts over `out`).  Fragment (tile mt, k-step ks, lane (m, g)) holds A[16 mt + m][32 ks + 8 g .. + 7].
-__global__ __launch_bounds__(256) void dpn_enc_pack_kernel(PackArgs a) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+DEV void pack_body(const PackArgs& a, const int idx) {
     const int lane = idx & 63, ks = (idx >> 6) & 7, mt = (idx >> 9) & 15, im = (idx >> 13) & 1, mat = idx >> 14;
     if (mat >= a.n) return;
     const float* W = a.W[mat];
@@ -775,7 +774,40 @@ __global__ __launch_bounds__(256) void dpn_enc_pack_kernel(PackArgs a) {
     *reinterpret_cast<u32x4*>(dst) = hi;
     *reinterpret_cast<u32x4*>(dst + 1024) = lo;
 }
+__global__ __launch_bounds__(256) void dpn_enc_pack_kernel(PackArgs a) { pack_body(a, blockIdx.x * 256 + threadIdx.x); }
 
+// Everything of the encoder's forward that depends on the step's inputs only -- the weight images, the im2col rows of the circular token
+// convolution (embed.py:45-47) and the lead-time positional encodings of the encoder (embed.py:58) and of the VariableNets
+// (variable_net.py:46) -- in ONE launch (they were four): block ranges [pack | im2col | lead-time PE].
+struct PrepArgs {
+    PackArgs pack;
+    int pack_blocks, col_blocks;
+    const float* x; int T, C; int64_t col_total; float* xu;
+    const float* h; int batch; const float* fa; int na; float* oa; const float* fb; int nb; float* ob;
+};
+__global__ __launch_bounds__(256) void dpn_enc_prep_kernel(PrepArgs a) {
+    int blk = blockIdx.x;
+    if (blk < a.pack_blocks) { pack_body(a.pack, blk * 256 + threadIdx.x); return; }
+    blk -= a.pack_blocks;
+    if (blk < a.col_blocks) {                                                // out[b*T + t][c*3 + tap] = x[b*T + (t + tap - 1) mod T][c]
+        const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+        if (i >= a.col_total) return;
+        const int64_t tg = i / (3 * a.C);
+        const int r = (int)(i - tg * 3 * a.C), c = r / 3, tap = r - 3 * c;
+        const int64_t b = tg / a.T;
+        int ts = (int)(tg - b * a.T) + tap - 1;
+        ts = ts < 0 ? ts + a.T : (ts >= a.T ? ts - a.T : ts);
+        a.xu[i] = a.x[(b * a.T + ts) * a.C + c];
+        return;
+    }
+    blk -= a.col_blocks;
+    const int i = blk * 256 + threadIdx.x;                                   // SineCosPE of the scalar lead time (position_encoding.py:35-50)
+    if (i >= a.batch * (a.na + a.nb)) return;
+    const int b = i / (a.na + a.nb), j = i - b * (a.na + a.nb);
+    const float hv = a.h[b];
+    if (j < a.na) { const float s_ = hv * a.fa[j]; a.oa[(int64_t)b * 2 * a.na + 2 * j] = sinf(s_); a.oa[(int64_t)b * 2 * a.na + 2 * j + 1] = cosf(s_); }
+    else { const int jj = j - a.na; const float s_ = hv * a.fb[jj]; a.ob[(int64_t)b * 2 * a.nb + 2 * jj] = sinf(s_); a.ob[(int64_t)b * 2 * a.nb + 2 * jj + 1] = cosf(s_); }
+}
 
 // ------------------------------------------------------------------------------------------------ weight gradients
 // d W[M][N] = G^T X over the token rows (G: the cotangent [rows][M] of a linear's output, X: its input [rows][N]); d b = column sums of G.
@@ -995,6 +1027,28 @@ int dpn_wgrad16(int n, const DpnWgradProblem* problems, int n_jobs, const DpnCol
         for (int i = 0; i < n; ++i) per = per > (int64_t)problems[i].M * problems[i].N + problems[i].M ? per : (int64_t)problems[i].M * problems[i].N + problems[i].M;
         hipLaunchKernelGGL(dpn_wgrad16_reduce_kernel, dim3((unsigned)((per + 255) / 256), n), dim3(256), 0, s, a);
     }
+    return (int)hipGetLastError();
+}
+
+int dpn_enc_prep(const DpnEncPrep* p, void* stream) {
+    if (!p || p->n_mats < 0 || p->n_mats > DPN_ENC_MAX_MATS || (p->n_mats && (!p->weights || !p->packed))) return -1;
+    if ((p->x != nullptr) != (p->xu != nullptr) || (p->x && (p->T <= 0 || p->C <= 0 || p->batch <= 0))) return -1;
+    if (p->h && (p->batch <= 0 || !p->freqs_a || !p->out_a || p->n_a <= 0 || p->n_b < 0 || (p->n_b > 0 && (!p->freqs_b || !p->out_b)))) return -1;
+    PrepArgs a{};
+    for (int i = 0; i < p->n_mats; ++i) {
+        if (!p->weights[i]) return -1;
+        a.pack.W[i] = p->weights[i];
+    }
+    a.pack.n = p->n_mats; a.pack.out = static_cast<char*>(p->packed); a.pack.status = p->status_dev;
+    a.pack_blocks = p->n_mats * 64;
+    a.x = p->x; a.T = p->T; a.C = p->C; a.xu = p->xu;
+    a.col_total = p->x ? (int64_t)p->batch * p->T * p->C * 3 : 0;
+    a.col_blocks = (int)((a.col_total + 255) / 256);
+    a.h = p->h; a.batch = p->batch; a.fa = p->freqs_a; a.na = p->n_a; a.oa = p->out_a; a.fb = p->freqs_b; a.nb = p->h ? p->n_b : 0; a.ob = p->out_b;
+    const int pe_blocks = p->h ? (p->batch * (p->n_a + a.nb) + 255) / 256 : 0;
+    const int blocks = a.pack_blocks + a.col_blocks + pe_blocks;
+    if (blocks <= 0) return -1;
+    hipLaunchKernelGGL(dpn_enc_prep_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

@@ -269,15 +269,16 @@ class _DataEmbeddingFn(torch.autograd.Function):
     layout) with its bias sum."""
 
     @staticmethod
-    def forward(ctx, field, conv_w, conv_b, token, pos, h, freq_bands):
+    def forward(ctx, field, conv_w, conv_b, token, pos, h, freq_bands, xu=None, te=None):
         from .linear import _launch, _problem
         lib = L.load()
         B, T, C = field.shape
-        x = _c(field.detach().reshape(B * T, C).float())
         D = conv_w.shape[0]
-        dev = x.device
-        xu = torch.empty((B * T, 3 * C), dtype=torch.float32, device=dev)
-        L.check(lib.dpn_im2col_circ3(_p(x), T, C, B, _p(xu), _s()), 'dpn_im2col_circ3')
+        dev = field.device
+        if xu is None:                                               # (encoder_prep has made both when the whole encoder runs fused)
+            x = _c(field.detach().reshape(B * T, C).float())
+            xu = torch.empty((B * T, 3 * C), dtype=torch.float32, device=dev)
+            L.check(lib.dpn_im2col_circ3(_p(x), T, C, B, _p(xu), _s()), 'dpn_im2col_circ3')
         w2 = _c(conv_w).view(D, 3 * C)
         # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one MFMA launch; their partial products are
         # added (fixed order) together with the bias by the assemble kernel
@@ -291,7 +292,8 @@ class _DataEmbeddingFn(torch.autograd.Function):
             q.A[0], q.B[0], q.C = xu.data_ptr() + k0 * 4, w2.data_ptr() + k0 * 4, emb_parts.data_ptr() + i * B * T * D * 4
             problems.append(q)
         _launch(problems)
-        te = lead_time_pe(h, freq_bands)
+        if te is None:
+            te = lead_time_pe(h, freq_bands)
         n_tok = token.shape[-2]
         out = torch.empty((B, n_tok + T, D), dtype=torch.float32, device=dev)
         L.check(lib.dpn_embed_assemble(_p(_c(token)), n_tok, _p(emb_parts), len(bounds), T, B, _p(conv_b), _p(_c(pos)), _p(te), _p(out), _s()),
@@ -319,17 +321,25 @@ class _DataEmbeddingFn(torch.autograd.Function):
             held = wgrad16([(g_emb, xu, dw, db)])                   # (the launch is queued; `held` may go: the stream orders the reuse)
         g_tok = g3[:, :ctx.n_tok]
         g_tok = g_tok.reshape(ctx.tok_shape) if B == 1 else g_tok.sum(dim=0).reshape(ctx.tok_shape)
-        return None, dw.view(ctx.w_shape), db, g_tok, None, None, None
+        return None, dw.view(ctx.w_shape), db, g_tok, None, None, None, None, None
 
 
-def data_embedding_fused(field, emb_module, token, h):
-    """-> [B, n_tok + T, 256] or None when the module does not fit the kernels (then the caller takes the per-op path)."""
+def _embedding_fits(field, emb_module, token, h):
     conv = emb_module.value_embedding.tokenConv
-    if not (field.is_cuda and field.dim() == 3 and conv.weight.shape[0] == 256 and conv.kernel_size == (3,)
-            and conv.bias is not None and token.shape[-1] == 256 and h.numel() == field.shape[0]):
+    return (field.is_cuda and field.dim() == 3 and conv.weight.shape[0] == 256 and conv.kernel_size == (3,)
+            and conv.bias is not None and token.shape[-1] == 256 and h.numel() == field.shape[0])
+
+
+def data_embedding_fused(field, emb_module, token, h, prep=None):
+    """-> [B, n_tok + T, 256] or None when the module does not fit the kernels (then the caller takes the per-op path).
+    prep: an EncoderPrep of the same (field, h): its im2col rows and lead-time encoding are used instead of two launches here."""
+    conv = emb_module.value_embedding.tokenConv
+    if not _embedding_fits(field, emb_module, token, h):
         return None
     n = token.shape[-2] + field.shape[1]
     pos = emb_module.position_embedding.pe[0, :n]
+    if prep is not None:
+        return _DataEmbeddingFn.apply(field, conv.weight, conv.bias, token, pos, h, emb_module.time_embending.freq_bands, prep.xu, prep.te)
     return _DataEmbeddingFn.apply(field, conv.weight, conv.bias, token, pos, h, emb_module.time_embending.freq_bands)
 
 
@@ -589,7 +599,7 @@ class _EncoderStackFn(torch.autograd.Function):
     then gf, bef, wp, bp when final."""
 
     @staticmethod
-    def forward(ctx, x0, B, Lt, nl, final, *params):
+    def forward(ctx, x0, B, Lt, nl, final, wpack, *params):
         lib = L.load()
         x0 = _c(x0)
         n, D = x0.shape
@@ -598,13 +608,9 @@ class _EncoderStackFn(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         lay = [params[_LAYER_PARAMS * l:_LAYER_PARAMS * (l + 1)] for l in range(nl)]
         fin = params[_LAYER_PARAMS * nl:] if final else None
-        mats = []
-        for p_ in lay:
-            mats += [_c(p_[0]), _c(p_[2]), _c(p_[4]), _c(p_[6]), _c(p_[10]), _c(p_[12])]       # 6 l + (q, k, v, o, c1, c2)
-        if final:
-            mats.append(_c(fin[2]))
-        n_mats = len(mats)
-        wpack = enc_pack(mats)
+        n_mats = 6 * nl + (1 if final else 0)                        # 6 l + (q, k, v, o, c1, c2), then the projection
+        if wpack is None:                                            # (encoder_prep has packed them when the whole encoder runs fused)
+            wpack = enc_pack(_stack_matrices(lay, fin))
         rt = int(os.environ.get('DPN_ENC_ROW_TILES', '0')) or (1 if n <= 2048 else 2)
         stream = _s()
 
@@ -730,7 +736,16 @@ class _EncoderStackFn(torch.autograd.Function):
             j_, jobs = jobs[:L.GEMM_MAX_JOBS], jobs[L.GEMM_MAX_JOBS:]
             keep.append(wgrad16(b_, j_))
         del keep
-        return (dx0, None, None, None, None, *grads)
+        return (dx0, None, None, None, None, None, *grads)
+
+
+def _stack_matrices(lay, fin):
+    mats = []
+    for p_ in lay:
+        mats += [_c(p_[0]), _c(p_[2]), _c(p_[4]), _c(p_[6]), _c(p_[10]), _c(p_[12])]
+    if fin is not None:
+        mats.append(_c(fin[2]))
+    return mats
 
 
 def _layer_params(layer):
@@ -750,7 +765,74 @@ def _layer_fits(layer):
                                                  layer.conv1, layer.conv2)))
 
 
-def encoder_stack_fused(x, layers, norm=None, projection=None):
+def _stack_fits(layers, norm, projection):
+    if os.environ.get('DPN_ENCODER_FP8') in ('1', 'mx') or os.environ.get('DPN_ENCODER_UNFUSED') == '1' or len(layers) < 1:
+        return False
+    if not all(_layer_fits(l_) and not getattr(l_.attention.inner_attention, 'output_attention', False) for l_ in layers):
+        return False
+    if (norm is None) != (projection is None):
+        return False
+    final = norm is not None
+    if final and not (norm.elementwise_affine and norm.eps == 1e-5 and tuple(projection.weight.shape) == (256, 256) and projection.bias is not None):
+        return False
+    return 6 * len(layers) + (1 if final else 0) <= L.ENC_MAX_MATS
+
+
+class EncoderPrep:
+    """dpn_enc_prep's outputs for one forward of the whole encoder: weight images, im2col rows, lead-time encodings."""
+    __slots__ = ('wpack', 'xu', 'te', 'pe_extra')
+
+
+def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
+    """ONE launch for everything of the encoder forward that depends on the step's inputs only (they were four: dpn_enc_pack,
+    dpn_im2col_circ3 and two dpn_lead_pe): the weight images of the stack, the im2col rows of the token convolution, the encoder's lead-time
+    encoding and (extra_freqs: the VariableNets' frequency table) the one the hyper-network heads take."""
+    lib = L.load()
+    lay = [_layer_params(l_) for l_ in layers]
+    mats = _stack_matrices(lay, (None, None, projection.weight))
+    B, T, C = field.shape
+    dev = field.device
+    x = _c(field.detach().reshape(B * T, C).float())
+    fa = _c(emb_module.time_embending.freq_bands)
+    hh = _c(h.detach().float().reshape(-1))
+    out = EncoderPrep()
+    out.wpack = torch.empty(int(lib.dpn_enc_pack_bytes(len(mats))), dtype=torch.uint8, device=dev)
+    out.xu = torch.empty((B * T, 3 * C), dtype=torch.float32, device=dev)
+    te = torch.empty((B, 2 * fa.numel()), dtype=torch.float32, device=dev)
+    q = L.DpnEncPrep()
+    arr = (ctypes.c_void_p * len(mats))(*[_p(m_).value for m_ in mats])
+    q.n_mats, q.weights, q.packed, q.status_dev = len(mats), ctypes.cast(arr, ctypes.c_void_p), _p(out.wpack), _p(enc_status(dev))
+    q.x, q.T, q.C, q.batch, q.xu = _p(x), T, C, B, _p(out.xu)
+    q.h, q.freqs_a, q.n_a, q.out_a = _p(hh), _p(fa), fa.numel(), _p(te)
+    out.pe_extra = None
+    if extra_freqs is not None:
+        fb = _c(extra_freqs)
+        out.pe_extra = torch.empty((B, 2 * fb.numel()), dtype=torch.float32, device=dev)
+        q.freqs_b, q.n_b, q.out_b = _p(fb), fb.numel(), _p(out.pe_extra)
+    L.check(lib.dpn_enc_prep(ctypes.byref(q), _s()), 'dpn_enc_prep')
+    out.te = te.view(-1) if B == 1 else te
+    return out
+
+
+def encoder_forward_fused(net, x_enc, forecast_h):
+    """TransformerNet.forward (transformer_net.py:123-129) on the fused nodes: prep (1 launch), data embedding, the encoder stack with
+    encoder.norm and the projection; None when a module does not fit.  net.extra_lead_freqs (set by PhysicsNet) asks the prep launch
+    for the VariableNets' lead-time encoding too: net.extra_lead_pe = (forecast_h, tensor)."""
+    enc, emb = net.encoder, net.enc_embedding
+    if not (x_enc.is_cuda and x_enc.dim() == 3 and enc.conv_layers is None and enc.norm is not None):
+        return None
+    layers = list(enc.attn_layers)
+    n_tok = net.learnable_token.shape[-2]
+    if not (_stack_fits(layers, enc.norm, net.projection) and _embedding_fits(x_enc, emb, net.learnable_token, forecast_h)
+            and n_tok + x_enc.shape[1] <= 288):
+        return None
+    prep = encoder_prep(x_enc, forecast_h, emb, getattr(net, 'extra_lead_freqs', None), layers, enc.norm, net.projection)
+    net.extra_lead_pe = (forecast_h, prep.pe_extra) if prep.pe_extra is not None else None
+    x0 = data_embedding_fused(x_enc, emb, net.learnable_token, forecast_h, prep=prep)
+    return encoder_stack_fused(x0, layers, enc.norm, net.projection, wpack=prep.wpack)
+
+
+def encoder_stack_fused(x, layers, norm=None, projection=None, wpack=None):
     """[B, L, 256] -> the encoder layers (+ encoder.norm + output projection when both are given) as one autograd node, or None when the
     modules do not fit the kernels (8 heads x 32, d_ff = 256, gelu, affine LayerNorms with eps 1e-5, L <= 288)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 256 and x.shape[1] <= 288 and len(layers) >= 1):
@@ -772,5 +854,5 @@ def encoder_stack_fused(x, layers, norm=None, projection=None):
             return None
         params += [norm.weight, norm.bias, projection.weight, projection.bias]
     B, Lt = x.shape[0], x.shape[1]
-    out = _EncoderStackFn.apply(x.reshape(B * Lt, 256), B, Lt, len(layers), final, *params)
+    out = _EncoderStackFn.apply(x.reshape(B * Lt, 256), B, Lt, len(layers), final, wpack, *params)
     return out.view(B, Lt, 256)

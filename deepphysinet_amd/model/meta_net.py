@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..encoder_ops import add_layer_norm, attention, data_embedding_fused, encoder_layer_fused, encoder_stack_fused
+from ..encoder_ops import add_layer_norm, attention, data_embedding_fused, encoder_forward_fused, encoder_layer_fused, encoder_stack_fused
 from ..linear import linear, linear_multi
 from ..utils.position_encoding import SineCosPE
 
@@ -176,11 +176,11 @@ class TransformerNet(nn.Module):
         self.projection = nn.Linear(d_model, c_out, bias=True)
 
     def forward(self, x_enc, forecast_h, enc_self_mask=None):
-        enc_out = self.enc_embedding(x_enc, forecast_h, self.learnable_token)
-        if enc_self_mask is None and self.encoder.conv_layers is None and self.encoder.norm is not None:
-            fused = encoder_stack_fused(enc_out, list(self.encoder.attn_layers), self.encoder.norm, self.projection)
-            if fused is not None:                          # all layers + encoder.norm + the projection: one node, 2 launches per layer
+        if enc_self_mask is None:
+            fused = encoder_forward_fused(self, x_enc, forecast_h)     # prep + embedding + all layers + encoder.norm + projection: 2 launches per layer
+            if fused is not None:
                 return fused
+        enc_out = self.enc_embedding(x_enc, forecast_h, self.learnable_token)
         enc_out, _ = self.encoder(enc_out, attn_mask=enc_self_mask)
         return linear(enc_out, self.projection.weight, self.projection.bias)
 

@@ -54,6 +54,8 @@ class PhysicsNet(nn.Module):
         key = self._cache_key(field_x, forecast_h) if use_cache else None
         if use_cache and self._meta_cache is not None and self._meta_cache[0] == key:
             return self._meta_cache[1]
+        # the encoder's prep launch also evaluates the VariableNets' lead-time encoding (one launch instead of two; field_weights picks it up)
+        object.__setattr__(self.meta_net.model, 'extra_lead_freqs', self.U_net.pe_fore_h.freq_bands)
         val = self.meta_net(field_x, forecast_h)
         if use_cache:
             self._meta_cache = (key, val)
@@ -75,7 +77,11 @@ class PhysicsNet(nn.Module):
         if meta_out.is_cuda:
             from ..encoder_ops import _HeadsFn, lead_time_pe
             B = meta_out.shape[0]
-            pe_h = lead_time_pe(forecast_h, nets[0].pe_fore_h.freq_bands)              # [B, 192] (same encoder in every net)
+            extra = getattr(self.meta_net.model, 'extra_lead_pe', None)                # made by the encoder's prep launch for this forecast_h
+            if extra is not None and extra[0] is forecast_h and extra[1].shape[0] == B:
+                pe_h = extra[1]
+            else:
+                pe_h = lead_time_pe(forecast_h, nets[0].pe_fore_h.freq_bands)          # [B, 192] (same encoder in every net)
             heads, evec = _HeadsFn.apply(meta_out, pe_h.reshape(B, 192),
                                          *[n.coord_input_fc.weight for n in nets], *[n.coord_hidden_fc.weight for n in nets],
                                          *[n.coord_input_fc.bias for n in nets], *[n.coord_hidden_fc.bias for n in nets],

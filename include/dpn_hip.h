@@ -208,6 +208,17 @@ int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o,
 int64_t dpn_enc_pack_bytes(int n_mats);
 int dpn_enc_pack(int n_mats, const float* const* weights /* host array of device pointers */, void* packed, int* status_dev, void* stream);
 
+/* dpn_enc_prep: everything of the encoder forward that depends on the step's inputs only, in ONE launch -- the weight images (dpn_enc_pack),
+ * the im2col rows of the circular token convolution (dpn_im2col_circ3: x [batch*T][C] -> xu [batch*T][3C]) and the lead-time SineCosPE for one
+ * or two frequency tables (dpn_lead_pe: h [batch] -> out_a [batch][2 n_a], out_b [batch][2 n_b]).  Each part is optional (n_mats = 0 / x = NULL
+ * / h = NULL). */
+typedef struct DpnEncPrep {
+    int32_t n_mats; const float* const* weights /* host array of device pointers */; void* packed; int* status_dev;
+    const float* x; int32_t T, C, batch; float* xu;
+    const float* h; const float* freqs_a; int32_t n_a; float* out_a; const float* freqs_b; int32_t n_b; float* out_b;
+} DpnEncPrep;
+int dpn_enc_prep(const DpnEncPrep* p, void* stream);
+
 /* Forward.  tail = 1:  x1 = norm1(x + o Wo^T + bo);  pre = x1 Wc1^T + bc1;  act = gelu(pre);  x2 = norm2(x1 + act Wc2^T + bc2)
  *                      (o = the attention output, x = the layer input; x1, xhat1, rstd1, pre, act, x2, xhat2, rstd2 are written);
  *           next = 1:  y0, y1, y2 = t Wn0^T + bn0, ...   the NEXT layer's q / k / v projections of t = x2 (tail = 1) or t = xin (tail = 0);
