@@ -64,6 +64,11 @@ class DpnEncBwd(Structure):
                                         'gs2', 'dpre', 'gs1', 'dout', 'gx', 'partial_f', 'partial2', 'partial1')]
 
 
+class DpnGemm16Problem(Structure):
+    _fields_ = [(n, c_void_p) for n in ('A', 'B', 'C', 'asum', 'bias')] + [(n, c_int32) for n in ('M', 'N', 'K', 'ldc')] + \
+               [(n, c_int64) for n in ('a_sm', 'a_sk', 'b_sn', 'b_sk')]
+
+
 class DpnEncPrep(Structure):
     _fields_ = [('n_mats', c_int32), ('weights', c_void_p), ('packed', c_void_p), ('status_dev', c_void_p),
                 ('x', c_void_p), ('T', c_int32), ('C', c_int32), ('batch', c_int32), ('xu', c_void_p),
@@ -121,6 +126,8 @@ EXPORTS = {
     'dpn_enc_pack': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_wgrad16_partial_floats': (c_int64, [c_int, c_void_p, c_int]),
     'dpn_wgrad16': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    'dpn_gemm16_partial_floats': (c_int64, [c_int, c_void_p, c_int]),
+    'dpn_gemm16': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'dpn_enc_prep': (c_int, [POINTER(DpnEncPrep), c_void_p]),
     'dpn_enc_fwd': (c_int, [POINTER(DpnEncFwd), c_void_p]),
     'dpn_enc_bwd': (c_int, [POINTER(DpnEncBwd), c_void_p]),

@@ -819,11 +819,16 @@ __global__ __launch_bounds__(256) void dpn_enc_prep_kernel(PrepArgs a) {
 // by a power of two taken from the largest magnitude seen SO FAR in that operand strip, and when a block raises it the accumulators are
 // rescaled (exact: powers of two) -- cotangent rows that differ by many decades (a field whose loss is 100 x the median's) cost nothing.
 // Long reductions (batches of fields) are cut into row slices whose partial tiles dpn_wgrad16_reduce adds in a fixed order.
+// The same kernel serves every small GEMM with a short output and any operand orientation (dpn_gemm16): C[m][n] = sum_k A(m, k) B(n, k) with
+// element strides per operand -- A(m, k) = A[m * a_sm + k * a_sk] -- so "rows are k" (the weight gradients: a_sm = 1, a_sk = ld) and "k is
+// contiguous" (x W^T: a_sm = ld, a_sk = 1) are the same code; the eight k-values of a fragment slot are eight dword loads either way.
 struct WgProblem {
-    const float *G, *X;
-    float *dW, *db;
-    int M, N, rows, ldg, ldx, ldw;
-    int64_t part_off;                            // floats: this problem's partials [slices][M * N + M]
+    const float *G, *X;                          // A (its 16-column strip is private to a wave), B (shared through LDS)
+    float *dW, *db;                              // C, and the sums over k of A (the bias gradient when A is a cotangent) or NULL
+    const float* bias;                           // [N] added to every row of C, or NULL
+    int M, N, rows, ldw;                         // rows = K
+    int64_t g_sm, g_sk, x_sn, x_sk;
+    int64_t part_off;                            // floats: this problem's partials [slices][M * N (+ M with db)]
 };
 constexpr int kWgMaxProblems = DPN_WGRAD_MAX_PROBLEMS, kWgMaxJobs = DPN_GEMM_MAX_JOBS;
 struct WgJob { const float* partial; float* out_a; float* out_b; int nblocks, pad; };
@@ -866,16 +871,32 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
     const int c = lane & 15, g = lane >> 4;
     const int gm = m0 + wave * 16 + c, xn = n0 + wave * 16 + c;              // this lane's column of G (its A strip) and of X (the tile it stages)
     const bool gok = gm < p.M, xok = xn < p.N;
-    const float* gp = p.G + gm;
-    const float* xp = p.X + xn;
-    float gv[8], xv[8];
-    auto fetch = [&](int ks) __attribute__((always_inline)) {
+    // (everything the loop needs from the problem record in registers: read through the reference, each use is a scalar load from the kernel
+    // arguments with its own wait -- measured 1.5 us per 32-row block; loads are unconditional from a clamped address, zeroed by a select)
+    const int64_t g_sk = p.g_sk, x_sk = p.x_sk;
+    const float* gp = p.G + (gok ? gm * p.g_sm : 0);
+    const float* xp = p.X + (xok ? xn * p.x_sn : 0);
+    constexpr int kWgDepth = 4;                  // rows in flight: blocks of 32 (a dependent global round trip per block would be a chain of latencies)
+    float gv[kWgDepth][8], xv[kWgDepth][8];
+    // Loads are unconditional, from a clamped row, and land in the ring untouched; rows / columns outside the problem are zeroed by a
+    // multiplication when the block is CONSUMED.  (A select makes the compiler sink every load into a branch of its own, and a mask applied
+    // at fetch time puts an s_waitcnt vmcnt(0) in front of every barrier: both measured at ~1.5 us per 32-row block.)
+    auto fetch = [&](int ks, float (&gd)[8], float (&xd)[8]) __attribute__((always_inline)) {
+        const int r0 = r_begin + ks * 32 + g * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t r = r0 + e < r_end ? r0 + e : r_begin;
+            gd[e] = gp[r * g_sk];
+            xd[e] = xp[r * x_sk];
+        }
+    };
+    auto mask_rows = [&](int ks, float (&gd)[8], float (&xd)[8]) __attribute__((always_inline)) {
         const int r0 = r_begin + ks * 32 + g * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const bool rok = r0 + e < r_end;
-            gv[e] = (rok && gok) ? gp[(int64_t)(r0 + e) * p.ldg] : 0.f;
-            xv[e] = (rok && xok) ? xp[(int64_t)(r0 + e) * p.ldx] : 0.f;
+            gd[e] *= (rok && gok) ? 1.f : 0.f;
+            xd[e] *= (rok && xok) ? 1.f : 0.f;
         }
     };
     f32x4 am[4], ac[4];
@@ -884,55 +905,63 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
     int eg_cur = 13, ex_mine = 13, ex_seen[4] = {13, 13, 13, 13};
     float bsum = 0.f;
     const bool want_b = blockIdx.x == 0 && p.db != nullptr;
-    if (nk > 0) fetch(0);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        // ---- this wave's G strip: running scale, split (registers only)
-        float mg = 0.f, mx = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { mg = fmaxf(mg, fabsf(gv[e])); mx = fmaxf(mx, fabsf(xv[e])); bsum += gv[e]; }
-        const int eg = exp_bits(wave_absmax_uniform(mg)), ex = exp_bits(wave_absmax_uniform(mx));
-        if (eg > eg_cur) {
-            const int d = max(eg_cur - eg, -200);
+    for (int d = 0; d < kWgDepth; ++d)
+        if (d < nk) fetch(d, gv[d], xv[d]);
+    for (int ks0 = 0; ks0 < nk; ks0 += kWgDepth) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int d = 0; d < kWgDepth; ++d) {
+            const int ks = ks0 + d;
+            if (ks >= nk) break;
+            const int buf = d & 1;                                           // kWgDepth is even: consecutive blocks alternate buffers
+            // ---- this wave's G strip: running scale, split (registers only)
+            mask_rows(ks, gv[d], xv[d]);
+            float mg = 0.f, mx = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { am[t][j] = __builtin_ldexpf(am[t][j], d); ac[t][j] = __builtin_ldexpf(ac[t][j], d); }
-            eg_cur = eg;
-        }
-        if (ex > ex_mine) ex_mine = ex;
-        float gs[8], xs[8];
+            for (int e = 0; e < 8; ++e) { mg = fmaxf(mg, fabsf(gv[d][e])); mx = fmaxf(mx, fabsf(xv[d][e])); bsum += gv[d][e]; }
+            const int eg = exp_bits(wave_absmax_uniform(mg)), ex = exp_bits(wave_absmax_uniform(mx));
+            if (eg > eg_cur) {
+                const int dd = max(eg_cur - eg, -200);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gs[e] = __builtin_ldexpf(gv[e], 140 - eg_cur); xs[e] = __builtin_ldexpf(xv[e], 140 - ex_mine); }      // maximum into [2^13, 2^14)
-        u32x4 ahi, alo, bhi, blo;
-        split8(gs, ahi, alo);
-        split8(xs, bhi, blo);
-        *reinterpret_cast<u32x4*>(&xf[buf][wave][0][lane * 16]) = bhi;
-        *reinterpret_cast<u32x4*>(&xf[buf][wave][1][lane * 16]) = blo;
-        if (lane == 0) xe[buf][wave] = ex_mine;
-        if (ks + 1 < nk) fetch(ks + 1);                                      // the next 32 rows fly under the barrier and the MFMAs
-        __syncthreads();
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int et = xe[buf][t];
-            if (et > ex_seen[t]) {
-                const int d = max(ex_seen[t] - et, -200);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { am[t][j] = __builtin_ldexpf(am[t][j], d); ac[t][j] = __builtin_ldexpf(ac[t][j], d); }
-                ex_seen[t] = et;
+                    for (int j = 0; j < 4; ++j) { am[t][j] = __builtin_ldexpf(am[t][j], dd); ac[t][j] = __builtin_ldexpf(ac[t][j], dd); }
+                eg_cur = eg;
             }
-            const u32x4 b0 = *reinterpret_cast<const u32x4*>(&xf[buf][t][0][lane * 16]);
-            const u32x4 b1 = *reinterpret_cast<const u32x4*>(&xf[buf][t][1][lane * 16]);
-            am[t] = mfma(ahi, b0, am[t]);
-            ac[t] = mfma(ahi, b1, ac[t]);
-            ac[t] = mfma(alo, b0, ac[t]);
+            if (ex > ex_mine) ex_mine = ex;
+            float gs[8], xs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gs[e] = __builtin_ldexpf(gv[d][e], 140 - eg_cur); xs[e] = __builtin_ldexpf(xv[d][e], 140 - ex_mine); }      // maximum into [2^13, 2^14)
+            u32x4 ahi, alo, bhi, blo;
+            split8(gs, ahi, alo);
+            split8(xs, bhi, blo);
+            *reinterpret_cast<u32x4*>(&xf[buf][wave][0][lane * 16]) = bhi;
+            *reinterpret_cast<u32x4*>(&xf[buf][wave][1][lane * 16]) = blo;
+            if (lane == 0) xe[buf][wave] = ex_mine;
+            if (ks + kWgDepth < nk) fetch(ks + kWgDepth, gv[d], xv[d]);      // refill the slot: kWgDepth blocks ahead
+            barrier_lds();                                                   // (LDS only: a __syncthreads() would drain the rows in flight)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int et = xe[buf][t];
+                if (et > ex_seen[t]) {
+                    const int dd = max(ex_seen[t] - et, -200);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { am[t][j] = __builtin_ldexpf(am[t][j], dd); ac[t][j] = __builtin_ldexpf(ac[t][j], dd); }
+                    ex_seen[t] = et;
+                }
+                const u32x4 b0 = *reinterpret_cast<const u32x4*>(&xf[buf][t][0][lane * 16]);
+                const u32x4 b1 = *reinterpret_cast<const u32x4*>(&xf[buf][t][1][lane * 16]);
+                am[t] = mfma(ahi, b0, am[t]);
+                ac[t] = mfma(ahi, b1, ac[t]);
+                ac[t] = mfma(alo, b0, ac[t]);
+            }
+            // (double-buffered X fragments: the next block's stores go to the other buffer; the barrier of that block orders them against
+            // this block's reads of THIS buffer two blocks later)
         }
-        // (double-buffered X fragments: the next block's stores go to the other buffer; the barrier of that block orders them against this
-        // block's reads of THIS buffer two blocks later)
     }
     // ---- epilogue: undo the scales, write the tile (or the slice's partial tile)
     const bool direct = a.slices == 1;
-    float* out = direct ? p.dW : a.partials + p.part_off + (int64_t)sl * ((int64_t)p.M * p.N + p.M);
+    float* out = direct ? p.dW : a.partials + p.part_off + (int64_t)sl * ((int64_t)p.M * p.N + (p.db ? p.M : 0));
     const int ldo = direct ? p.ldw : p.N;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -941,7 +970,8 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = m0 + wave * 16 + g * 4 + j;
-            if (row < p.M && col < p.N) out[(int64_t)row * ldo + col] = __builtin_ldexpf(fmaf(ac[t][j], kLoInv, am[t][j]), max(sh, -250));
+            if (row < p.M && col < p.N)
+                out[(int64_t)row * ldo + col] = __builtin_ldexpf(fmaf(ac[t][j], kLoInv, am[t][j]), max(sh, -250)) + ((direct && p.bias) ? p.bias[col] : 0.f);
         }
     }
     if (want_b) {
@@ -954,13 +984,13 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
 // partial tiles of the row slices -> d W, d b (fixed order)
 __global__ __launch_bounds__(256) void dpn_wgrad16_reduce_kernel(WgArgs a) {
     const WgProblem& p = a.p[blockIdx.y];
-    const int64_t mn = (int64_t)p.M * p.N, per = mn + p.M;
+    const int64_t mn = (int64_t)p.M * p.N, per = mn + (p.db ? p.M : 0);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= per || (i >= mn && !p.db)) return;
+    if (i >= per) return;
     const float* src = a.partials + p.part_off + i;
     float v = src[0];
     for (int s = 1; s < a.slices; ++s) v += src[(int64_t)s * per];
-    if (i < mn) p.dW[(i / p.N) * p.ldw + (i % p.N)] = v;
+    if (i < mn) p.dW[(i / p.N) * p.ldw + (i % p.N)] = v + (p.bias ? p.bias[i % p.N] : 0.f);
     else p.db[i - mn] = v;
 }
 
@@ -992,42 +1022,69 @@ int dpn_enc_pack(int n_mats, const float* const* weights, void* packed, int* sta
     return (int)hipGetLastError();
 }
 
-int64_t dpn_wgrad16_partial_floats(int n, const DpnWgradProblem* problems, int slices) {
-    if (n <= 0 || !problems || slices <= 1) return 0;
-    int64_t tot = 0;
-    for (int i = 0; i < n; ++i) tot += (int64_t)slices * ((int64_t)problems[i].M * problems[i].N + problems[i].M);
-    return tot;
-}
-
-int dpn_wgrad16(int n, const DpnWgradProblem* problems, int n_jobs, const DpnColsumJob* jobs, int slices, float* partials, void* stream) {
+static int gemm16_launch(int n, const DpnGemm16Problem* problems, int n_jobs, const DpnColsumJob* jobs, int slices, float* partials, int reduce,
+                         void* stream) {
     if (n < 0 || n > kWgMaxProblems || n_jobs < 0 || n_jobs > kWgMaxJobs || (n && !problems) || (n_jobs && !jobs) || n + n_jobs == 0) return -1;
     if (slices < 1 || (slices > 1 && !partials)) return -1;
     WgArgs a{};
     a.n = n; a.slices = slices; a.partials = partials;
-    int gx = 1, gy = 1, max_rows = 0;
-    int64_t off = 0;
+    int gx = 1, gy = 1, max_k = 0;
+    int64_t off = 0, per_max = 0;
     for (int i = 0; i < n; ++i) {
-        const DpnWgradProblem& q = problems[i];
-        if (!q.G || !q.X || !q.dW || q.M <= 0 || q.N <= 0 || q.rows <= 0 || q.ldg < q.M || q.ldx < q.N || q.ldw < q.N) return -1;
-        a.p[i] = WgProblem{q.G, q.X, q.dW, q.db, q.M, q.N, q.rows, q.ldg, q.ldx, q.ldw, off};
-        off += (int64_t)slices * ((int64_t)q.M * q.N + q.M);
+        const DpnGemm16Problem& q = problems[i];
+        if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.ldc < q.N) return -1;
+        a.p[i] = WgProblem{q.A, q.B, q.C, q.asum, q.bias, q.M, q.N, q.K, q.ldc, q.a_sm, q.a_sk, q.b_sn, q.b_sk, off};
+        const int64_t per = (int64_t)q.M * q.N + (q.asum ? q.M : 0);
+        off += (int64_t)slices * per;
+        per_max = per_max > per ? per_max : per;
         gx = gx > (q.N + 63) / 64 ? gx : (q.N + 63) / 64;
         gy = gy > (q.M + 63) / 64 ? gy : (q.M + 63) / 64;
-        max_rows = max_rows > q.rows ? max_rows : q.rows;
+        max_k = max_k > q.K ? max_k : q.K;
     }
-    a.rows_per_slice = ((max_rows + slices - 1) / slices + 31) / 32 * 32;
+    a.rows_per_slice = ((max_k + slices - 1) / slices + 31) / 32 * 32;
     for (int i = 0; i < n_jobs; ++i) {
         if (!jobs[i].partial || !jobs[i].out_a || !jobs[i].out_b || jobs[i].n_blocks <= 0) return -1;
         a.job[i] = WgJob{jobs[i].partial, jobs[i].out_a, jobs[i].out_b, jobs[i].n_blocks, 0};
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(dpn_wgrad16_kernel, dim3(gx, gy, n * slices + n_jobs), dim3(256), 0, s, a);
-    if (slices > 1 && n > 0) {
-        int64_t per = 0;
-        for (int i = 0; i < n; ++i) per = per > (int64_t)problems[i].M * problems[i].N + problems[i].M ? per : (int64_t)problems[i].M * problems[i].N + problems[i].M;
-        hipLaunchKernelGGL(dpn_wgrad16_reduce_kernel, dim3((unsigned)((per + 255) / 256), n), dim3(256), 0, s, a);
-    }
+    if (slices > 1 && n > 0 && reduce)
+        hipLaunchKernelGGL(dpn_wgrad16_reduce_kernel, dim3((unsigned)((per_max + 255) / 256), n), dim3(256), 0, s, a);
     return (int)hipGetLastError();
+}
+
+int64_t dpn_gemm16_partial_floats(int n, const DpnGemm16Problem* problems, int slices) {
+    if (n <= 0 || !problems || slices <= 1) return 0;
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) tot += (int64_t)slices * ((int64_t)problems[i].M * problems[i].N + (problems[i].asum ? problems[i].M : 0));
+    return tot;
+}
+
+int dpn_gemm16(int n, const DpnGemm16Problem* problems, int slices, float* partials, int reduce, void* stream) {
+    return gemm16_launch(n, problems, 0, nullptr, slices, partials, reduce, stream);
+}
+
+static int wgrad_as_gemm16(int n, const DpnWgradProblem* problems, DpnGemm16Problem* out) {
+    for (int i = 0; i < n; ++i) {
+        const DpnWgradProblem& q = problems[i];
+        if (!q.G || !q.X || !q.dW || q.M <= 0 || q.N <= 0 || q.rows <= 0 || q.ldg < q.M || q.ldx < q.N || q.ldw < q.N) return -1;
+        out[i] = DpnGemm16Problem{q.G, q.X, q.dW, q.db, nullptr, q.M, q.N, q.rows, q.ldw, 1, q.ldg, 1, q.ldx};
+    }
+    return 0;
+}
+
+int64_t dpn_wgrad16_partial_floats(int n, const DpnWgradProblem* problems, int slices) {
+    if (n <= 0 || n > kWgMaxProblems || !problems || slices <= 1) return 0;
+    DpnGemm16Problem g[kWgMaxProblems];
+    if (wgrad_as_gemm16(n, problems, g)) return 0;
+    return dpn_gemm16_partial_floats(n, g, slices);
+}
+
+int dpn_wgrad16(int n, const DpnWgradProblem* problems, int n_jobs, const DpnColsumJob* jobs, int slices, float* partials, void* stream) {
+    if (n < 0 || n > kWgMaxProblems || (n && !problems)) return -1;
+    DpnGemm16Problem g[kWgMaxProblems];
+    if (wgrad_as_gemm16(n, problems, g)) return -1;
+    return gemm16_launch(n, g, n_jobs, jobs, slices, partials, 1, stream);
 }
 
 int dpn_enc_prep(const DpnEncPrep* p, void* stream) {

@@ -280,23 +280,36 @@ class _DataEmbeddingFn(torch.autograd.Function):
             xu = torch.empty((B * T, 3 * C), dtype=torch.float32, device=dev)
             L.check(lib.dpn_im2col_circ3(_p(x), T, C, B, _p(xu), _s()), 'dpn_im2col_circ3')
         w2 = _c(conv_w).view(D, 3 * C)
-        # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one MFMA launch; their partial products are
-        # added (fixed order) together with the bias by the assemble kernel
-        K3, parts = 3 * C, 16
-        ks = (K3 + parts - 1) // parts
-        bounds = [(k0, min(k0 + ks, K3)) for k0 in range(0, K3, ks)]
-        emb_parts = torch.empty((len(bounds), B * T, D), dtype=torch.float32, device=dev)
-        problems = []
-        for i, (k0, k1) in enumerate(bounds):
-            q = _problem(B * T, D, k1 - k0, [(xu, K3, w2, K3)], emb_parts, D, 0, 1)
-            q.A[0], q.B[0], q.C = xu.data_ptr() + k0 * 4, w2.data_ptr() + k0 * 4, emb_parts.data_ptr() + i * B * T * D * 4
-            problems.append(q)
-        _launch(problems)
+        K3 = 3 * C
+        if os.environ.get('DPN_EMBED_GEMM16') != '1':
+            # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one exact-fp32 MFMA launch (24 us)
+            parts = 16
+            ks = (K3 + parts - 1) // parts
+            bounds = [(k0, min(k0 + ks, K3)) for k0 in range(0, K3, ks)]
+            emb_parts = torch.empty((len(bounds), B * T, D), dtype=torch.float32, device=dev)
+            problems = []
+            for i, (k0, k1) in enumerate(bounds):
+                q = _problem(B * T, D, k1 - k0, [(xu, K3, w2, K3)], emb_parts, D, 0, 1)
+                q.A[0], q.B[0], q.C = xu.data_ptr() + k0 * 4, w2.data_ptr() + k0 * 4, emb_parts.data_ptr() + i * B * T * D * 4
+                problems.append(q)
+            _launch(problems)
+            n_parts = len(bounds)
+        else:
+            # (measured experiment, DPN_EMBED_GEMM16=1: the same product on the f16 hi+lo MFMA GEMM dpn_gemm16, K cut into 38 slices: 31.6 us
+            # + a slower assemble -- with k contiguous the kernel's dword loads touch 64 cache lines per instruction -- and the tile-level scales
+            # make a field's result depend on its batch neighbours at the 1e-7 level; not the product path)
+            tiles = ((B * T + 63) // 64) * ((D + 63) // 64)
+            n_parts = max(1, min(38, 456 // tiles))
+            q = L.DpnGemm16Problem()
+            emb_parts = torch.empty((n_parts, B * T, D), dtype=torch.float32, device=dev)
+            q.A, q.B, q.C, q.M, q.N, q.K, q.ldc = _p(xu), _p(w2), _p(emb_parts), B * T, D, K3, D
+            q.a_sm, q.a_sk, q.b_sn, q.b_sk = K3, 1, K3, 1
+            L.check(lib.dpn_gemm16(1, ctypes.byref(q), n_parts, _p(emb_parts), 0, _s()), 'dpn_gemm16')
         if te is None:
             te = lead_time_pe(h, freq_bands)
         n_tok = token.shape[-2]
         out = torch.empty((B, n_tok + T, D), dtype=torch.float32, device=dev)
-        L.check(lib.dpn_embed_assemble(_p(_c(token)), n_tok, _p(emb_parts), len(bounds), T, B, _p(conv_b), _p(_c(pos)), _p(te), _p(out), _s()),
+        L.check(lib.dpn_embed_assemble(_p(_c(token)), n_tok, _p(emb_parts), n_parts, T, B, _p(conv_b), _p(_c(pos)), _p(te), _p(out), _s()),
                 'dpn_embed_assemble')
         ctx.save_for_backward(xu)
         ctx.n_tok, ctx.w_shape, ctx.tok_shape, ctx.B = n_tok, conv_w.shape, token.shape, B

@@ -266,6 +266,19 @@ int64_t dpn_wgrad16_partial_floats(int n, const DpnWgradProblem* problems, int s
 int dpn_wgrad16(int n, const DpnWgradProblem* problems /* host array */, int n_jobs, const DpnColsumJob* jobs, int slices, float* partials,
                 void* stream);
 
+/* The same kernel for any small GEMM, one launch for up to DPN_WGRAD_MAX_PROBLEMS of them:  C[m][n] = sum_k A(m, k) B(n, k) (+ bias[n]),
+ * A(m, k) = A[m * a_sm + k * a_sk], B(n, k) = B[n * b_sn + k * b_sk] (element strides: "k runs over rows" is a_sm = 1, a_sk = ld; "k is
+ * contiguous" is a_sm = ld, a_sk = 1); asum[m] = sum_k A(m, k) (optional).  slices > 1 cuts K; with reduce = 0 the caller adds the partial
+ * results partials[problem][slice][M * N (+ M)] itself (the data embedding's assemble kernel does).  Used for the token convolution
+ * (embed.py:45-47: x_unfolded W^T with K = 3 * 2405) instead of the exact-fp32 dpn_sgemm_batch. */
+typedef struct DpnGemm16Problem {
+    const float* A; const float* B; float* C; float* asum; const float* bias;
+    int32_t M, N, K, ldc;
+    int64_t a_sm, a_sk, b_sn, b_sk;
+} DpnGemm16Problem;
+int64_t dpn_gemm16_partial_floats(int n, const DpnGemm16Problem* problems, int slices);
+int dpn_gemm16(int n, const DpnGemm16Problem* problems /* host array */, int slices, float* partials, int reduce, void* stream);
+
 /* out = LayerNorm_256(x + r) * gamma + beta (eps 1e-5), r may be NULL (transformer_net.py:37,44,68); saves xhat [rows][256] and rstd [rows].
  * Backward: gx = d/d(x + r) (the same tensor is the gradient of x and of r), dgamma, dbeta [256].  With dgamma = dbeta = NULL only gx and the
  * per-block partial sums in `scratch` ([ceil(rows/4)][512]) are produced, to be reduced by a DpnColsumJob of dpn_sgemm_batch_jobs. */
