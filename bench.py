@@ -180,7 +180,7 @@ def main():
         del many
     crit = torch.nn.MSELoss()
     # N > 1 (or DPN_BENCH_SPLIT_STEP=1 on one GPU, to time the same code path): three graph segments with a bucket all-reduce behind each
-    split_step = (world > 1 or one_rank_rccl or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1') and args.leads == 1
+    split_step = world > 1 or one_rank_rccl or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1'
     # DPN_BENCH_CAPTURE_COLLECTIVES=1: capture the bucket all-reduces inside ONE graph with the segments (opt-in: measured with a one-rank
     # RCCL group on the single-GPU test box, profiles/; the default keeps the collectives host-issued between four segment graphs)
     one_graph_collectives = os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') == '1' and split_step and (world > 1 or one_rank_rccl)
@@ -200,15 +200,13 @@ def main():
                 loss = m.place_one_batch(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'],
                                          batch['forecast_h'], crit, lf, 0, 0, dev)
             loss.backward(one)                         # persistent seed: no ones_like fill per step
-            if world > 1:                              # configs[2] on N GPUs: one bucketed all-reduce behind the whole backward
-                sync()
             opt.step()                                 # global-norm clip (2.5e7) + Adam in the HIP library
             return loss
 
         if not split_step:
             return [whole], None
         from deepphysinet_amd.interface.interface_physics import StagedPdeStep
-        staged = StagedPdeStep(m, opt, batch, lf)
+        staged = StagedPdeStep(m, opt, lead if args.leads > 1 else batch, lf, lead_batch=args.leads > 1)
         return list(staged.stages) + [opt.step], staged
 
     def run(prec, steps, warmup, use_graph):
@@ -229,7 +227,7 @@ def main():
                     if i == n_reduce - 1:
                         sync.wait()
         graphs = None
-        capturable = use_graph and not (world > 1 and not split_step)      # a step with the collective inside stays eager
+        capturable = use_graph
         if capturable:
             try:
                 s = torch.cuda.Stream()
@@ -319,7 +317,8 @@ def main():
             ver = None
         return {'backend': backend, 'backend_is': 'RCCL (torch backend "nccl" on ROCm)' if backend == 'nccl' else backend, 'world': world,
                 'rccl_version': ver, 'devices': every, 'distinct_devices': len({(d['pci'], d['uuid'], d['device_index']) for d in every}),
-                'gradient_buckets_mb': None, 'reduce_op': 'AVG in place on the flat gradient buffer, one all-reduce per backward segment'}
+                'gradient_buckets_mb': None, 'reduce_op': 'AVG in place on the flat gradient buffer, one all-reduce per backward segment',
+                'HSA_ENABLE_IPC_MODE_LEGACY': D.ipc_mode()}
 
     sync = None
     coll = collective_info()
@@ -332,13 +331,15 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate' if args.prec == 'bf16' else 'bf16x2 (hi+lo split bf16 MFMA operands), fp32 accumulate',
         'data': 'synthetic',
-        'config': {'workload': ('configs[1]: 0.25deg grid 257x145 = %d collocation points/GPU/step, one field sample, six PDE residual losses, '
+        'config': {'workload': (('configs[1]' if world == 1 else 'configs[3] (configs[1] per GPU, data-parallel over %d GPUs, RCCL bucket all-reduces under the backward)' % world) +
+                                ': 0.25deg grid 257x145 = %d collocation points/GPU/step, one field sample per GPU, six PDE residual losses, '
                                 'encoder+hyper-net+fwd+Jacobian+bwd+clip+Adam' % args.points) if args.leads == 1 else
-                               ('configs[2]: %d forecast-lead field samples x %d collocation points per GPU per step (one batched encoder pass, '
+                               (('configs[2]' if world == 1 else 'configs[3] (configs[2] per GPU, data-parallel over %d GPUs, RCCL bucket all-reduces under the backward)' % world) +
+                                ': %d forecast-lead field samples x %d collocation points per GPU per step (one batched encoder pass, '
                                 'point kernels field after field), six PDE residual losses, fwd+Jacobian+bwd+clip+Adam' % (args.leads, args.points)),
                    'leads': args.leads,
                    'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world,
-                   'step_segments': (1 if one_graph_collectives else 4) if split_step else 1,
+                   'step_segments': (1 if one_graph_collectives else 4) if split_step else 1,     # three backward segments + the optimiser
                    'collectives_in_graph': bool(one_graph_collectives)},
         'timed_seconds': dt,
         **({'warning': 'timed region %.3f s < 0.2 s: ms_per_step is still a mean over %d graph replays, but GPU-utilisation samplers '

@@ -29,10 +29,30 @@ def init_from_env(backend=None, force=False):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # this pool's driver only supports dmabuf IPC (RCCL needs it)
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            if backend == 'nccl':
+                torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == 'nccl':
+                # the first collective is where a wrong IPC mode shows (hipIpcGetMemHandle: invalid argument): fail HERE, with the setting named
+                probe = torch.ones(1, device=torch.device('cuda', local))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError('the probe all-reduce returned %r instead of %d' % (probe.item(), world))
+        except Exception as e:                                       # noqa
+            raise RuntimeError(
+                'deepphysinet_amd.distributed: the %s process group of %d rank(s) did not come up (%s: %s).  Multi-process GPU work on this '
+                'platform needs dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY is %r in this process (this module sets 0 when it is unset); if the '
+                "node's driver wants the legacy mode, export HSA_ENABLE_IPC_MODE_LEGACY=1 before starting the ranks.  MASTER_ADDR=%s "
+                'MASTER_PORT=%s RANK=%d LOCAL_RANK=%d' % (backend, world, type(e).__name__, str(e)[:300], os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+                                                          os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'), rank, local)) from e
     return rank, world, local
+
+
+def ipc_mode():
+    """The IPC setting the ranks run with (recorded in bench.py's `collective` object)."""
+    return os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
 
 
 def _all_reduce_mean(flat, world, group, async_op):

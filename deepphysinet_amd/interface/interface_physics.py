@@ -275,27 +275,37 @@ class InterfacePhysics(nn.Module):
         staged = (grad_sync is not None and hasattr(grad_sync, 'reduce_bucket') and grad_sync.active() and isinstance(optimizer, FusedClipAdam)
                   and heads is not None)
         if staged:
-            # the staged form needs THIS optimiser's flat buffer laid out in the three buckets of gradient_buckets() and every parameter
+            # the staged form needs THIS optimiser's flat buffer laid out in the four buckets of gradient_buckets() and every parameter
             # trainable; anything else (an optimiser built without `layout`, a reducer bound to another optimiser or to none, frozen
             # parameters) takes the plain backward + grad_sync(parameters) below
             buckets = self.physics_net.gradient_buckets()
             lay = getattr(optimizer, 'layout_ids', None)
-            staged = (getattr(grad_sync, 'opt', None) is optimizer and len(getattr(optimizer, 'bucket_bounds', ())) == 3
+            staged = (getattr(grad_sync, 'opt', None) is optimizer and len(getattr(optimizer, 'bucket_bounds', ())) == 4
                       and lay == [[id(p) for p in b_] for b_ in buckets]
                       and all(p.requires_grad for b_ in buckets for p in b_))
         if staged:
             # data-parallel step: the backward pass is cut where a bucket of gradients is complete and that bucket's all-reduce is queued at
             # once, so it travels under the rest of the backward (what DistributedDataParallel's bucket hooks do in the reference, :903-907,
-            # :1056).  Layout buckets (PhysicsNet.gradient_buckets): point statics | hyper-network heads | encoder; the first two travel as
-            # ONE all-reduce (the heads' backward is two launches: a collective of its own costs more than the 40 us it could start earlier)
+            # :1056).  Layout buckets (PhysicsNet.gradient_buckets): point statics | hyper-network heads | encoder layers | data embedding;
+            # the first two travel as ONE all-reduce (the heads' backward is two launches: a collective of its own costs more than the 40 us
+            # it could start earlier), the token convolution's 7.4 MB (the last gradient to complete) alone
             g = torch.autograd.grad(train_loss, [heads, evec] + list(statics), grad_outputs=self._seed)
             optimizer.place_gradients(list(statics), g[2:])
             g2 = torch.autograd.grad([heads, evec], [meta_out] + buckets[1], grad_outputs=[g[0], g[1]], allow_unused=True)
             optimizer.place_gradients(buckets[1], g2[1:])
             grad_sync.reduce_bucket(0, 2)
-            g3 = torch.autograd.grad([meta_out], buckets[2], grad_outputs=[g2[0]], allow_unused=True)
-            optimizer.place_gradients(buckets[2], g3)
-            grad_sync.reduce_bucket(2)
+            x0 = getattr(self.physics_net.meta_net.model, 'last_embedding', None)
+            if x0 is not None and x0.requires_grad:
+                g3 = torch.autograd.grad([meta_out], [x0] + buckets[2], grad_outputs=[g2[0]], allow_unused=True)
+                optimizer.place_gradients(buckets[2], g3[1:])
+                grad_sync.reduce_bucket(2)
+                g4 = torch.autograd.grad([x0], buckets[3], grad_outputs=[g3[0]], allow_unused=True)
+                optimizer.place_gradients(buckets[3], g4)
+                grad_sync.reduce_bucket(3)
+            else:
+                g3 = torch.autograd.grad([meta_out], buckets[2] + buckets[3], grad_outputs=[g2[0]], allow_unused=True)
+                optimizer.place_gradients(buckets[2] + buckets[3], g3)
+                grad_sync.reduce_bucket(2, 4)
             grad_sync.wait()
             self.physics_net.clear_field_cache()
         else:
@@ -476,26 +486,31 @@ class InterfacePhysics(nn.Module):
 
 
 class StagedPdeStep:
-    """place_one_batch + backward of one field sample, cut where a bucket of gradients is complete (PhysicsNet.gradient_buckets), so that
-    a data-parallel caller can start that bucket's all-reduce while the rest of the backward pass runs (BASELINE configs[3]: "bucketed
-    overlap with backward"; the reference gets the same from DistributedDataParallel's bucket hooks, interface_physics.py:903-907,:1056):
+    """place_one_batch (or, lead_batch, place_lead_batch) + backward, cut where a bucket of gradients is complete
+    (PhysicsNet.gradient_buckets), so that a data-parallel caller can start that bucket's all-reduce while the rest of the backward pass runs
+    (BASELINE configs[3]: "bucketed overlap with backward"; the reference gets the same from DistributedDataParallel's bucket hooks,
+    interface_physics.py:903-907,:1056):
         stages[0]  zero_grad, encoder + heads forward, point forward / residuals, point backward,
-                   hyper-network heads backward                                                     -> layout buckets 0 and 1 (48 static tensors,
-                                                                                                       the heads): stage_buckets[0] = (0, 2)
-        stages[1]  encoder backward                                                                 -> layout bucket 2: stage_buckets[1] = (2, 3)
+                   hyper-network heads backward                     -> layout buckets 0 and 1 (48 static tensors, the heads): stage_buckets[0] = (0, 2)
+        stages[1]  encoder layers + norm + projection backward       -> layout bucket 2: stage_buckets[1] = (2, 3)
+        stages[2]  data embedding backward (the token convolution's 7.4 MB gradient: the last to complete, it travels alone so that the
+                   other 6.4 MB of the encoder start one launch earlier) -> layout bucket 3: stage_buckets[2] = (3, 4)
     Each stage is a plain callable (capturable in a hipGraph of its own, on one capture stream and one memory pool); after stage i the caller
     queues `grad_sync.reduce_bucket(*stage_buckets[i])`.  (Round 2 cut the heads' backward off as a stage of its own: three collectives and
     four graph segments cost 1.80 -> 2.00 ms with a one-rank RCCL group; the heads' backward is two launches, so the statics' all-reduce
-    loses ~40 us of head start and still has the whole encoder backward, 0.3 ms, to travel under.)"""
+    loses ~40 us of head start and still has the whole encoder backward, 0.3 ms, to travel under.)
+    batch: place_one_batch's tensors (x, y, t, f, field_data, coord_data, forecast_h); with lead_batch they carry a leading B (field_data
+    [B, 159, 2405], x .. f [B, N], coord_data [B, N, 6], forecast_h [B, 1, 1]) and the loss is the mean of the B field totals."""
 
-    def __init__(self, interface, optimizer, batch, loss_factor=None):
+    def __init__(self, interface, optimizer, batch, loss_factor=None, lead_batch=False):
         self.m, self.opt, self.b = interface, optimizer, batch
         self.lf = loss_factor or interface.train_cfg['losses']['loss_factor']
+        self.lead_batch = bool(lead_batch)
         net = interface.physics_net
         self.buckets = net.gradient_buckets()
         self.loss = None
-        self.stages = (self.stage_points_and_heads, self.stage_encoder)
-        self.stage_buckets = ((0, 2), (2, 3))
+        self.stages = (self.stage_points_and_heads, self.stage_encoder, self.stage_embedding)
+        self.stage_buckets = ((0, 2), (2, 3), (3, 4))
         self._seed = None
 
     def _assign(self, params, grads):
@@ -507,8 +522,16 @@ class StagedPdeStep:
         self.opt.zero_grad(set_to_none=True)
         cfg = m.point_config(self.lf)
         self.meta_out = net.encode_field(b['field_data'], b['forecast_h'])
+        self.x0 = getattr(net.meta_net.model, 'last_embedding', None)        # the cut between stages 1 and 2 (None: the encoder ran unfused)
         self.heads, self.evec, statics = net.field_weights(b['field_data'], b['forecast_h'], meta_out=self.meta_out)
-        _, total = pde_losses(cfg, b['x'], b['y'], b['t'], b['f'], b['coord_data'], self.heads, self.evec, statics, with_total=True)
+        if self.lead_batch:
+            from ..point_path import pde_losses_batch
+            B = b['field_data'].shape[0]
+            self.heads, self.evec = self.heads.reshape(B, 256, -1), self.evec.reshape(B, 6, 256)
+            _, totals = pde_losses_batch(cfg, b['x'], b['y'], b['t'], b['f'], b['coord_data'], self.heads, self.evec, statics)
+            total = totals.mean().float()
+        else:
+            _, total = pde_losses(cfg, b['x'], b['y'], b['t'], b['f'], b['coord_data'], self.heads, self.evec, statics, with_total=True)
         if self._seed is None:
             self._seed = torch.ones((), dtype=total.dtype, device=total.device)
         g = torch.autograd.grad(total, [self.heads, self.evec] + list(statics), grad_outputs=self._seed)
@@ -529,7 +552,21 @@ class StagedPdeStep:
         self._assign(params, g[1:])
 
     def stage_encoder(self):
+        if self.x0 is None or not self.x0.requires_grad:             # no cut available: the whole encoder in this stage, stage 2 is empty
+            params = self.buckets[2] + self.buckets[3]
+            g = torch.autograd.grad([self.meta_out], params, grad_outputs=[self.g_meta], allow_unused=True)
+            self._assign(params, g)
+            self.g_x0 = None
+            return
         params = self.buckets[2]
-        g = torch.autograd.grad([self.meta_out], params, grad_outputs=[self.g_meta], allow_unused=True)
-        self._assign(params, g)
-        self.meta_out = self.heads = self.evec = self.g_heads = self.g_evec = self.g_meta = None
+        g = torch.autograd.grad([self.meta_out], [self.x0] + params, grad_outputs=[self.g_meta], allow_unused=True)
+        self.g_x0 = g[0]
+        self._assign(params, g[1:])
+
+    def stage_embedding(self):
+        if self.g_x0 is not None:
+            params = self.buckets[3]
+            g = torch.autograd.grad([self.x0], params, grad_outputs=[self.g_x0], allow_unused=True)
+            self._assign(params, g)
+        self.meta_out = self.heads = self.evec = self.g_heads = self.g_evec = self.g_meta = self.x0 = self.g_x0 = None
+        self.m.physics_net.clear_field_cache()

@@ -63,6 +63,8 @@ class PhysicsNet(nn.Module):
 
     def clear_field_cache(self):
         self._meta_cache = None
+        if getattr(self.meta_net.model, 'last_embedding', None) is not None:
+            object.__setattr__(self.meta_net.model, 'last_embedding', None)
 
     def field_weights(self, field_x, forecast_h, use_cache=False, meta_out=None):
         """Everything the point kernels need for one field sample: (heads [256, 2700], evec [6,256], statics[48]); for a batch of B > 1
@@ -104,16 +106,20 @@ class PhysicsNet(nn.Module):
 
     def gradient_buckets(self):
         """The parameters grouped by when the backward pass finishes their gradients: [the 48 tensors the point kernels read directly
-        (ready after the point backward), the hyper-network heads + lead-time embeddings (after _HeadsFn.backward), the encoder].
+        (ready after the point backward) | the hyper-network heads + lead-time embeddings (after _HeadsFn.backward) | the encoder layers,
+        encoder.norm and the output projection (after the encoder stack's backward: its single weight-gradient launch) | the data embedding
+        (learnable tokens, token convolution: the 7.4 MB gradient that completes last)].
         optim.FusedClipAdam(layout=...) lays its flat gradient buffer out in this order and distributed.GradientAllReduce reduces
         bucket after bucket while the rest of the backward pass runs."""
         nets = self.nets_in_output_order()
         statics = [p for n in nets for p in n.static_params()]
         heads = [p for n in nets for p in (n.coord_input_fc.weight, n.coord_input_fc.bias, n.coord_hidden_fc.weight, n.coord_hidden_fc.bias,
                                            n.fore_h_fc.weight, n.fore_h_fc.bias)]
-        seen = {id(p) for p in statics + heads}
+        tn = self.meta_net.model
+        embed = [tn.learnable_token] + list(tn.enc_embedding.parameters())
+        seen = {id(p) for p in statics + heads + embed}
         rest = [p for p in self.parameters() if id(p) not in seen]
-        return [statics, heads, rest]
+        return [statics, heads, rest, embed]
 
     def _cfg(self):
         from ..point_path import PointConfig

@@ -70,9 +70,10 @@ def test_gradients_land_in_the_flat_buffer_and_equal_the_plain_backward():
     _loss(m, g).backward()
     for k, p in m.physics_net.named_parameters():
         assert torch.allclose(p.grad, 2 * plain[k], rtol=1e-6, atol=0), k
-    # bucket layout: 48 static tensors | 36 head tensors | encoder
+    # bucket layout: 48 static tensors | 36 head tensors | encoder layers, encoder.norm, projection | data embedding (token, token convolution)
     sizes = [sum(p.numel() for p in b) for b in m.physics_net.gradient_buckets()]
-    assert [len(b) for b in m.physics_net.gradient_buckets()] == [48, 36, 71] and sum(sizes) == 5607314
+    assert [len(b) for b in m.physics_net.gradient_buckets()] == [48, 36, 68, 3] and sum(sizes) == 5607314
+    assert sizes[3] == 128 * 256 + 256 * 2405 * 3 + 256
     assert opt.bucket_bounds[0][0] == 0 and opt.bucket_bounds[-1][1] == flat.numel()
     assert all(a[1] == b[0] for a, b in zip(opt.bucket_bounds, opt.bucket_bounds[1:]))
 
@@ -152,7 +153,7 @@ def test_fused_optimizer_is_a_torch_optimizer_with_device_side_lr():
 
 
 def test_staged_step_equals_the_plain_step():
-    """StagedPdeStep (two backward segments, the layout buckets stage_buckets[i] complete after segment i) gives bit-for-bit the gradients of
+    """StagedPdeStep (three backward segments, the layout buckets stage_buckets[i] complete after segment i) gives bit-for-bit the gradients of
     loss.backward()."""
     from deepphysinet_amd.interface.interface_physics import StagedPdeStep
     g = _gpu(synthetic_inputs(700, tag='inter'))
@@ -174,6 +175,35 @@ def test_staged_step_equals_the_plain_step():
         assert torch.equal(p.grad, plain[k]), k
     opt.step()
     assert np.isfinite(float(opt.grad_norm))
+
+
+def test_staged_lead_batch_step_equals_place_lead_batch():
+    """the staged step for a batch of field samples (configs[2] sharded over ranks = configs[3] as SURVEY 8d defines it):
+    StagedPdeStep(lead_batch=True) gives bit for bit the gradients of place_lead_batch(...).backward(), every layout bucket complete after its
+    stage."""
+    from deepphysinet_amd.interface.interface_physics import StagedPdeStep
+    B, n = 3, 1500
+    many = [_gpu(synthetic_inputs(n, tag='lead%d' % k, forecast_h=24.0 * k / 360.0)) for k in range(B)]
+    lead = {k: torch.stack([b_[k].reshape(-1) for b_ in many]) for k in ('x', 'y', 't', 'f')}
+    lead['coord_data'] = torch.stack([b_['coord_data'] for b_ in many])
+    lead['field_data'] = torch.cat([b_['field_data'] * (1.0 + 0.1 * k) for k, b_ in enumerate(many)], dim=0)
+    lead['forecast_h'] = torch.cat([b_['forecast_h'] for b_ in many], dim=0)
+    m = _model()
+    opt = m.build_optimizer()
+    opt.zero_grad(set_to_none=True)
+    lf = m.train_cfg['losses']['loss_factor']
+    loss, _ = m.place_lead_batch(lead['x'], lead['y'], lead['t'], lead['f'], lead['field_data'], lead['coord_data'], lead['forecast_h'],
+                                 torch.nn.MSELoss(), lf)
+    loss.backward()
+    plain = {k: p.grad.clone() for k, p in m.physics_net.named_parameters()}
+    st = StagedPdeStep(m, opt, lead, lead_batch=True)
+    for i, stage in enumerate(st.stages):
+        stage()
+        for k in range(*st.stage_buckets[i]):
+            assert all(p.grad is not None for p in m.physics_net.gradient_buckets()[k])
+    assert float(st.loss) == float(loss.detach())
+    for k, p in m.physics_net.named_parameters():
+        assert torch.equal(p.grad, plain[k]), k
 
 
 def _free_port():
@@ -261,6 +291,22 @@ def test_bench_starts_its_own_ranks():
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['step_segments'] == 4
     assert out['value'] > 0 and np.isfinite(out['ms_per_step'])
+    assert out['config']['workload'].startswith('configs[3]') and out['collective']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_bench_two_ranks_with_a_lead_batch_run_the_staged_captured_step():
+    """`bench.py --gpus 2 --leads 3` (configs[2] per rank, sharded: configs[3] as SURVEY 8d defines it) runs the staged step
+    -- three captured backward segments with a bucket all-reduce behind each, then the optimiser -- not an eager step with one collective."""
+    env = dict(os.environ, DPN_BENCH_ONE_DEVICE='1', DPN_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--leads', '3', '--steps', '2', '--warmup', '1', '--points', '4096',
+                        '--no-cpu-baseline', '--no-alt'], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['config']['leads'] == 3 and out['config']['step_segments'] == 4 and out['config']['hip_graph'] is True
+    assert out['config']['workload'].startswith('configs[3] (configs[2] per GPU')
+    assert out['value'] > 0 and np.isfinite(out['ms_per_step']) and out['parameters_finite'] is True
 
 
 def test_bench_step_with_rccl_collectives_on_one_rank():
