@@ -214,7 +214,7 @@ def test_data_loss_and_reference_forward_surface(golden_dir):
     m.physics_net.zero_grad()
     loss = m.data_loss(g['x'], g['y'], g['t'], g['field_data'], g['coord_data'], g['labels'], g['forecast_h'])
     loss.backward()
-    assert abs(float(loss) - float(d['loss'])) <= 5e-5 * float(d['loss']), (float(loss), float(d['loss']))
+    assert abs(float(loss.detach()) - float(d['loss'])) <= 5e-5 * float(d['loss']), (float(loss.detach()), float(d['loss']))
     ref_norm = dict(zip([str(n) for n in d['names']], d['norms']))
     for name, p in m.physics_net.named_parameters():
         if name.endswith('key_projection.bias'):
@@ -345,7 +345,7 @@ def test_config0_one_degree_grid_data_loss_only():
     g = _gpu(inp)
     loss = m.data_loss(g['x'], g['y'], g['t'], g['field_data'], g['coord_data'], g['labels'], g['forecast_h'])
     loss.backward()
-    assert abs(float(loss) - float(ref)) <= 5e-5 * float(ref)
+    assert abs(float(loss.detach()) - float(ref)) <= 5e-5 * float(ref)
     for name, p in m.physics_net.named_parameters():
         if name.endswith('key_projection.bias'):
             continue
@@ -599,14 +599,15 @@ def test_config2_lead_batch_in_one_step_equals_the_loop():
                                 _dev())
         l_b.backward()
         total += float(l_b.detach())
-    # same kernels, but the batched encoder sums its GEMMs in another order than a single field's (see the gradient check below): the
-    # hyper-weights differ in their last bits and a point next to a ReLU kink / clip bound can change sides (bf16x2 caveat)
-    assert abs(float(loss.detach()) - total) <= 2e-4 * abs(total)
-    # Same kernels, but the batched encoder runs its GEMMs in the many-tile form (64-deep k-tiles) and a single field in the one-stage
-    # form: the same sums in another order, i.e. hyper-weights that differ in their last bits.  A point next to a ReLU kink, a clip bound
-    # or the condensation switch of the vapour equation can then change sides (measured: one point of field 0 moves its energy / vapour
-    # terms by 3e-4 and the -- tiny -- V_net gradients by up to 2e-3 of their own norm).  So: all gradients together within 2e-4, every
-    # tensor within 5e-3 of its own norm, single elements within 1e-2 of the tensor's maximum.
+    # Since round 4 the encoder's arithmetic does not depend on the batch: the row-local fused nodes scale and multiply row by row, the token
+    # convolution runs the same split-K form for one field and for five, the hyper-network heads of a batch are bit-identical to a single
+    # field's.  So the forward pass -- every loss term of every field -- is IDENTICAL, no switch can change sides, and what is left is the
+    # order in which parameter gradients are summed over fields and row blocks (fp32 reassociation): every gradient element within
+    # TOL['bf16x2']['grad'] of its tensor's maximum with two orders of margin, all gradients together within 1e-5.
+    assert abs(float(loss.detach()) - total) <= 1e-6 * abs(total)
+    for b in range(B):
+        t_b = m.pde_loss_terms(g[b]['x'], g[b]['y'], g[b]['t'], g[b]['f'], g[b]['field_data'], g[b]['coord_data'], g[b]['forecast_h']).detach()
+        assert torch.equal(t_b.float().cpu(), terms[b].detach().float().cpu()), (b, t_b, terms[b])
     num = den = 0.0
     for n_, p in m.physics_net.named_parameters():
         if n_.endswith('key_projection.bias'):
@@ -615,9 +616,8 @@ def test_config2_lead_batch_in_one_step_equals_the_loop():
         d_ = (a_ - b_).abs()
         num += float(d_.double().pow(2).sum())
         den += float(b_.double().pow(2).sum())
-        assert float(d_.pow(2).mean().sqrt()) <= 5e-3 * float(b_.pow(2).mean().sqrt()) + 1e-30, n_
-        assert float(d_.max()) <= 1e-2 * float(b_.abs().max()) + 1e-30, n_
-    assert (num / den) ** 0.5 <= 2e-4, (num / den) ** 0.5
+        assert float(d_.max()) <= 0.02 * TOL['bf16x2']['grad'] * float(b_.abs().max()) + 1e-30, (n_, float(d_.max()), float(b_.abs().max()))
+    assert (num / den) ** 0.5 <= 1e-5, (num / den) ** 0.5
 
 
 def test_error_behaviour_matches_the_reference_convention():
@@ -908,7 +908,7 @@ def _terms_vs_oracle_flip_free(m, inp, st=None, gain=1.0, with_clip=True, max_fl
     flipped, _ = _flipped_points(m, inp, st=st, gain=gain, with_clip=with_clip)
     idx = torch.nonzero(flipped).flatten().tolist()
     n = flipped.shape[0]
-    assert len(idx) <= (max(3, n // 100) if max_flipped is None else max_flipped), idx
+    assert len(idx) <= (max(3, n // 150) if max_flipped is None else max_flipped), idx        # measured: 32 of 5 197 points (0.62 %), 3 of 200
     sub = _without(inp, flipped) if idx else inp
     gs = _gpu(sub)
     terms = m.pde_loss_terms(gs['x'], gs['y'], gs['t'], gs['f'], gs['field_data'], gs['coord_data'], gs['forecast_h']).detach().double().cpu().numpy()
@@ -1114,7 +1114,10 @@ def test_config4_fp8_encoder_workload():
     err_prod = np.abs(got['0'] - ref['parts']) / np.abs(ref['parts'])
     err_fp8 = np.abs(got['1'] - ref['parts']) / np.abs(ref['parts'])
     assert np.all(np.isfinite(got['1']))
-    assert err_prod.max() <= 1e-3, err_prod                          # the product path on the same inputs (kink-free batches hold 1e-4)
+    if err_prod.max() > 1e-4:                                        # the product path on the same inputs: 1e-4 once the points whose switches differ
+        mine, ref_ff, idx = _terms_vs_oracle_flip_free(m, inp)       # from the oracle arithmetic's are named and removed (like every other test)
+        print('config4 sample: removed points %s' % idx)
+        assert idx and np.all(np.abs(mine - ref_ff) <= 1e-4 * np.abs(ref_ff)), (idx, mine, ref_ff)
     assert err_fp8.max() <= 0.5, err_fp8                             # configs[4]: stated tolerance
     assert err_fp8.max() > 10 * err_prod.max(), (err_fp8, err_prod)  # ... and it is a real precision loss, not noise
 

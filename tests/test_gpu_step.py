@@ -141,7 +141,7 @@ def test_fused_optimizer_is_a_torch_optimizer_with_device_side_lr():
     assert np.allclose(lrs[:5], [9.09e-5, 6.72e-5, 3.78e-5, 1.41e-5, 5e-6], rtol=5e-3)       # SURVEY appendix A probe sequence
     torch.cuda.synchronize()
     for a, b in zip(w, ref_w):
-        assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max()), 'graph replays did not follow the schedule'
+        assert float((a - b).detach().abs().max()) < 2e-6 * float(b.detach().abs().max()), 'graph replays did not follow the schedule'
     assert int(mine.step_count) == 7                             # one eager step + six replays (the capture itself executes nothing)
     sd = mine.state_dict()
     other = torch.optim.Adam([t.detach().clone().requires_grad_(True) for t in w], lr=1.0)
@@ -576,3 +576,32 @@ def test_distributed_training_loop_with_an_odd_sample_count(tmp_path):
     assert len(a.files) == 156
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_plain_bf16_trains_like_the_parity_grade_mode():
+    """the plain-bf16 operand mode is quoted as `other_precision_mode` only, and nothing showed that it trains.  Thirty
+    optimiser steps from the same initial weights on the same batch in both modes, in the regime the reference trains in for its first 2000
+    steps (data loss only, interface_physics.py:436-441; with the PDE terms switched on from step 0 and Adam at 1e-4 the loss of THIS
+    initialisation explodes within three steps in either mode -- factors up to 1e14 -- and a trajectory comparison means nothing): the bf16
+    loss falls in both modes by a factor > 2, and the mean over the last ten steps agrees within 25 % (measured: 3.63e6 -> 1.14e6 parity-grade,
+    -> 1.33e6 plain bf16; step by step the two runs differ by up to 40 % -- Adam at 1e-4 through the hyper-network makes single steps jump by
+    factors of two in either mode, so a step-wise bound would only measure that).  Plain bf16 stays out of every headline regardless."""
+    g = _gpu(synthetic_inputs(4096, tag='margin', margin=True))
+    traj = {}
+    for prec in ('bf16x2', 'bf16'):
+        m = _model(prec)
+        opt = m.build_optimizer()
+        losses = []
+        for it in range(30):
+            opt.zero_grad(set_to_none=True)
+            loss = m.data_loss(g['x'], g['y'], g['t'], g['field_data'], g['coord_data'], g['labels'], g['forecast_h'])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        traj[prec] = np.array(losses)
+    a, b = traj['bf16x2'], traj['bf16']
+    print('data loss, parity-grade mode:', a[[0, 9, 19, 29]], ' plain bf16:', b[[0, 9, 19, 29]], ' max step-wise deviation %.2e' % np.max(np.abs(b - a) / np.abs(a)))
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+    assert abs(b[0] - a[0]) <= 5e-3 * a[0]                           # same initial weights: the first loss differs by the operand rounding only
+    assert a[-10:].mean() < 0.5 * a[0] and b[-10:].mean() < 0.5 * b[0], (a, b)
+    assert abs(b[-10:].mean() - a[-10:].mean()) <= 0.25 * a[-10:].mean(), (a[-10:].mean(), b[-10:].mean())
