@@ -128,7 +128,7 @@ def main():
                     help='bf16x2 (default): the parity-grade mode (PDE losses within 1e-4 of the fp32 reference); bf16: plain bf16 operands')
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=16384)
+    ap.add_argument('--cpu-sample', type=int, default=0, help='points of the CPU baseline sample (0 = the workload itself: all --points)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
     ap.add_argument('--encoder-fp8', nargs='?', const='1', default=None, choices=['1', 'mx'],
@@ -493,12 +493,14 @@ def main():
                     cpu_model = next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), None)
             except OSError:
                 pass
-            v, secs = cpu_baseline(args.cpu_sample, seed=1)
-            v2, secs2 = cpu_baseline(args.cpu_sample, seed=1, share_derivatives=True)
+            n_cpu = args.cpu_sample or args.points                # default: the identical step, all points of the workload
+            v, secs = cpu_baseline(n_cpu, seed=1)
+            v2, secs2 = cpu_baseline(n_cpu, seed=1, share_derivatives=True)
             out['cpu_baseline'] = {'value': v, 'unit': 'points/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                                   'sample': 'oracle place_one_batch + backward (fp32, 28 autograd.grad calls) on %d points of the same '
-                                             'synthetic field; best of 3 after 1 warm-up, %.1f s per pass; host: %s, %d logical cores, %d threads used '
-                                             '(--cpu-sample 37265 times the whole grid)' % (args.cpu_sample, secs, cpu_model, os.cpu_count() or 0, torch.get_num_threads()),
+                                   'sample': 'oracle place_one_batch + backward (fp32, 28 autograd.grad calls) on %d of the %d points of the same '
+                                             'synthetic field (%s); best of 3 after 1 warm-up, %.1f s per pass; host: %s, %d logical cores, %d threads used'
+                                             % (n_cpu, args.points, 'the identical step' if n_cpu == args.points else 'a bounded sample', secs, cpu_model,
+                                                os.cpu_count() or 0, torch.get_num_threads()),
                                    'host_cpu': cpu_model, 'host_logical_cores': os.cpu_count(),
                                    'shared_jacobian_variant': {'value': v2, 'seconds_per_pass': secs2,
                                                                'note': 'same oracle, the 18 distinct derivatives taken once (SURVEY 8d variant ii)'}}

@@ -106,6 +106,8 @@ EXPORTS = {
                         c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_fwd_ref': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_fwd_ref_nets': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
+                                 c_int, c_void_p, c_void_p, c_void_p]),
     'dpn_contract_gpe': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'dpn_residual': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(DpnGeometry), POINTER(DpnPhysics), c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p]),

@@ -2303,8 +2303,22 @@ int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, vo
 static unsigned* g_timeline = nullptr;
 int dpn_debug_set_timeline(void* buf) { g_timeline = reinterpret_cast<unsigned*>(buf); return 0; }    // experiment build only, not in dpn_hip.h
 #endif
+static int fwd_launch(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, const float* ref_data, int64_t n,
+                      const float* freqs, const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream,
+                      int n_nets);
 int dpn_fwd_ref(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, const float* ref_data, int64_t n,
                 const float* freqs, const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream) {
+    return fwd_launch(x, y, t, pe_in, coord_data, ref_data, n, freqs, geo, packed, prec, out_n, jac_n, saved, stream, kNets);
+}
+// the first n_nets VariableNets only (inference: nothing is saved); the other columns of out_n / jac_n are left untouched
+int dpn_fwd_ref_nets(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, const float* ref_data, int64_t n,
+                     const float* freqs, const DpnGeometry* geo, const void* packed, int prec, int n_nets, float* out_n, float* jac_n, void* stream) {
+    if (n_nets < 1 || n_nets > kNets) return -1;
+    return fwd_launch(x, y, t, pe_in, coord_data, ref_data, n, freqs, geo, packed, prec, out_n, jac_n, nullptr, stream, n_nets);
+}
+static int fwd_launch(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, const float* ref_data, int64_t n,
+                      const float* freqs, const DpnGeometry* geo, const void* packed, int prec, float* out_n, float* jac_n, void* saved, void* stream,
+                      int n_nets) {
     if (!coord_data || !freqs || !geo || !packed || !out_n || n <= 0 || (prec != 1 && prec != 2)) return -1;
     if (!pe_in && (!x || !y || !t)) return -1;
 #ifdef DPN_TIMELINE
@@ -2313,7 +2327,7 @@ int dpn_fwd_ref(const float* x, const float* y, const float* t, const float* pe_
     FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, 0, ref_data};
 #endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)(a.n_pad / 128), kNets);
+    const dim3 grid((unsigned)(a.n_pad / 128), n_nets);
 #ifdef DPN_EXPERIMENT_FWD2
     if (!pe_in && getenv("DPN_FWD2") != nullptr) {          // experiment build only: the shelved eight-wave kernel
         if (prec == 1) hipLaunchKernelGGL(dpn_fwd2_kernel<1>, grid, dim3(512), 0, s, a);
@@ -2327,7 +2341,7 @@ int dpn_fwd_ref(const float* x, const float* y, const float* t, const float* pe_
     const char* force = getenv("DPN_FWD_KERNEL");          // read per call: the tests switch kernels inside one process
     const bool tiles = force ? (force[0] == 't') : (prec == 2);
     if (tiles && !pe_in) {
-        const dim3 grid64((unsigned)(a.n_pad / 64), kNets);
+        const dim3 grid64((unsigned)(a.n_pad / 64), n_nets);
         if (saved && features_prepass()) {             // positional features once per point (read by the six nets' workgroups)
             char* feat = reinterpret_cast<char*>(saved) + saved_state_bytes(a.n_pad, prec);
             a.feat = feat;

@@ -64,11 +64,13 @@ class VariableNet(nn.Module):
         import copy
         cfg = copy.copy(getattr(self, '_point_cfg', None) or PointConfig())
         heads = torch.cat([w1b1] * 6 + [w2b2] * 6, dim=1)
-        # the point kernels evaluate six nets per launch (this one fills all six slots; a one-net launch would need a net count in every
-        # entry point of the C ABI, for a surface the training step never calls) and add ref_data inside the kernel (dpn_fwd_ref): the output
-        # is the kernel's own sum, not rebuilt by subtraction.  ref_data enters as a constant; where the caller needs d out / d ref_data
-        # (= 1) it is added outside
+        # the point kernels evaluate six nets per launch: this one fills all six slots, and an inference call (nothing requires a gradient)
+        # launches the first slot only (cfg.n_nets = 1 -> dpn_fwd_ref_nets); a differentiated call keeps the six-slot launch, whose saved
+        # state the backward kernels expect.  ref_data is added inside the kernel (dpn_fwd_ref): the output is the kernel's own sum, not
+        # rebuilt by subtraction.  ref_data enters as a constant; where the caller needs d out / d ref_data (= 1) it is added outside
         ref = ref_data.reshape(-1, 1)
         cfg.ref6 = (torch.zeros_like(ref) if ref.requires_grad else ref.detach()).expand(-1, 6).contiguous()
+        needs_grad = torch.is_grad_enabled() and any(v.requires_grad for v in (meta_out, coord, coord_data, ref_data) + tuple(self.parameters()))
+        cfg.n_nets = 6 if needs_grad else 1
         out = point_fields(cfg, coord_data, heads, evec.unsqueeze(0).expand(6, -1).contiguous(), self.static_params() * 6, pe_in=coord)
         return out[:, 0:1] + ref if ref.requires_grad else out[:, 0:1]

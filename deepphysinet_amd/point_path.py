@@ -139,6 +139,12 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
         ws.alloc_saved()
     geo = cfg.geometry()
     # ref6 [N,6]: the reference's separate ref_data argument (VariableNet.forward standalone); None: coord_data's columns (PhysicsNet.forward)
+    n_nets = int(getattr(cfg, 'n_nets', 6) or 6)
+    if n_nets < 6 and not want_saved and not want_jac:             # VariableNet.forward standalone, inference: only the nets that are asked for
+        out_n.zero_()
+        L.check(lib.dpn_fwd_ref_nets(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), _ptr(ref6), n, _ptr(_freqs(dev)), ctypes.byref(geo),
+                                     _ptr(ws.packed), cfg.prec, n_nets, _ptr(out_n), None, _stream()), 'dpn_fwd_ref_nets')
+        return out_n, jac_n
     L.check(lib.dpn_fwd_ref(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), _ptr(ref6), n, _ptr(_freqs(dev)), ctypes.byref(geo),
                             _ptr(ws.packed), cfg.prec, _ptr(out_n), _ptr(jac_n), _ptr(ws.saved), _stream()), 'dpn_fwd')
     return out_n, jac_n
@@ -234,8 +240,8 @@ class _PointFieldsFn(torch.autograd.Function):
         tens = [None if v is None else _f32c(v) for v in (x, y, t, pe_in, coord_data, heads, evec)]
         x_, y_, t_, pe_, cd_, hd_, ev_ = tens
         st = [_f32c(s) for s in statics]
-        need_grad = any(v.requires_grad for v in (heads, evec) + tuple(statics))
-        want_gpe = pe_in is not None and pe_in.requires_grad
+        need_grad = any(v.requires_grad for v in (heads, evec) + tuple(statics)) and int(getattr(cfg, 'n_nets', 6) or 6) == 6
+        want_gpe = pe_in is not None and pe_in.requires_grad        # (n_nets < 6: the caller has established that nothing is differentiated)
         ws = _Workspace(cd_.shape[0], cfg.prec, cd_.device)
         nets = _net_ptrs(hd_, ev_, st)
         ref6 = getattr(cfg, 'ref6', None)                 # VariableNet.forward's own ref_data (a constant: no gradient flows to it here)

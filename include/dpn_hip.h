@@ -102,6 +102,12 @@ int dpn_fwd_ref(const float* x, const float* y, const float* t, const float* pe_
                 int64_t n_points, const float* freqs, const DpnGeometry* geo, const void* packed, int prec,
                 float* out_n, float* jac_n, void* saved, void* stream);
 
+/* dpn_fwd_ref for the first n_nets VariableNets only (1..6), inference only (nothing is saved for a backward pass): VariableNet.forward
+ * standalone (model/variable_net.py:49-87) evaluates ONE net, not six.  Columns >= n_nets of out_n / jac_n are left untouched. */
+int dpn_fwd_ref_nets(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, const float* ref_data,
+                     int64_t n_points, const float* freqs, const DpnGeometry* geo, const void* packed, int prec, int n_nets,
+                     float* out_n, float* jac_n, void* stream);
+
 /* g_pe[N][192] = sum_k g_out[N][k] * gpe[N][k][192]: backward of PhysicsNet.forward w.r.t. its encoded-coordinate input. */
 int dpn_contract_gpe(const float* g_out, const float* gpe, int64_t n_points, float* g_pe, void* stream);
 

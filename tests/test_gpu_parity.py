@@ -1011,6 +1011,9 @@ def test_variable_net_standalone_forward_matches_oracle():
             want = O.variable_net_forward(st, name, meta_ref, coord_ref, inp['coord_data'], ref_data.cpu(), inp['forecast_h'])
         assert out.shape == (n, 1)
         assert float((out.detach().cpu() - want).abs().max() / want.abs().max()) < TOL['bf16x2']['field'], name
+        with torch.no_grad():                                                   # inference: the one-net launch (dpn_fwd_ref_nets), same values
+            out1 = net(meta.detach(), coord, g['coord_data'], ref_data, g['forecast_h'])
+        assert torch.equal(out1, out.detach()), name
     net.zero_grad(set_to_none=True)
     out.sum().backward()
     assert net.out_fc.weight.grad is not None and bool(torch.isfinite(net.out_fc.weight.grad).all())
