@@ -715,6 +715,7 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
     const int net = blockIdx.y;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    TS_STAMP(0);
     const char* pk = a.packed + (long)net * pack_bytes_per_net(NS);
 #if TS_PRIO == 2
     __builtin_amdgcn_s_setprio(1);
@@ -789,7 +790,9 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
         ts::save_tile_k<NS, NS>(ov.Z0, net, tile0 + p, ct, lane, I, false, f0, f1);
 #endif
     }
+    TS_STAMP(1);
     ts::barrier_lds();
+    TS_STAMP(2);
     // ---------------- Z1 = m1 (.) (w1 Z0 + g b1) -> X (+ K-layout rows)
     f32x16 acc[2][2];
     Frag<NS> F[2][2][2];
@@ -805,6 +808,7 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
 #else
     ts::gemm<NS, 12, 2, false, ts::NoSide, false>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
 #endif
+    TS_STAMP(3);
     ts::gemm_head<NS, 16, 2>(chunk(kS1 + 2 * w * 16), lane, H);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -819,14 +823,18 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
             ts::save_tile_k<NS, NS>(ov.Z1, net, tile0 + p, 2 * w + t, lane, I, false, F[t][p][0], F[t][p][1]);
 #endif
         }
+    TS_STAMP(4);
     ts::barrier_lds();                                        // everybody is done reading Z0
+    TS_STAMP(5);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) ts::x_store<NS>(xl, 4 * w + 2 * t + kk, p, F[t][p][kk]);
+    TS_STAMP(6);
     ts::barrier_lds();
+    TS_STAMP(7);
     // ---------------- Z = w2 Z1 + Wd (g pe6) + g (b2 + bd + e): channel per lane (SWAP), acc[t][p] = [points of column tile p][channels of tile 2w+t]
     {
         const int rr = (j & 3) + 4 * (j >> 3), hh = (j >> 2) & 1;   // natural-order read of cvec for channel 32T + j from the [h][T][r] permuted vector
@@ -854,6 +862,7 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
 #else
     ts::gemm<NS, 16, 2, true, ts::NoSide, false>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
 #endif
+    TS_STAMP(8);
     ts::gemm_head<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), lane, H);
     Frag<NS> f6[3][2];
     {   // G6 = g pe6 -> X (k-steps 0..11) and K-layout rows: units as for Z0
@@ -868,14 +877,18 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
             ts::save_tile_k<NS, NS>(ov.G6, net, tile0 + p, ct, lane, I, false, f6[uu][0], f6[uu][1]);
 #endif
         }
+        TS_STAMP(9);
         ts::barrier_lds();                                    // everybody is done reading Z1
+        TS_STAMP(10);
 #pragma unroll
         for (int uu = 0; uu < 3; ++uu) {
             const int u = 3 * w + uu, ct = u >> 1, p = u & 1;
             ts::x_store<NS>(xl, 2 * ct, p, f6[uu][0]);
             ts::x_store<NS>(xl, 2 * ct + 1, p, f6[uu][1]);
         }
+        TS_STAMP(11);
         ts::barrier_lds();
+        TS_STAMP(12);
     }
 #if TS_DEFER_SAVES
     {
@@ -885,6 +898,7 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
 #else
     ts::gemm<NS, 12, 2, true, ts::NoSide, false>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc);
 #endif
+    TS_STAMP(13);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -901,4 +915,5 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
                 }
                 store_d_as_k(ov.Z, net, NS, s, tile0 + p, 2 * w + t, lane, d);
             }
+    TS_STAMP(14);
 }

@@ -540,6 +540,10 @@ DEV void store_d_as_k(const KMat& m, int net, int ns, int s, int64_t tile32, int
     b.x = pack2(d[8], d[9]); b.y = pack2(d[10], d[11]); b.z = pack2(d[12], d[13]); b.w = pack2(d[14], d[15]);
     // streaming stores: 0.4 GB of operands per launch pass through once and must not evict the L2-resident weight stream
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#ifdef TS_ABL_NOSTORE            // ablation build (timing only, wrong results on purpose): the packed values stay alive, nothing is written
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+    return;
+#endif
     __builtin_nontemporal_store(u32x4_t{a.x, a.y, a.z, a.w}, reinterpret_cast<u32x4_t*>(kmat_ptr(m, net, ns, s, tile32, ct, lane, 0)));
     __builtin_nontemporal_store(u32x4_t{b.x, b.y, b.z, b.w}, reinterpret_cast<u32x4_t*>(kmat_ptr(m, net, ns, s, tile32, ct, lane, 1)));
 }
@@ -1062,6 +1066,9 @@ struct BwdArgs {
     const float *g_out, *g_jxi;
     void* saved;
     void* operands;
+#ifdef DPN_TIMELINE
+    unsigned* timeline;      // experiment build: [net][workgroup][4 waves][48] shader clocks at the phase boundaries of dpn_bwd_tiles_kernel
+#endif
 };
 
 template <int NS>
@@ -2400,8 +2407,13 @@ int dpn_bwd_points(const float* x, const float* y, const float* t, const float* 
                    void* operands, void* stream) {
     if (!coord_data || !freqs || !geo || !packed || !g_out || !saved || !operands || n <= 0 || (prec != 1 && prec != 2)) return -1;
     if (pe_in ? (g_jxi != nullptr) : (!x || !y || !t)) return -1;
+#ifdef DPN_TIMELINE
+    BwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), g_out, g_jxi,
+              const_cast<void*>(saved), operands, g_timeline};
+#else
     BwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), g_out, g_jxi,
               const_cast<void*>(saved), operands};
+#endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
     const char* force = getenv("DPN_BWD_KERNEL");          // ring | tiles (A/B measurements, bitwise comparison in the tests)

@@ -345,7 +345,7 @@ def test_config0_one_degree_grid_data_loss_only():
     g = _gpu(inp)
     loss = m.data_loss(g['x'], g['y'], g['t'], g['field_data'], g['coord_data'], g['labels'], g['forecast_h'])
     loss.backward()
-    assert abs(float(loss.detach()) - float(ref)) <= 5e-5 * float(ref)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 5e-5 * float(ref.detach())
     for name, p in m.physics_net.named_parameters():
         if name.endswith('key_projection.bias'):
             continue
