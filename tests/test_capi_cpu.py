@@ -60,6 +60,34 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.DpnSampler) == 6 * 4 + 5 * 8 + 2 * 4
 
 
+def test_ctypes_structs_have_the_c_compilers_layout(tmp_path):
+    """Every struct of include/dpn_hip.h the binding mirrors: size and the offset of every field as gcc lays them out (the round-4 entry
+    points take structs of ~30 pointers and a dozen ints: one missing pad would shift every pointer behind it)."""
+    import subprocess
+    from deepphysinet_amd import _lib
+    names = ['DpnNetPtrs', 'DpnNetGradPtrs', 'DpnGeometry', 'DpnPhysics', 'DpnSizes', 'DpnGemmProblem', 'DpnColsumJob', 'DpnLnGemm', 'DpnSampler',
+             'DpnEncPrep', 'DpnEncFwd', 'DpnEncBwd', 'DpnWgradProblem', 'DpnGemm16Problem']
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dpn_hip.h"', 'int main(void) {']
+    want = {}
+    for n in names:
+        st = getattr(_lib, n)
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (n, n))
+        want[n] = ctypes.sizeof(st)
+        for f in st._fields_:
+            fname = {'n_blocks': 'n_blocks'}.get(f[0], f[0])
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (n, f[0], n, fname))
+            want['%s.%s' % (n, f[0])] = getattr(st, f[0]).offset
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(['gcc', '-I' + os.path.join(root, 'include'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = {ln.split()[0]: int(ln.split()[1]) for ln in out.splitlines()}
+    assert got == want, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)}
+
+
 LAYOUT_TEST = r'''
 #include <cstdio>
 #include <set>
