@@ -898,10 +898,32 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
     const float* xp = p.X + (xok ? xn * p.x_sn : 0);
     constexpr int kWgDepth = 4;                  // rows in flight: blocks of 32 (a dependent global round trip per block would be a chain of latencies)
     float gv[kWgDepth][8], xv[kWgDepth][8];
-    // Loads are unconditional, from a clamped row, and land in the ring untouched; rows / columns outside the problem are zeroed by a
-    // multiplication when the block is CONSUMED.  (A select makes the compiler sink every load into a branch of its own, and a mask applied
-    // at fetch time puts an s_waitcnt vmcnt(0) in front of every barrier: both measured at ~1.5 us per 32-row block.)
+    // Fast path ("rows are k" for both operands: the weight gradients): buffer loads -- one instruction per load (the lane's eight row
+    // offsets are computed once, the block's base is a scalar), and the descriptor ends behind the slice's last row, so rows beyond it
+    // and the columns of lanes outside the problem (offset 2^31 - 16) read as zero without any mask.  (The generic form spends ~6 VALU per
+    // load on 64-bit addresses and 2 per element on masks: ~500 VALU per 32-row block and wave against 12 MFMAs.)
+    const bool fast = p.g_sm == 1 && p.x_sn == 1 && (int64_t)p.rows * g_sk * 4 < (1ll << 31) && (int64_t)p.rows * x_sk * 4 < (1ll << 31);
+    __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, fast ? (int)((int64_t)r_end * g_sk * 4) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, fast ? (int)((int64_t)r_end * x_sk * 4) : 0, 0x00020000);
+    int gvo[8], xvo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        gvo[e] = gok ? (int)(((g * 8 + e) * g_sk + gm) * 4) : 0x7ffffff0;
+        xvo[e] = xok ? (int)(((g * 8 + e) * x_sk + xn) * 4) : 0x7ffffff0;
+    }
     auto fetch = [&](int ks, float (&gd)[8], float (&xd)[8]) __attribute__((always_inline)) {
+        if (fast) {
+            const int gso = (int)((r_begin + ks * 32) * g_sk * 4), xso = (int)((r_begin + ks * 32) * x_sk * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gvo[e], gso, 0));
+                xd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xvo[e], xso, 0));
+            }
+            return;
+        }
+        // generic strides: unconditional loads from a clamped row, landing in the ring untouched; rows / columns outside the problem are
+        // zeroed by a multiplication when the block is CONSUMED.  (A select makes the compiler sink every load into a branch of its own,
+        // and a mask applied at fetch time puts an s_waitcnt vmcnt(0) in front of every barrier: both measured at ~1.5 us per block.)
         const int r0 = r_begin + ks * 32 + g * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -911,6 +933,7 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
         }
     };
     auto mask_rows = [&](int ks, float (&gd)[8], float (&xd)[8]) __attribute__((always_inline)) {
+        if (fast) return;
         const int r0 = r_begin + ks * 32 + g * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1014,6 +1037,194 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_reduce_kernel(WgArgs a) {
     else p.db[i - mn] = v;
 }
 
+
+// ------------------------------------------------------------------------------------------------ attention forward, 16-row query tiles
+// FullAttention (attn.py:50-68): o = softmax(q k^T / sqrt(32)) v per head, 8 heads x 32, L <= 288 tokens per field.  Round 3's kernel
+// (dpn_attn_fwd_kernel, exact-fp32 MFMA, 32-row tiles, K and V of the head staged through 151 KB of LDS) measured 11 us per layer on a
+// workload of a few MFLOP: it is launch-to-first-data plus a chain of LDS stages.  Here q, k and v never pass through LDS: with the f16
+// hi+lo split of the GEMMs above a lane's eight consecutive head channels of ONE token row ARE an MFMA fragment slot (scores: k = head
+// channel, exactly one k-step), and eight consecutive token rows of one channel are a slot of the P V product (k = key).  Workgroup =
+// (16 query rows, head): four waves, wave w takes key tiles w, w + 4, ... of the scores and key blocks w, w + 4, w + 8 of P V; only the
+// 16 x 288 score / probability block and the waves' partial outputs go through LDS (27 KB).  Rows of q and k are scaled by a power of
+// two each (the scales factor out of the head-channel contraction), v by one power of two per wave (its rows are contracted over).
+constexpr int kALmax = 288, kASS = 292;
+struct Attn16Args { const float *q, *k, *v; float *out, *P; int L; float scale; };
+
+DEV void load8g(float (&v)[8], const float* p) {                           // eight consecutive floats (32-byte aligned rows of a [..][256] tensor)
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+// scale the row that the four lanes (i, g = 0..3) hold (8 values each) so that its maximum lands in [8, 16); returns the biased exponent used
+DEV int scale_row32(float (&v)[8]) {
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
+    eb = eb < 4 ? 4 : eb;
+    const float sc = __builtin_bit_cast(float, (257 - eb) << 23);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= sc;
+    return eb;
+}
+
+__global__ __launch_bounds__(256) void dpn_attn16_fwd_kernel(Attn16Args a) {
+    __shared__ __attribute__((aligned(16))) float Ss[16 * kASS];
+    __shared__ __attribute__((aligned(16))) float part[4][16 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.y, q0 = blockIdx.x * 16, L = a.L;
+    const int64_t ro = (int64_t)blockIdx.z * L * kD;
+    const float* q = a.q + ro;
+    const float* k = a.k + ro;
+    const float* v = a.v + ro;
+    const int c = lane & 15, g = lane >> 4;
+    // ---- every load of the kernel in flight at once: the query fragment, this wave's key tiles (scores) and value blocks (P V)
+    // (unconditional loads from clamped rows, zeroed by a multiplication where they are consumed: a select would put every load into a
+    // branch of its own with its own wait)
+    float qv[8], kv[5][8], vv[3][2][8];
+    load8g(qv, q + (int64_t)min(q0 + c, L - 1) * kD + head * 32 + g * 8);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int jt = min(wave + 4 * u, 17), j = jt * 16 + c;                   // 18 key tiles of 16
+        load8g(kv[u], k + (int64_t)min(j, L - 1) * kD + head * 32 + g * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int ks = min(wave + 4 * u, 8);                                 // 9 key blocks of 32
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vv[u][nt][e] = v[(int64_t)min(ks * 32 + g * 8 + e, L - 1) * kD + head * 32 + nt * 16 + c];
+    }
+    {
+        const float mq = q0 + c < L ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] *= mq;
+    }
+    // ---- scores: S[i][j] = scale q_i . k_j
+    const int eq = scale_row32(qv);
+    u32x4 qhi, qlo;
+    split8(qv, qhi, qlo);
+    // the accumulator rows of this lane are queries 4 g + jj: their scales sit in lanes (4 g + jj, any g)
+    float qs[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) qs[jj] = __builtin_bit_cast(float, (__shfl(eq, 4 * g + jj) - 3) << 23) * a.scale;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int jt = wave + 4 * u;
+        if (jt >= 18) break;
+        {
+            const float mk = jt * 16 + c < L ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kv[u][e] *= mk;
+        }
+        const int ek = scale_row32(kv[u]);
+        u32x4 khi, klo;
+        split8(kv[u], khi, klo);
+        f32x4 am = (f32x4)0.f, ac = (f32x4)0.f;
+        am = mfma(qhi, khi, am);
+        ac = mfma(qhi, klo, ac);
+        ac = mfma(qlo, khi, ac);
+        const float ks_ = __builtin_bit_cast(float, (ek - 3) << 23);
+        const int col = jt * 16 + c;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            Ss[(4 * g + jj) * kASS + col] = col < L ? fmaf(ac[jj], kLoInv, am[jj]) * (qs[jj] * ks_) : -INFINITY;
+    }
+    __syncthreads();
+    // ---- softmax: wave w takes rows 4 w .. 4 w + 3, the 64 lanes stride the 288 columns; probabilities to LDS and to P (saved for the backward)
+    {
+        float e[4][5], mx[4], sm[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            mx[rr] = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int col = lane + 64 * u;
+                e[rr][u] = col < kALmax ? Ss[(4 * wave + rr) * kASS + col] : -INFINITY;
+                mx[rr] = fmaxf(mx[rr], e[rr][u]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) mx[rr] = fmaxf(mx[rr], __shfl_xor(mx[rr], o));
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            sm[rr] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { e[rr][u] = __expf(e[rr][u] - mx[rr]); sm[rr] += e[rr][u]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) sm[rr] += __shfl_xor(sm[rr], o);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * wave + rr;
+            const bool rok = q0 + row < L;
+            const float inv = 1.f / sm[rr];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int col = lane + 64 * u;
+                if (col < kALmax) {
+                    const float p = rok ? e[rr][u] * inv : 0.f;
+                    Ss[row * kASS + col] = p;
+                    if (rok) a.P[(((int64_t)blockIdx.z * 8 + head) * kALmax + q0 + row) * kALmax + col] = p;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- O = P V: this wave's key blocks; one power-of-two scale for all its value fragments
+    float vm = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                vv[u][nt][e] *= (wave + 4 * u < 9 && (wave + 4 * u) * 32 + g * 8 + e < L) ? 1.f : 0.f;
+                vm = fmaxf(vm, fabsf(vv[u][nt][e]));
+            }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_xor(vm, o));
+    int ev = (__builtin_bit_cast(int, vm) >> 23) & 0xff;
+    ev = ev < 4 ? 4 : ev;
+    const float vsc = __builtin_bit_cast(float, (257 - ev) << 23), vinv = __builtin_bit_cast(float, (ev - 3) << 23);
+    f32x4 om[2] = {(f32x4)0.f, (f32x4)0.f}, oc[2] = {(f32x4)0.f, (f32x4)0.f};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int ks = wave + 4 * u;
+        if (ks >= 9) break;
+        float pv[8];
+        lds8(pv, Ss + c * kASS + ks * 32 + g * 8);
+        u32x4 phi, plo;
+        split8(pv, phi, plo);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float sv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sv[e] = vv[u][nt][e] * vsc;
+            u32x4 vhi, vlo;
+            split8(sv, vhi, vlo);
+            om[nt] = mfma(phi, vhi, om[nt]);
+            oc[nt] = mfma(phi, vlo, oc[nt]);
+            oc[nt] = mfma(plo, vhi, oc[nt]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) part[wave][(4 * g + jj) * 32 + nt * 16 + c] = fmaf(oc[nt][jj], kLoInv, om[nt][jj]) * vinv;
+    __syncthreads();
+    for (int i = tid; i < 16 * 32; i += 256) {
+        const int row = i >> 5, col = i & 31;
+        if (q0 + row < L) a.out[ro + (int64_t)(q0 + row) * kD + head * 32 + col] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+    }
+}
+
 template <class K>
 int set_lds(K kernel, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1105,6 +1316,13 @@ int dpn_wgrad16(int n, const DpnWgradProblem* problems, int n_jobs, const DpnCol
     DpnGemm16Problem g[kWgMaxProblems];
     if (wgrad_as_gemm16(n, problems, g)) return -1;
     return gemm16_launch(n, g, n_jobs, jobs, slices, partials, 1, stream);
+}
+
+int dpn_attn16_fwd(const float* q, const float* k, const float* v, int L, int batch, float* out, float* P, void* stream) {
+    if (!q || !k || !v || !out || !P || L <= 0 || L > kALmax || batch <= 0 || batch > 32767) return -1;
+    Attn16Args a{q, k, v, out, P, L, 1.0f / sqrtf(32.0f)};
+    hipLaunchKernelGGL(dpn_attn16_fwd_kernel, dim3((L + 15) / 16, 8, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
 }
 
 int dpn_enc_prep(const DpnEncPrep* p, void* stream) {

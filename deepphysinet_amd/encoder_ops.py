@@ -640,7 +640,8 @@ class _EncoderStackFn(torch.autograd.Function):
         for l in range(nl):
             p_ = lay[l]
             o, P = new(n, D), new(B * 8, 288, 288)
-            L.check(lib.dpn_attn_fwd(_p(q), _p(k), _p(v), Lt, B, _p(o), _p(P), stream), 'dpn_attn_fwd')
+            attn = lib.dpn_attn_fwd if os.environ.get('DPN_ATTN_FWD') == 'fp32' else lib.dpn_attn16_fwd      # (round 3's exact-fp32 kernel: A/B runs)
+            L.check(attn(_p(q), _p(k), _p(v), Lt, B, _p(o), _p(P), stream), 'dpn_attn_fwd')
             x1, xhat1, rstd1, pre, act, x2, xhat2, rstd2 = new(n, D), new(n, D), new(n), new(n, D), new(n, D), new(n, D), new(n, D), new(n)
             kw = dict(tail=1, o=o, x=x, m_o=6 * l + 3, m_c1=6 * l + 4, m_c2=6 * l + 5, bo=p_[7], g1=p_[8], be1=p_[9], bc1=p_[11], bc2=p_[13],
                       g2=p_[14], be2=p_[15], x1=x1, xhat1=xhat1, rstd1=rstd1, pre=pre, act=act, x2=x2, xhat2=xhat2, rstd2=rstd2)

@@ -201,6 +201,9 @@ int dpn_sgemm_ln(const DpnLnGemm* problem, void* stream);
 int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, int batch, float* out, float* P, void* stream);
 int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L, int batch,
                  float* dq, float* dk, float* dv, void* stream);
+/* dpn_attn_fwd on the f16 hi+lo matrix cores with 16-row query tiles (same arguments, same P): q, k, v never pass through LDS -- a lane's
+ * eight consecutive head channels of one token row are an MFMA fragment slot.  The encoder's fused forward uses this one. */
+int dpn_attn16_fwd(const float* q, const float* k, const float* v, int L, int batch, float* out, float* P, void* stream);
 
 /* ---------------------------------------------------------------- row-local fused encoder nodes (csrc/dpn_encoder_chain.hip)
  * Everything of an EncoderLayer except the attention itself is row-wise (attn.py:183-185,196; transformer_net.py:33-44, :68, :129), so the
