@@ -269,7 +269,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
     layout) with its bias sum."""
 
     @staticmethod
-    def forward(ctx, field, conv_w, conv_b, token, pos, h, freq_bands, xu=None, te=None):
+    def forward(ctx, field, conv_w, conv_b, token, pos, h, freq_bands, xu=None, te=None, share=None):
         from .linear import _launch, _problem
         lib = L.load()
         B, T, C = field.shape
@@ -314,6 +314,11 @@ class _DataEmbeddingFn(torch.autograd.Function):
         ctx.save_for_backward(xu)
         ctx.n_tok, ctx.w_shape, ctx.tok_shape, ctx.B = n_tok, conv_w.shape, token.shape, B
         ctx.params = (conv_w, conv_b)
+        ctx.share = share
+        if share is not None and B == 1 and os.environ.get('DPN_EMBED_OWN_WGRAD') != '1':
+            # one field: the encoder stack's backward computes the token convolution's weight gradient inside ITS weight-gradient launch
+            # (dW = (d x0 rows of the field tokens)^T xu: both operands exist there) and hands it back through `share`
+            share.embed = dict(xu=xu, n_tok=n_tok, conv_w=conv_w, conv_b=conv_b, grads=None)
         return out
 
     @staticmethod
@@ -323,6 +328,12 @@ class _DataEmbeddingFn(torch.autograd.Function):
         D, B = ctx.w_shape[0], ctx.B
         g3 = g.reshape(B, -1, D)
         g_emb = _c(g3[:, ctx.n_tok:]).reshape(n, D)              # one field: a contiguous row range (no copy)
+        done = getattr(ctx.share, 'embed', None) if ctx.share is not None else None
+        if done is not None and done.get('grads') is not None:       # computed by the stack node's weight-gradient launch
+            dw, db = done['grads']
+            done['grads'] = None
+            g_tok = g3[:, :ctx.n_tok].reshape(ctx.tok_shape)
+            return None, dw.view(ctx.w_shape), db, g_tok, None, None, None, None, None, None
         dw, db = new_grad(ctx.params[0], (D, K3)), new_grad(ctx.params[1])
         if os.environ.get('DPN_ENCODER_UNFUSED') == '1':
             batch = []
@@ -334,7 +345,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
             held = wgrad16([(g_emb, xu, dw, db)])                   # (the launch is queued; `held` may go: the stream orders the reuse)
         g_tok = g3[:, :ctx.n_tok]
         g_tok = g_tok.reshape(ctx.tok_shape) if B == 1 else g_tok.sum(dim=0).reshape(ctx.tok_shape)
-        return None, dw.view(ctx.w_shape), db, g_tok, None, None, None, None, None
+        return None, dw.view(ctx.w_shape), db, g_tok, None, None, None, None, None, None
 
 
 def _embedding_fits(field, emb_module, token, h):
@@ -352,7 +363,7 @@ def data_embedding_fused(field, emb_module, token, h, prep=None):
     n = token.shape[-2] + field.shape[1]
     pos = emb_module.position_embedding.pe[0, :n]
     if prep is not None:
-        return _DataEmbeddingFn.apply(field, conv.weight, conv.bias, token, pos, h, emb_module.time_embending.freq_bands, prep.xu, prep.te)
+        return _DataEmbeddingFn.apply(field, conv.weight, conv.bias, token, pos, h, emb_module.time_embending.freq_bands, prep.xu, prep.te, prep)
     return _DataEmbeddingFn.apply(field, conv.weight, conv.bias, token, pos, h, emb_module.time_embending.freq_bands)
 
 
@@ -612,7 +623,7 @@ class _EncoderStackFn(torch.autograd.Function):
     then gf, bef, wp, bp when final."""
 
     @staticmethod
-    def forward(ctx, x0, B, Lt, nl, final, wpack, *params):
+    def forward(ctx, x0, B, Lt, nl, final, wpack, share, *params):
         lib = L.load()
         x0 = _c(x0)
         n, D = x0.shape
@@ -662,6 +673,7 @@ class _EncoderStackFn(torch.autograd.Function):
         ctx.save_for_backward(wpack, *saved, *([xf, xhatf, rstdf] if final else []), *[p_[8] for p_ in lay], *[p_[14] for p_ in lay],
                               *([fin[0]] if final else []))
         ctx.B, ctx.Lt, ctx.nl, ctx.final, ctx.rt, ctx.n_mats = B, Lt, nl, final, rt, n_mats
+        ctx.share = share
         ctx.params = params                                          # identify the gradient slots (grad_arena); never read
         return out
 
@@ -743,6 +755,15 @@ class _EncoderStackFn(torch.autograd.Function):
             res = gs1
         dx0 = new(n, D)
         bwd(head=1, body=0, res=res, dq=dq, dk=dk, dv=dv, m_h0=0, m_h1=1, m_h2=2, gx=dx0)
+        emb = getattr(ctx.share, 'embed', None) if ctx.share is not None else None
+        if emb is not None and B == 1 and n < 1024:
+            # the token convolution's weight gradient joins the launch: G = the field-token rows of d x0, X = the im2col rows (embed.py:45-47)
+            g_emb = dx0[emb['n_tok']:]
+            dwt = new_grad(emb['conv_w'], (D, emb['xu'].shape[1]))
+            dbt = new_grad(emb['conv_b'])
+            batch.append((g_emb, emb['xu'], dwt, dbt))
+            keep.append(g_emb)
+            emb['grads'] = (dwt, dbt)
         # every weight gradient of the stack and the LayerNorm parameter sums: ONE launch (dpn_wgrad16; plus its slice reduction for batches
         # of fields)
         while batch or jobs:
@@ -750,7 +771,7 @@ class _EncoderStackFn(torch.autograd.Function):
             j_, jobs = jobs[:L.GEMM_MAX_JOBS], jobs[L.GEMM_MAX_JOBS:]
             keep.append(wgrad16(b_, j_))
         del keep
-        return (dx0, None, None, None, None, None, *grads)
+        return (dx0, None, None, None, None, None, None, *grads)
 
 
 def _stack_matrices(lay, fin):
@@ -794,7 +815,7 @@ def _stack_fits(layers, norm, projection):
 
 class EncoderPrep:
     """dpn_enc_prep's outputs for one forward of the whole encoder: weight images, im2col rows, lead-time encodings."""
-    __slots__ = ('wpack', 'xu', 'te', 'pe_extra')
+    __slots__ = ('wpack', 'xu', 'te', 'pe_extra', 'embed')
 
 
 def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
@@ -810,6 +831,7 @@ def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
     fa = _c(emb_module.time_embending.freq_bands)
     hh = _c(h.detach().float().reshape(-1))
     out = EncoderPrep()
+    out.embed = None
     out.wpack = torch.empty(int(lib.dpn_enc_pack_bytes(len(mats))), dtype=torch.uint8, device=dev)
     out.xu = torch.empty((B * T, 3 * C), dtype=torch.float32, device=dev)
     te = torch.empty((B, 2 * fa.numel()), dtype=torch.float32, device=dev)
@@ -844,10 +866,10 @@ def encoder_forward_fused(net, x_enc, forecast_h):
     net.extra_lead_pe = (forecast_h, prep.pe_extra) if prep.pe_extra is not None else None
     x0 = data_embedding_fused(x_enc, emb, net.learnable_token, forecast_h, prep=prep)
     object.__setattr__(net, 'last_embedding', x0)                   # where a staged backward cuts between the stack and the data embedding
-    return encoder_stack_fused(x0, layers, enc.norm, net.projection, wpack=prep.wpack)
+    return encoder_stack_fused(x0, layers, enc.norm, net.projection, wpack=prep.wpack, share=prep)
 
 
-def encoder_stack_fused(x, layers, norm=None, projection=None, wpack=None):
+def encoder_stack_fused(x, layers, norm=None, projection=None, wpack=None, share=None):
     """[B, L, 256] -> the encoder layers (+ encoder.norm + output projection when both are given) as one autograd node, or None when the
     modules do not fit the kernels (8 heads x 32, d_ff = 256, gelu, affine LayerNorms with eps 1e-5, L <= 288)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 256 and x.shape[1] <= 288 and len(layers) >= 1):
@@ -869,5 +891,5 @@ def encoder_stack_fused(x, layers, norm=None, projection=None, wpack=None):
             return None
         params += [norm.weight, norm.bias, projection.weight, projection.bias]
     B, Lt = x.shape[0], x.shape[1]
-    out = _EncoderStackFn.apply(x.reshape(B * Lt, 256), B, Lt, len(layers), final, wpack, *params)
+    out = _EncoderStackFn.apply(x.reshape(B * Lt, 256), B, Lt, len(layers), final, wpack, share, *params)
     return out.view(B, Lt, 256)
