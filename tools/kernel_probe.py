@@ -1,4 +1,6 @@
-"""Times the four point kernels in isolation (HIP events, eager) for the bench workload."""
+"""Times the four point kernels in isolation (HIP events, eager) for the bench workload.
+DPN_PROBE_SOAK=<kernel>,<seconds>: first keep that kernel running back to back for so long (tools/clock_watch.py samples the clocks and the
+socket power it settles at) -- only that kernel is then timed."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,7 +38,16 @@ with torch.no_grad():
     def k_fwd_nosave(): L.check(lib.dpn_fwd(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed), cfg.prec, PP._ptr(out_n), PP._ptr(jac_n), None, s), 'fwd')
     def k_fwd_fields(): L.check(lib.dpn_fwd(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed), cfg.prec, PP._ptr(out_n), None, None, s), 'fwd')
     extra = (('fwd, nothing saved', k_fwd_nosave), ('fwd, fields only', k_fwd_fields)) if os.environ.get('DPN_PROBE_VARIANTS') else ()
+    soak = os.environ.get('DPN_PROBE_SOAK', '').split(',')
     for name, fn in (('pack', k_pack), ('fwd', k_fwd), ('bwd', k_bwd), ('wgrad', k_wgrad)) + extra:
+        if soak[0]:
+            if name != soak[0]:
+                continue
+            import time
+            t0 = time.time()
+            while time.time() - t0 < float(soak[1]):
+                for _ in range(50): fn()
+                torch.cuda.synchronize()
         for _ in range(3): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
