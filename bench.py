@@ -96,6 +96,42 @@ def cpu_baseline(sample_points, seed, share_derivatives=False):
     return sample_points / best, best
 
 
+def sample_power(work, seconds=2.0):
+    """Median shader clock and socket power (rocm-smi) while `work()` keeps the GPU busy for `seconds`: the MFMA-heavy point kernels run AT the
+    socket's power cap, where the clock -- and with it the MFMA peak a kernel can be priced against -- is what the power management leaves
+    (profiles/round4_point_kernel_clocks.txt).  None when rocm-smi is not there or says nothing."""
+    import shutil, statistics, subprocess, threading
+    smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    if not os.path.exists(smi):
+        return None
+    rows, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                d = json.loads(subprocess.run([smi, '--showclocks', '--showpower', '--json'], capture_output=True, text=True, timeout=10).stdout)
+                c = d[sorted(d)[0]]
+                clk = [v for k, v in c.items() if k.startswith('sclk clock speed')]
+                pw = [v for k, v in c.items() if 'Power (W)' in k]
+                rows.append((float(str(clk[0]).strip('()Mhz')), float(pw[0])))
+            except Exception:       # noqa
+                pass
+            time.sleep(0.05)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        work()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=15)
+    rows = rows[1:] if len(rows) > 3 else rows           # the first sample may predate the load
+    if not rows:
+        return None
+    return {'sclk_mhz': statistics.median(r[0] for r in rows), 'socket_w': statistics.median(r[1] for r in rows), 'samples': len(rows),
+            'source': 'rocm-smi --showclocks --showpower, median over %.1f s of back-to-back work' % seconds}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD torch.distributed.run and hand back its exit code.  The
     parent may already have touched the GPU runtime (on ROCm torch.cuda.device_count() can fall through to hipGetDeviceCount), so it only
@@ -131,6 +167,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=0, help='points of the CPU baseline sample (0 = the workload itself: all --points)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
+    ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi clock / socket power samples (about 5 s)')
     ap.add_argument('--encoder-fp8', nargs='?', const='1', default=None, choices=['1', 'mx'],
                     help='BASELINE configs[4]: the encoder layers\' forward GEMMs on fp8 (OCP e4m3) MFMA, bf16x2 Jacobian path; OFF by default -- it moves '
                          'the PDE losses by 1e-2 ... 2e-1 (tests/test_gpu_parity.py::test_config4_fp8_encoder_workload) and buys no time.  '
@@ -295,7 +332,7 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt = float(tt.item())
-        return m, dt, graphs is not None
+        return m, dt, graphs is not None, fn
 
     def collective_info():
         """Who took part: backend, world size, every rank's device (index, PCI bus id, name) gathered over the process group itself, and the
@@ -322,7 +359,7 @@ def main():
 
     sync = None
     coll = collective_info()
-    m, dt, graphed = run(args.prec, args.steps, args.warmup, not args.no_graph)
+    m, dt, graphed, step_fn = run(args.prec, args.steps, args.warmup, not args.no_graph)
     ms_per_step = dt / args.steps * 1e3
     pts_per_s = args.points * args.leads * world * args.steps / dt
 
@@ -438,6 +475,12 @@ def main():
             k_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / reps
             b_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / reps
             w_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / reps
+            sustained = None
+            if not args.no_power:
+                def soak():
+                    for _ in range(40):
+                        launch()
+                sustained = sample_power(soak, 2.5)
         ach = args.points * ALG_FLOP_FWD_JAC / (k_ms * 1e-3)
         ns = 2 if prec == 'bf16x2' else 1
         nsplit = 3 if prec == 'bf16x2' else 1
@@ -452,6 +495,10 @@ def main():
                 'algorithmic_bytes': args.points * 136,          # 40 B in + 96 B out per point: the kernel is MFMA-bound
                 'executed_mfma_tflops': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / 1e12,
                 'executed_mfma_frac_of_peak': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / MFMA_PEAK_BF16}
+        if sustained is not None:
+            # the kernel alone, back to back: the clock the socket's power cap leaves it, and the dense peak AT that clock (peak above = 2.4 GHz)
+            sustained['peak_at_this_clock_tflops'] = MFMA_PEAK_BF16 / 1e12 * sustained['sclk_mhz'] / 2400.0
+            roof['kernel_back_to_back'] = sustained
         # operands of the four products per point per net: M2 (0/1 bf16, one plane: 512 B) + Z, M2 + Z1, M2 + G6, T1 + Z0
         # = 3 x 512 + 2304 B of bf16 (the 2304 x2 in the hi+lo mode); v is not an operand any more (affine in m2: csrc SavedView)
         w_bytes = ws.sizes.n_pad * 6 * (3 * 512 + 2304 * ns)
@@ -472,11 +519,16 @@ def main():
     if rank == 0:
         out['roofline'], out['roofline_hbm_kernel'] = kernel_rooflines(m, args.prec)
         out['roofline']['step_frac_of_peak'] = pts_per_s / world * ALG_FLOP_STEP / MFMA_PEAK_BF16
+        if not args.no_power and world == 1:
+            def steps_():
+                for _ in range(25):
+                    step_fn()
+            out['power'] = sample_power(steps_, 2.0)          # the whole step replayed back to back (after the timed region)
         if not args.no_alt and world == 1:
             alt = 'bf16x2' if args.prec == 'bf16' else 'bf16'
             del m
             torch.cuda.empty_cache()
-            m2, dt2, _ = run(alt, max(5, args.steps // 3), 3, not args.no_graph)
+            m2, dt2, _, _ = run(alt, max(5, args.steps // 3), 3, not args.no_graph)
             st2 = max(5, args.steps // 3)
             out['other_precision_mode'] = {'mode': alt, 'value': args.points * args.leads * st2 / dt2, 'ms_per_step': dt2 / st2 * 1e3,
                                            'parity': 'PDE losses within 1e-4 of the fp32 reference' if alt == 'bf16x2' else

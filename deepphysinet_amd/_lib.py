@@ -61,7 +61,7 @@ class DpnEncFwd(Structure):
 class DpnEncBwd(Structure):
     _fields_ = [('wpack', c_void_p)] + [(n, c_int32) for n in ('n_mats', 'rows', 'row_tiles', 'head', 'body', 'm_h0', 'm_h1', 'm_h2', 'm_c2', 'm_c1', 'm_o')] + \
                [(n, c_void_p) for n in ('res', 'dq', 'dk', 'dv', 'dmeta', 'xhatf', 'rstdf', 'gin', 'xhat2', 'rstd2', 'pre', 'xhat1', 'rstd1', 'g2', 'g1', 'gf',
-                                        'gs2', 'dpre', 'gs1', 'dout', 'gx', 'partial_f', 'partial2', 'partial1')]
+                                        'gs2', 'dpre', 'gs1', 'dout', 'gx', 'partial_f', 'partial2', 'partial1', 'gx_head')] + [('gx_head_rows', c_int32)]
 
 
 class DpnGemm16Problem(Structure):

@@ -532,6 +532,8 @@ struct BwdArgs {
     const float* vec[3];
     float *gs2, *dpre, *gs1, *dout, *gx;
     float *partial_f, *partial2, *partial1;      // [workgroups][512]: sums over the workgroup's rows of g xhat | g
+    float* gx_head;                              // BODY 0: the first gx_head_rows rows of gx once more (the learnable tokens' gradient slot)
+    int gx_head_rows;
     ENC_TL_ARG
 };
 
@@ -682,7 +684,10 @@ __global__ __launch_bounds__(kThreads) void dpn_enc_bwd_kernel(BwdArgs a) {
     }
     if constexpr (!BODY) {
 #pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) store8(a.gx + off[tt], g[tt], ok[tt]);
+        for (int tt = 0; tt < NTT; ++tt) {
+            store8(a.gx + off[tt], g[tt], ok[tt]);
+            if (row0 + tt * 16 + rl.n16 < a.gx_head_rows) store8(a.gx_head + off[tt], g[tt], ok[tt]);
+        }
         return;
     } else {
         // (every row pass: arithmetic and the X image first, barrier, and only then the stores of the weight-gradient operands)
@@ -1422,6 +1427,7 @@ int dpn_enc_bwd(const DpnEncBwd* p, void* stream) {
     a.xhat2 = p->xhat2; a.rstd2 = p->rstd2; a.pre = p->pre; a.xhat1 = p->xhat1; a.rstd1 = p->rstd1;
     a.vec[VB_G2] = p->g2; a.vec[VB_G1] = p->g1; a.vec[VB_GF] = p->gf;
     a.gs2 = p->gs2; a.dpre = p->dpre; a.gs1 = p->gs1; a.dout = p->dout; a.gx = p->gx;
+    a.gx_head = p->gx_head; a.gx_head_rows = (p->gx_head && !p->body) ? p->gx_head_rows : 0;
     a.partial_f = p->partial_f; a.partial2 = p->partial2; a.partial1 = p->partial1;
     ENC_TL_SET(a);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

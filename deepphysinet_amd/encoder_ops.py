@@ -318,7 +318,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
         if share is not None and B == 1 and os.environ.get('DPN_EMBED_OWN_WGRAD') != '1':
             # one field: the encoder stack's backward computes the token convolution's weight gradient inside ITS weight-gradient launch
             # (dW = (d x0 rows of the field tokens)^T xu: both operands exist there) and hands it back through `share`
-            share.embed = dict(xu=xu, n_tok=n_tok, conv_w=conv_w, conv_b=conv_b, grads=None)
+            share.embed = dict(xu=xu, n_tok=n_tok, conv_w=conv_w, conv_b=conv_b, token=token, grads=None, g_tok=None)
         return out
 
     @staticmethod
@@ -332,7 +332,9 @@ class _DataEmbeddingFn(torch.autograd.Function):
         if done is not None and done.get('grads') is not None:       # computed by the stack node's weight-gradient launch
             dw, db = done['grads']
             done['grads'] = None
-            g_tok = g3[:, :ctx.n_tok].reshape(ctx.tok_shape)
+            g_tok = done.get('g_tok')
+            done['g_tok'] = None
+            g_tok = g_tok.view(ctx.tok_shape) if g_tok is not None else g3[:, :ctx.n_tok].reshape(ctx.tok_shape)
             return None, dw.view(ctx.w_shape), db, g_tok, None, None, None, None, None, None
         dw, db = new_grad(ctx.params[0], (D, K3)), new_grad(ctx.params[1])
         if os.environ.get('DPN_ENCODER_UNFUSED') == '1':
@@ -754,8 +756,14 @@ class _EncoderStackFn(torch.autograd.Function):
             wgrad(base + 4, base + 5, D, dv, x)
             res = gs1
         dx0 = new(n, D)
-        bwd(head=1, body=0, res=res, dq=dq, dk=dk, dv=dv, m_h0=0, m_h1=1, m_h2=2, gx=dx0)
         emb = getattr(ctx.share, 'embed', None) if ctx.share is not None else None
+        if emb is not None and B == 1 and n < 1024 and emb.get('token') is not None:
+            # the learnable tokens' rows of d x0 also go straight to that parameter's gradient slot (no copy node behind the backward pass)
+            g_tok = new_grad(emb['token'], (emb['n_tok'], D))
+            bwd(head=1, body=0, res=res, dq=dq, dk=dk, dv=dv, m_h0=0, m_h1=1, m_h2=2, gx=dx0, gx_head=g_tok, gx_head_rows=emb['n_tok'])
+            emb['g_tok'] = g_tok
+        else:
+            bwd(head=1, body=0, res=res, dq=dq, dk=dk, dv=dv, m_h0=0, m_h1=1, m_h2=2, gx=dx0)
         if emb is not None and B == 1 and n < 1024:
             # the token convolution's weight gradient joins the launch: G = the field-token rows of d x0, X = the im2col rows (embed.py:45-47)
             g_emb = dx0[emb['n_tok']:]

@@ -251,7 +251,9 @@ int dpn_enc_fwd(const DpnEncFwd* p, void* stream);
  *   body = 1:  gs2 = norm2 backward of g;  dpre = (gs2 Wc2) * gelu'(pre);  gs1 = norm1 backward of (dpre Wc1 + gs2);  dout = gs1 Wo
  *              (gs2, dpre, gs1: the operands of the weight-gradient GEMMs dWc2 = gs2^T act, dWc1 = dpre^T x1, dWo = gs1^T o; dout: the
  *              attention backward's input; gs1 is also the residual-branch cotangent the next launch takes as `res`)
- *   body = 0:  gx = g   (the cotangent of the first layer's input)
+ *   body = 0:  gx = g   (the cotangent of the first layer's input); its first gx_head_rows rows are written to gx_head as well when that is
+ *              given (the learnable tokens in front of the field tokens, model/transformer_net.py:123-126: their gradient lands in its own
+ *              tensor without a copy)
  * partial_f / partial2 / partial1: [workgroups][512] = per-workgroup sums of (g * xhat | g) of the three LayerNorms, reduced in a fixed order by a
  * DpnColsumJob with n_blocks = ceil(rows / (16 row_tiles)). */
 typedef struct DpnEncBwd {
@@ -260,6 +262,7 @@ typedef struct DpnEncBwd {
     const float *res, *dq, *dk, *dv, *dmeta, *xhatf, *rstdf, *gin;
     const float *xhat2, *rstd2, *pre, *xhat1, *rstd1, *g2, *g1, *gf;
     float *gs2, *dpre, *gs1, *dout, *gx, *partial_f, *partial2, *partial1;
+    float* gx_head; int32_t gx_head_rows;
 } DpnEncBwd;
 int dpn_enc_bwd(const DpnEncBwd* p, void* stream);
 
