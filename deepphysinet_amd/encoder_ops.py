@@ -873,7 +873,9 @@ def encoder_forward_fused(net, x_enc, forecast_h):
     prep = encoder_prep(x_enc, forecast_h, emb, getattr(net, 'extra_lead_freqs', None), layers, enc.norm, net.projection)
     net.extra_lead_pe = (forecast_h, prep.pe_extra) if prep.pe_extra is not None else None
     x0 = data_embedding_fused(x_enc, emb, net.learnable_token, forecast_h, prep=prep)
-    object.__setattr__(net, 'last_embedding', x0)                   # where a staged backward cuts between the stack and the data embedding
+    # where a staged backward cuts between the stack and the data embedding -- kept only on request (PhysicsNet.encode_field(keep_embedding=True)):
+    # it holds this call's autograd graph
+    object.__setattr__(net, 'last_embedding', x0 if getattr(net, 'keep_last_embedding', False) else None)
     return encoder_stack_fused(x0, layers, enc.norm, net.projection, wpack=prep.wpack, share=prep)
 
 

@@ -245,7 +245,7 @@ class InterfacePhysics(nn.Module):
             # forward serves both of its losses and all points share one backward (point_path._StepLossFn)
             from ..point_path import step_losses
             cfg = self.point_config(lf)
-            meta_out = self.physics_net.encode_field(b['field_data'], b['forecast_h'])
+            meta_out = self.physics_net.encode_field(b['field_data'], b['forecast_h'], keep_embedding=grad_sync is not None)
             heads, evec, statics = self.physics_net.field_weights(b['field_data'], b['forecast_h'], meta_out=meta_out)
             cat = lambda a_, b_: torch.cat([a_.reshape(a_.shape[0], -1), b_.reshape(b_.shape[0], -1)], dim=0)
             _, inter_total, _, margin_total, data = step_losses(
@@ -521,8 +521,9 @@ class StagedPdeStep:
         net = m.physics_net
         self.opt.zero_grad(set_to_none=True)
         cfg = m.point_config(self.lf)
-        self.meta_out = net.encode_field(b['field_data'], b['forecast_h'])
+        self.meta_out = net.encode_field(b['field_data'], b['forecast_h'], keep_embedding=True)
         self.x0 = getattr(net.meta_net.model, 'last_embedding', None)        # the cut between stages 1 and 2 (None: the encoder ran unfused)
+        object.__setattr__(net.meta_net.model, 'last_embedding', None)       # (this object holds it from here on)
         self.heads, self.evec, statics = net.field_weights(b['field_data'], b['forecast_h'], meta_out=self.meta_out)
         if self.lead_batch:
             from ..point_path import pde_losses_batch

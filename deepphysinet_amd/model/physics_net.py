@@ -47,16 +47,22 @@ class PhysicsNet(nn.Module):
         return (field_x.data_ptr(), field_x._version, forecast_h.data_ptr(), forecast_h._version, torch.is_grad_enabled(), pv,
                 grad_arena.param_epoch[0], replayed)
 
-    def encode_field(self, field_x, forecast_h, use_cache=False):
+    def encode_field(self, field_x, forecast_h, use_cache=False, keep_embedding=False):
         """MetaNet output [1,287,256].  With use_cache the result is reused while (field, lead time, parameters) are unchanged
         inside one training step (the reference recomputes it three times per step with identical inputs).  A cached output carries the
-        autograd graph of the call that made it: it serves ONE backward pass (step-scoped; training_step clears it)."""
+        autograd graph of the call that made it: it serves ONE backward pass (step-scoped; training_step clears it).
+        keep_embedding: the fused encoder also leaves the data embedding's output in `meta_net.model.last_embedding` (where a staged backward
+        cuts between the encoder stack and the embedding).  Only on request: the tensor keeps that call's autograd graph alive, and a graph
+        that outlives its step pins the AccumulateGrad nodes of the parameters to the stream it ran on (a later hipGraph capture on another
+        stream then pulls that stream into the capture: the runtime dies in hipStreamEndCapture -- found with tools/soak.py)."""
         key = self._cache_key(field_x, forecast_h) if use_cache else None
         if use_cache and self._meta_cache is not None and self._meta_cache[0] == key:
             return self._meta_cache[1]
         # the encoder's prep launch also evaluates the VariableNets' lead-time encoding (one launch instead of two; field_weights picks it up)
         object.__setattr__(self.meta_net.model, 'extra_lead_freqs', self.U_net.pe_fore_h.freq_bands)
+        object.__setattr__(self.meta_net.model, 'keep_last_embedding', bool(keep_embedding))
         val = self.meta_net(field_x, forecast_h)
+        object.__setattr__(self.meta_net.model, 'keep_last_embedding', False)
         if use_cache:
             self._meta_cache = (key, val)
         return val

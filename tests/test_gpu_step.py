@@ -424,6 +424,39 @@ def test_fused_optimizer_refuses_reallocated_parameters_and_delayed_backward():
         opt.step()
 
 
+def test_plain_backward_without_an_optimiser_captures_into_a_graph_after_eager_steps_on_another_stream():
+    """Round 4 (found by tools/soak.py): the fused encoder used to leave the data embedding's output -- and with it the whole autograd graph of
+    the call -- on the module after EVERY forward.  The next forward then reused the parameters' AccumulateGrad nodes of that graph, which were
+    pinned to the stream of an earlier iteration; capturing the step on another stream pulled that stream into the capture and the runtime
+    died in hipStreamEndCapture.  reference shape: the plain loop of interface_physics.py:1016-1060 (forward, backward, no fused optimiser)."""
+    m = _model(seed=11)
+    g = _gpu(synthetic_inputs(256, tag='inter'))
+    params = list(m.physics_net.parameters())
+
+    def step():
+        m.physics_net.zero_grad(set_to_none=True)
+        loss = _loss(m, g)
+        loss.backward()
+        return loss.detach()
+    ref_loss = step().clone()
+    ref = [p.grad.detach().clone() for p in params]
+    assert getattr(m.physics_net.meta_net.model, 'last_embedding', None) is None      # nothing of the step's graph stays on the module
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step(); step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = step()
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_loss, ref_loss)
+        assert all(torch.equal(p.grad, r) for p, r in zip(params, ref))
+
+
 def test_encoder_cache_is_not_trusted_once_a_fused_step_lives_in_a_graph():
     """replays of a captured optimiser step rewrite the parameters without touching any host-side counter; from the capture on,
     encode_field(use_cache=True) recomputes outside a capture instead of serving a value from before the replays."""
