@@ -374,12 +374,12 @@ class _PdeLossBatchFn(torch.autograd.Function):
             ws = _Workspace(n, cfg.prec, dev)
             nets = _net_ptrs(hd_[b], ev_[b], st)
             out_n, jac_n = _forward_points(cfg, ws, nets, x_[b], y_[b], t_[b], None, cd_[b], want_jac=True, want_saved=need_grad)
-            L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_[b]), n, ctypes.byref(geo), ctypes.byref(ph), None, None, _ptr(sums),
-                                     None, None, _stream()), 'dpn_residual')
+            # eager: the block sums of the losses AND d total_b / d (out, Jacobian) for a unit cotangent in ONE pass over the points
+            L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_[b]), n, ctypes.byref(geo), ctypes.byref(ph), None,
+                                     _ptr(one) if eager else None, _ptr(sums), _ptr(g_out) if eager else None, _ptr(g_jxi) if eager else None,
+                                     _stream()), 'dpn_residual')
             L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses7[b]), _stream()), 'dpn_residual_finish')
-            if eager:                                             # d total_b / d (this field's weights), unit cotangent
-                L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_[b]), n, ctypes.byref(geo), ctypes.byref(ph), None, _ptr(one), None,
-                                         _ptr(g_out), _ptr(g_jxi), _stream()), 'dpn_residual(grad)')
+            if eager:                                             # d total_b / d (this field's weights)
                 g_stat = [flat[b, starts[i]:starts[i + 1]].view(STATIC_SHAPES[i % 8]) for i in range(48)]
                 _backward_points(cfg, ws, nets, x_[b], y_[b], t_[b], None, cd_[b], g_out, g_jxi, st, into=(g_heads[b], g_evec[b], g_stat))
                 del ws, out_n, jac_n

@@ -8,7 +8,7 @@ for f in bench_bf16x2.json bench_bf16.json bench_bf16x2_per_gemm_encoder_of_roun
          cfg2_61leads_kernel_stats_bf16x2.txt phase_times_bf16x2.txt phase_times_bf16.txt phase_times_bf16x2_no_l2_helpers.txt \
          phase_times_bf16x2_per_gemm_encoder_of_round3.txt reference_shaped_step_bf16x2.json reference_shaped_step_bf16.json \
          kernel_trace_stats_bench_bf16x2.txt kernel_trace_stats_bench_bf16.txt step_timeline_bf16x2.txt step_timeline_bf16.txt \
-         pmc_eager_step_bf16x2.txt pmc_eager_step_bf16.txt microbench_kstep_asm.txt microbench_kstep_asm_clocks.txt point_kernel_clocks.txt; do
+         pmc_eager_step_bf16x2.txt pmc_eager_step_bf16.txt microbench_kstep_asm.txt microbench_kstep_asm_clocks.txt point_kernel_clocks.txt soak_bitwise.txt; do
   [ -f $S/$f ] && grep -v "amdgpu.ids\|AccumulateGrad\|run_backward" $S/$f > $D/round4_$f
 done
 for v in tl tlnostore tlnomfma tlnoaload tlnosincos; do

@@ -43,6 +43,7 @@ timeout 300 python tools/enc_timeline.py > $R/enc_timeline_with_l2_helpers.txt 2
 DPN_ENC_NO_HELPERS=1 timeout 300 python tools/enc_timeline.py > $R/enc_timeline_cold_l2.txt 2>&1
 DPN_ENC_NO_HELPERS=1 ENC_TL_WARM=1 timeout 300 python tools/enc_timeline.py > $R/enc_timeline_warm_l2.txt 2>&1
 timeout 300 python tools/wgrad16_bench.py > $R/wgrad16_bench.txt 2>&1
+( timeout 1200 python tools/soak.py bf16x2 300; timeout 900 python tools/soak.py bf16 300 ) 2>&1 | grep -v "amdgpu.ids\|AccumulateGrad\|run_backward" > $R/soak_bitwise.txt
 timeout 600 python tools/enc_batch_check.py 1 3 > $R/encoder_vs_fp64.txt 2>&1
 timeout 600 python tools/enc_batch_check.py 8 4 >> $R/encoder_vs_fp64.txt 2>&1
 timeout 900 python tools/enc_batch_check.py 61 4 >> $R/encoder_vs_fp64.txt 2>&1
