@@ -903,49 +903,64 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
     const float* xp = p.X + (xok ? xn * p.x_sn : 0);
     constexpr int kWgDepth = 4;                  // rows in flight: blocks of 32 (a dependent global round trip per block would be a chain of latencies)
     float gv[kWgDepth][8], xv[kWgDepth][8];
-    // Fast path ("rows are k" for both operands: the weight gradients): buffer loads -- one instruction per load (the lane's eight row
-    // offsets are computed once, the block's base is a scalar), and the descriptor ends behind the slice's last row, so rows beyond it
-    // and the columns of lanes outside the problem (offset 2^31 - 16) read as zero without any mask.  (The generic form spends ~6 VALU per
-    // load on 64-bit addresses and 2 per element on masks: ~500 VALU per 32-row block and wave against 12 MFMAs.)
-    const bool fast = p.g_sm == 1 && p.x_sn == 1 && (int64_t)p.rows * g_sk * 4 < (1ll << 31) && (int64_t)p.rows * x_sk * 4 < (1ll << 31);
-    __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, fast ? (int)((int64_t)r_end * g_sk * 4) : 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, fast ? (int)((int64_t)r_end * x_sk * 4) : 0, 0x00020000);
+    // Fast paths, chosen per operand: buffer loads -- one instruction per load, the block's base a scalar, and whatever lies outside the
+    // descriptor (lanes outside the problem: offset 2^31 - 16) reads as zero without a mask.
+    //   mode 1 "rows are k" (the weight gradients: element stride 1 along m / n): eight dword loads per block, the lane's eight row offsets
+    //          computed once; the descriptor ends behind the slice's last row, so rows beyond it are zero too.
+    //   mode 2 "k is contiguous" (x W^T: the token convolution, the hyper-network heads): the lane's eight k-values are 32 contiguous bytes
+    //          = two 16-byte loads (dword-aligned rows: K = 7 215 does not make them 16-byte aligned, buffer loads do not ask for it); the
+    //          k-tail of the last block is zeroed when the block is consumed.
+    //   mode 0 generic strides (~6 VALU per load on 64-bit addresses and 2 per element on masks: ~500 VALU per 32-row block and wave
+    //          against 12 MFMAs).
+    const int g_mode = (p.g_sm == 1 && (int64_t)p.rows * g_sk * 4 < (1ll << 31)) ? 1 : (g_sk == 1 && (int64_t)p.M * p.g_sm * 4 < (1ll << 31)) ? 2 : 0;
+    const int x_mode = (p.x_sn == 1 && (int64_t)p.rows * x_sk * 4 < (1ll << 31)) ? 1 : (x_sk == 1 && (int64_t)p.N * p.x_sn * 4 < (1ll << 31)) ? 2 : 0;
+    __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0,
+        g_mode == 1 ? (int)((int64_t)r_end * g_sk * 4) : g_mode == 2 ? (int)((int64_t)p.M * p.g_sm * 4) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0,
+        x_mode == 1 ? (int)((int64_t)r_end * x_sk * 4) : x_mode == 2 ? (int)((int64_t)p.N * p.x_sn * 4) : 0, 0x00020000);
     int gvo[8], xvo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        gvo[e] = gok ? (int)(((g * 8 + e) * g_sk + gm) * 4) : 0x7ffffff0;
-        xvo[e] = xok ? (int)(((g * 8 + e) * x_sk + xn) * 4) : 0x7ffffff0;
+        gvo[e] = !gok ? 0x7ffffff0 : g_mode == 2 ? (int)((gm * p.g_sm + g * 8) * 4) + 16 * (e & 1) : (int)(((g * 8 + e) * g_sk + gm) * 4);
+        xvo[e] = !xok ? 0x7ffffff0 : x_mode == 2 ? (int)((xn * p.x_sn + g * 8) * 4) + 16 * (e & 1) : (int)(((g * 8 + e) * x_sk + xn) * 4);
     }
-    auto fetch = [&](int ks, float (&gd)[8], float (&xd)[8]) __attribute__((always_inline)) {
-        if (fast) {
-            const int gso = (int)((r_begin + ks * 32) * g_sk * 4), xso = (int)((r_begin + ks * 32) * x_sk * 4);
+    auto fetch1 = [&](const int mode, const __amdgpu_buffer_rsrc_t rs, const int (&vo)[8], const int64_t sk, const float* base, const int ks,
+                      float (&d)[8]) __attribute__((always_inline)) {
+        if (mode == 1) {
+            const int so = (int)((r_begin + ks * 32) * sk * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[e], so, 0));
+        } else if (mode == 2) {
+            const int so = (r_begin + ks * 32) * 4;
+            const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[0], so, 0));
+            const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[1], so, 0));
+            d[0] = lo[0]; d[1] = lo[1]; d[2] = lo[2]; d[3] = lo[3]; d[4] = hi[0]; d[5] = hi[1]; d[6] = hi[2]; d[7] = hi[3];
+        } else {
+            // generic strides: unconditional loads from a clamped row, landing in the ring untouched; rows / columns outside the problem are
+            // zeroed by a multiplication when the block is CONSUMED.  (A select makes the compiler sink every load into a branch of its own,
+            // and a mask applied at fetch time puts an s_waitcnt vmcnt(0) in front of every barrier: both measured at ~1.5 us per block.)
+            const int r0 = r_begin + ks * 32 + g * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                gd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gvo[e], gso, 0));
-                xd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xvo[e], xso, 0));
+                const int64_t r = r0 + e < r_end ? r0 + e : r_begin;
+                d[e] = base[r * sk];
             }
-            return;
-        }
-        // generic strides: unconditional loads from a clamped row, landing in the ring untouched; rows / columns outside the problem are
-        // zeroed by a multiplication when the block is CONSUMED.  (A select makes the compiler sink every load into a branch of its own,
-        // and a mask applied at fetch time puts an s_waitcnt vmcnt(0) in front of every barrier: both measured at ~1.5 us per block.)
-        const int r0 = r_begin + ks * 32 + g * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t r = r0 + e < r_end ? r0 + e : r_begin;
-            gd[e] = gp[r * g_sk];
-            xd[e] = xp[r * x_sk];
         }
     };
-    auto mask_rows = [&](int ks, float (&gd)[8], float (&xd)[8]) __attribute__((always_inline)) {
-        if (fast) return;
+    auto fetch = [&](int ks, float (&gd)[8], float (&xd)[8]) __attribute__((always_inline)) {
+        fetch1(g_mode, grs, gvo, g_sk, gp, ks, gd);
+        fetch1(x_mode, xrs, xvo, x_sk, xp, ks, xd);
+    };
+    auto mask1 = [&](const int mode, const bool ok, const int ks, float (&d)[8]) __attribute__((always_inline)) {
+        if (mode == 1) return;
         const int r0 = r_begin + ks * 32 + g * 8;
+        if (mode == 2 && r0 + 8 <= r_end) return;                            // (only the k-tail of the last block; wave-divergent at most there)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool rok = r0 + e < r_end;
-            gd[e] *= (rok && gok) ? 1.f : 0.f;
-            xd[e] *= (rok && xok) ? 1.f : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) d[e] *= (r0 + e < r_end && ok) ? 1.f : 0.f;
+    };
+    auto mask_rows = [&](int ks, float (&gd)[8], float (&xd)[8]) __attribute__((always_inline)) {
+        mask1(g_mode, gok, ks, gd);
+        mask1(x_mode, xok, ks, xd);
     };
     f32x4 am[4], ac[4];
 #pragma unroll

@@ -295,11 +295,14 @@ class _DataEmbeddingFn(torch.autograd.Function):
             _launch(problems)
             n_parts = len(bounds)
         else:
-            # (measured experiment, DPN_EMBED_GEMM16=1: the same product on the f16 hi+lo MFMA GEMM dpn_gemm16, K cut into 38 slices: 31.6 us
-            # + a slower assemble -- with k contiguous the kernel's dword loads touch 64 cache lines per instruction -- and the tile-level scales
-            # make a field's result depend on its batch neighbours at the 1e-7 level; not the product path)
+            # (measured experiment, DPN_EMBED_GEMM16=1: the same product on the f16 hi+lo MFMA GEMM dpn_gemm16.  With the kernel's
+            # "k is contiguous" load path (two 16-byte buffer loads per operand and block) 17 us at 38 K-slices + 11.6 us assemble, 20.6 + 6.4 us
+            # at 16 (DPN_EMBED_PARTS) against 23.7 + 6.2 us for the exact-fp32 split-K launch: the kernel spends ~2 300 cycles per 32-k block on
+            # scales and splits for 12 MFMAs, and the tile-level scales make a field's result depend on its batch neighbours at the 1e-7
+            # level; not the product path.  What would pay is operands split ONCE -- by dpn_enc_prep, per-row scales -- and a load-only
+            # kernel; at 64 x 64 tiles that GEMM moves 74 MB through L2 for 1 GFLOP.)
             tiles = ((B * T + 63) // 64) * ((D + 63) // 64)
-            n_parts = max(1, min(38, 456 // tiles))
+            n_parts = int(os.environ.get('DPN_EMBED_PARTS', '0')) or max(1, min(38, 456 // tiles))
             q = L.DpnGemm16Problem()
             emb_parts = torch.empty((n_parts, B * T, D), dtype=torch.float32, device=dev)
             q.A, q.B, q.C, q.M, q.N, q.K, q.ldc = _p(xu), _p(w2), _p(emb_parts), B * T, D, K3, D
