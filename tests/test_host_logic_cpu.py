@@ -282,3 +282,27 @@ def test_staged_data_parallel_step_is_only_taken_with_the_matching_optimiser_lay
     assert "getattr(grad_sync, 'opt', None) is optimizer" in src and 'layout_ids' in src and 'requires_grad' in src
     from deepphysinet_amd import optim
     assert 'self.layout_ids' in inspect.getsource(optim.FusedClipAdam.__init__)
+
+
+def test_bench_power_sampling_degrades_to_none_without_rocm_smi(monkeypatch, tmp_path):
+    """bench.py's clock / socket power samples (rocm-smi) are an extra: without the tool, or when it prints nothing usable, the fields are
+    null and the bench line is printed all the same."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import shutil
+    calls = []
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+    monkeypatch.setattr(shutil, 'which', lambda name: None)
+    real_exists = os.path.exists
+    monkeypatch.setattr(os.path, 'exists', lambda p: False if str(p).endswith('rocm-smi') else real_exists(p))
+    assert bench.sample_power(lambda: calls.append(1), seconds=0.05) is None and not calls      # no tool: the work is not even started
+    fake = tmp_path / 'rocm-smi'
+    fake.write_text('#!/bin/sh\necho "not json"\n')
+    fake.chmod(0o755)
+    monkeypatch.setattr(shutil, 'which', lambda name: str(fake))
+    monkeypatch.setattr(os.path, 'exists', real_exists)
+    assert bench.sample_power(lambda: calls.append(1), seconds=0.2) is None and calls            # garbage output: no samples, no exception
+    fake.write_text('#!/bin/sh\necho \'{"card0": {"sclk clock speed:": "(1977Mhz)", "Current Socket Graphics Package Power (W)": "1395.0"}}\'\n')
+    out = bench.sample_power(lambda: calls.append(1), seconds=0.5)
+    assert out is not None and out['sclk_mhz'] == 1977.0 and out['socket_w'] == 1395.0 and out['samples'] >= 1
