@@ -132,6 +132,9 @@ EXPORTS = {
     'dpn_gemm16_partial_floats': (c_int64, [c_int, c_void_p, c_int]),
     'dpn_gemm16': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'dpn_enc_prep': (c_int, [POINTER(DpnEncPrep), c_void_p]),
+    'dpn_conv16_kp': (c_int64, [c_int]),
+    'dpn_conv16_split': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_conv16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dpn_enc_fwd': (c_int, [POINTER(DpnEncFwd), c_void_p]),
     'dpn_enc_bwd': (c_int, [POINTER(DpnEncBwd), c_void_p]),
     'dpn_add_ln_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -810,6 +810,60 @@ struct PrepArgs {
     const float* x; int T, C; int64_t col_total; float* xu;
     const float* h; int batch; const float* fa; int na; float* oa; const float* fb; int nb; float* ob;
 };
+struct ConvSplitArgs {                           // dpn_conv16's operand images: one block per im2col row / per weight row
+    const float* x; int T, C, batch; const float* conv_w;
+    int xs_blocks, ws_blocks, Kp;
+    _Float16 *xs, *ws; int *xe, *we;
+};
+// one row of K values -> power-of-two scale (row maximum into [8, 16)), f16 hi / lo fragment slots of Kp values (zeros behind K), the biased
+// exponent.  ONE pass over memory: a thread's values (k = tid + 256 u: coalesced loads, all in flight at once) stay in registers between the
+// maximum and the split; the f16 halves pass through LDS so that the stores are whole 16-byte fragment slots (2-byte stores straight from the
+// registers: 58 store instructions per thread, each touching eight lines -- the launch took 20 us instead of 9).
+// Layout = MFMA-fragment images, as the encoder's weight images: per (16-row strip, 32-k block) 2 KB = [hi | lo][lane = (k % 32) / 8 * 16 +
+// row % 16][8 f16], so that a wave's fragment load is ONE contiguous KB.  (Row-major planes made every 16-byte piece of a load its own cache
+// line access -- 64 tag look-ups per instruction: the loads alone were 7 of the kernel's 15 us.)  `strip`: the strip's first element, c = row % 16.
+constexpr int kSplitIters = 29;                  // rows of up to 7 424 values (3 x 2 405 = 7 215)
+template <class Val>
+DEV void split_row_planes(const Val& val, const int K, const int Kp, _Float16* strip, const int c, int* e_out) {
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) _Float16 stage[2][kSplitIters * 256];
+    const int tid = threadIdx.x;
+    float v[kSplitIters];
+#pragma unroll
+    for (int u = 0; u < kSplitIters; ++u) {
+        const int k = tid + 256 * u;
+        v[u] = val(k < K ? k : K - 1);           // (clamped index: an unconditional load; the tail is zeroed below)
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < kSplitIters; ++u) {
+        v[u] = (tid + 256 * u < K) ? v[u] : 0.f;
+        m = fmaxf(m, fabsf(v[u]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
+    eb = eb < 4 ? 4 : eb;
+    const float sc = __builtin_bit_cast(float, (257 - eb) << 23);
+#pragma unroll
+    for (int u = 0; u < kSplitIters; ++u) {
+        const int k = tid + 256 * u;
+        const float x = v[u] * sc;
+        const _Float16 h_ = (_Float16)x;
+        stage[0][k] = h_;
+        stage[1][k] = (_Float16)((x - (float)h_) * kLoScale);
+    }
+    __syncthreads();
+    for (int j = tid; j * 8 < Kp; j += 256) {    // slot j = k / 8: block j / 4, k-group j % 4
+        _Float16* slot = strip + (j >> 2) * 1024 + ((j & 3) * 16 + c) * 8;
+        *reinterpret_cast<u32x4*>(slot) = *reinterpret_cast<const u32x4*>(&stage[0][j * 8]);
+        *reinterpret_cast<u32x4*>(slot + 512) = *reinterpret_cast<const u32x4*>(&stage[1][j * 8]);
+    }
+    if (tid == 0) *e_out = eb;
+}
 __global__ __launch_bounds__(256) void dpn_enc_prep_kernel(PrepArgs a) {
     int blk = blockIdx.x;
     if (blk < a.pack_blocks) { pack_body(a.pack, blk * 256 + threadIdx.x); return; }
@@ -832,6 +886,152 @@ __global__ __launch_bounds__(256) void dpn_enc_prep_kernel(PrepArgs a) {
     const float hv = a.h[b];
     if (j < a.na) { const float s_ = hv * a.fa[j]; a.oa[(int64_t)b * 2 * a.na + 2 * j] = sinf(s_); a.oa[(int64_t)b * 2 * a.na + 2 * j + 1] = cosf(s_); }
     else { const int jj = j - a.na; const float s_ = hv * a.fb[jj]; a.ob[(int64_t)b * 2 * a.nb + 2 * jj] = sinf(s_); a.ob[(int64_t)b * 2 * a.nb + 2 * jj + 1] = cosf(s_); }
+}
+
+// Experiment (DPN_CONV16=1): the token convolution's operands split once per step for dpn_conv16.  Its own launch: inside dpn_enc_prep the
+// 29 KB of LDS and the registers of split_row_planes slowed every other block range of that launch (encoder forward 183 -> 189 us).
+__global__ __launch_bounds__(256) void dpn_conv16_split_kernel(ConvSplitArgs a) {
+    int blk = blockIdx.x;
+    if (blk < a.xs_blocks) {                                                 // im2col row blk = (b, t) as planes: k = c * 3 + tap, as xu below
+        const int64_t b = blk / a.T;
+        const int t = blk - (int)b * a.T;
+        const float* xb = a.x + b * a.T * a.C;
+        const int T = a.T, C = a.C;
+        auto val = [&](const int k) __attribute__((always_inline)) {
+            const int c = k / 3, tap = k - 3 * c;
+            int ts = t + tap - 1;
+            ts = ts < 0 ? ts + T : (ts >= T ? ts - T : ts);
+            return xb[(int64_t)ts * C + c];
+        };
+        split_row_planes(val, 3 * C, a.Kp, a.xs + (int64_t)(blk >> 4) * 32 * a.Kp, blk & 15, a.xe + blk);
+        return;
+    }
+    blk -= a.xs_blocks;
+    if (blk < a.ws_blocks) {                                                 // weight row blk
+        const float* wr = a.conv_w + (int64_t)blk * 3 * a.C;
+        auto val = [&](const int k) __attribute__((always_inline)) { return wr[k]; };
+        split_row_planes(val, 3 * a.C, a.Kp, a.ws + (int64_t)(blk >> 4) * 32 * a.Kp, blk & 15, a.we + blk);
+        return;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the token convolution as a GEMM on pre-split planes
+// parts[s][m][n] = sum_{k in slice s} x(m, k) w(n, k)  (model/embed.py:45-47: circular Conv1d(C, 256, 3) over the tokens = im2col rows times
+// the weight rows, K = 3 C = 7 215).  The operands were split ONCE by dpn_enc_prep (f16 hi / lo planes, one power-of-two scale per row), so the
+// loop is loads and MFMAs only.  A workgroup (4 waves) owns a 128 x 64 tile of one K-slice; wave w owns rows 32 w .. 32 w + 31 (two A strips x
+// hi | lo: four 16-byte loads per 32-k block, private) against all four column tiles, whose B fragments (4 tiles x hi | lo) are staged through
+// LDS, two per wave and block, double-buffered with one LDS-only barrier per block: 24 MFMAs per wave and block for 8 KB of LDS reads (a
+// 16 x 128 wave tile does the same MFMAs for 16 KB and measured 2 600 cycles per block: the LDS reads of eight waves, not the MFMAs).
+// Straight-line code for the slice's blocks (behind a loop's back edge hipcc waits for every load in flight), loads four blocks ahead.
+constexpr int kConvBlocks = 16;                 // 32-k blocks per K-slice at most (blocks behind the slice's end multiply zeros)
+struct Conv16Args { const _Float16 *xs, *ws; const int *xe, *we; int M, N, Kp, blocks_per_slice, slices, tn, tm; float* parts; };
+__global__ __launch_bounds__(256) void dpn_conv16_kernel(Conv16Args a) {
+    __shared__ __attribute__((aligned(16))) char bf[2][8][1024];             // [buffer][column tile * 2 + plane][lane x 16 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (K-slice, tile): all tiles of a slice on ONE XCD (block b runs on XCD b % 8 -- observed placement, used for speed only), so
+    // that the slice's 1 MB of planes is fetched into that XCD's L2 once and the 4 x / 3 x re-reads of the tiles hit there (spread over the
+    // XCDs the launch moved 74 MB through the fabric: 21 -> 15 us with the tile change alone)
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3, tiles = a.tn * a.tm;
+    const int sl = xcd + 8 * (jj / tiles), tile = jj % tiles;
+    if (sl >= a.slices) return;
+    const int n0 = (tile % a.tn) * 64, m0 = (tile / a.tn) * 128;
+    const int total = a.Kp / 32, kb0 = sl * a.blocks_per_slice;
+    const int nb = min(total - kb0, a.blocks_per_slice);
+    const int c = lane & 15, g = lane >> 4;
+    const int row0 = m0 + wave * 32 + c, col = n0 + wave * 16 + c;           // this lane's A rows (row0, row0 + 16), and the column it stages (tile `wave`)
+    // fragment images (dpn_enc_prep): per (16-row strip, 32-k block) 2 KB = [hi | lo][lane][16 B]; a strip holds Kp / 32 blocks
+    const int nblk = a.Kp / 32;
+    const int64_t xbytes = (int64_t)((a.M + 15) / 16) * nblk * 2048, wbytes = (int64_t)((a.N + 15) / 16) * nblk * 2048;
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.xs), 0, (int)xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.ws), 0, (int)wbytes, 0x00020000);
+    // (strips outside the problem: an offset behind the descriptor reads as zero; rows of a partial last strip hold whatever the buffer held:
+    // they only reach output rows that are not stored)
+    int xvo[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int strip = (m0 >> 4) + wave * 2 + r;
+        xvo[r] = strip * 16 < a.M ? (int)((int64_t)strip * nblk * 2048) + lane * 16 : 0x7ffff000;
+    }
+    const int wstrip = (n0 >> 4) + wave;
+    const int wvo = wstrip * 16 < a.N ? (int)((int64_t)wstrip * nblk * 2048) + lane * 16 : 0x7ffff000;
+    constexpr int D = 6;                         // blocks in flight: the planes were written a launch ago by other XCDs, the first touch is a memory round trip
+    u32x4 ah[D][2], al[D][2], bh[D], bl[D];
+    // (every block issues exactly six loads, blocks behind the slice's end from an offset behind the descriptor = zeros: with loads under
+    // conditions hipcc cannot count them and waits for ALL of them at every block -- one memory round trip per block)
+    auto fetch = [&](const int i, const int s_) __attribute__((always_inline)) {
+        const int so = i < nb ? (kb0 + i) * 2048 : 0x7ffff000;               // one block of a strip: 2 KB [hi | lo]
+#ifdef CONV_ABL_NOLOAD                           // (ablation builds, wrong results on purpose: tools/variant_build.py --unit=5)
+        if (i >= 0) return;
+#endif
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            ah[s_][r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[r], so, 0));
+            al[s_][r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[r] + 1024, so, 0));
+        }
+        bh[s_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0));
+        bl[s_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo + 1024, so, 0));
+    };
+    f32x4 am[2][4], ac[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { am[r][t] = (f32x4)0.f; ac[r][t] = (f32x4)0.f; }
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d, d);
+#pragma unroll
+    for (int i = 0; i < kConvBlocks; ++i) {
+        const int d = i % D, buf = i & 1;
+        u32x4 bq[8];                                                         // all eight B fragments first, into registers of their own
+#ifdef CONV_ABL_NOLDS
+#pragma unroll
+        for (int f = 0; f < 8; ++f) bq[f] = (f & 1) ? bl[d] : bh[d];
+#else
+        *reinterpret_cast<u32x4*>(&bf[buf][2 * wave][lane * 16]) = bh[d];
+        *reinterpret_cast<u32x4*>(&bf[buf][2 * wave + 1][lane * 16]) = bl[d];
+        barrier_lds();                                                       // (LDS only: the blocks in flight stay in flight)
+#pragma unroll
+        for (int f = 0; f < 8; ++f) bq[f] = *reinterpret_cast<const u32x4*>(&bf[buf][f][lane * 16]);
+#endif
+#ifdef CONV_ABL_NOMFMA
+#pragma unroll
+        for (int f = 0; f < 8; ++f) asm volatile("" ::"v"(bq[f]));
+        asm volatile("" ::"v"(ah[d][0]), "v"(ah[d][1]), "v"(al[d][0]), "v"(al[d][1]));
+        if (i + D < kConvBlocks) fetch(i + D, d);
+        continue;
+#endif
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) am[r][t] = mfma(ah[d][r], bq[2 * t], am[r][t]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ac[r][t] = mfma(ah[d][r], bq[2 * t + 1], ac[r][t]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ac[r][t] = mfma(al[d][r], bq[2 * t], ac[r][t]);
+        if (i + D < kConvBlocks) fetch(i + D, d);                            // refill the slot this block just used
+        // (double buffer: block i + 1 writes the other buffer; its barrier orders block i + 2's writes behind this block's reads)
+    }
+    float* out = a.parts + (int64_t)sl * a.M * a.N;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int er[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int rr = m0 + wave * 32 + 16 * r + g * 4 + j; er[j] = rr < a.M ? a.xe[rr] : 130; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cc = n0 + t * 16 + c;
+            if (cc >= a.N) continue;
+            const int ec = a.we[cc];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = m0 + wave * 32 + 16 * r + g * 4 + j;
+                if (rr < a.M) out[(int64_t)rr * a.N + cc] = __builtin_ldexpf(fmaf(ac[r][t][j], kLoInv, am[r][t][j]), er[j] + ec - 260);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients
@@ -1364,6 +1564,34 @@ int dpn_enc_prep(const DpnEncPrep* p, void* stream) {
     const int blocks = a.pack_blocks + a.col_blocks + pe_blocks;
     if (blocks <= 0) return -1;
     hipLaunchKernelGGL(dpn_enc_prep_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int64_t dpn_conv16_kp(int K) { return K <= 0 ? 0 : ((int64_t)K + 31) / 32 * 32; }
+
+int dpn_conv16_split(const float* x, int T, int C, int batch, const float* conv_w, int conv_n, void* xs, int32_t* xe, void* ws, int32_t* we, void* stream) {
+    if (!x || !conv_w || !xs || !xe || !ws || !we || T <= 0 || C <= 0 || batch <= 0 || conv_n <= 0) return -1;
+    ConvSplitArgs a{};
+    a.x = x; a.T = T; a.C = C; a.batch = batch; a.conv_w = conv_w;
+    a.Kp = (int)dpn_conv16_kp(3 * C);
+    if (a.Kp > kSplitIters * 256) return -1;
+    if (((int64_t)batch * T + 15) / 16 * 16 * a.Kp * 4 >= 0x7ffff000ll) return -1;      // (the images are addressed through one 2 GB buffer descriptor)
+    a.xs_blocks = batch * T; a.ws_blocks = conv_n;
+    a.xs = static_cast<_Float16*>(xs); a.ws = static_cast<_Float16*>(ws); a.xe = xe; a.we = we;
+    hipLaunchKernelGGL(dpn_conv16_split_kernel, dim3(a.xs_blocks + a.ws_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+int dpn_conv16(const void* xs, const int32_t* xe, const void* ws, const int32_t* we, int M, int N, int Kp, int slices, float* parts, void* stream) {
+    if (!xs || !xe || !ws || !we || !parts || M <= 0 || N <= 0 || Kp <= 0 || (Kp & 31) || slices <= 0) return -1;
+    if ((int64_t)(M + 15) / 16 * 16 * Kp * 4 >= 0x7ffff000ll || (int64_t)(N + 15) / 16 * 16 * Kp * 4 >= 0x7ffff000ll) return -1;
+    const int total = Kp / 32, per = (total + slices - 1) / slices;
+    if ((int64_t)(slices - 1) * per >= total || per > kConvBlocks) return -1;    // every slice owns at least one block, at most kConvBlocks
+    const int tn = (N + 63) / 64, tm = (M + 127) / 128;
+    Conv16Args a{static_cast<const _Float16*>(xs), static_cast<const _Float16*>(ws), xe, we, M, N, Kp, per, slices, tn, tm, parts};
+    const int64_t grid = 8ll * ((slices + 7) / 8) * tn * tm;                      // 8 XCD lanes x (slices per XCD) x tiles
+    if (grid > 0x7fffffff) return -1;
+    hipLaunchKernelGGL(dpn_conv16_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

@@ -281,7 +281,14 @@ class _DataEmbeddingFn(torch.autograd.Function):
             L.check(lib.dpn_im2col_circ3(_p(x), T, C, B, _p(xu), _s()), 'dpn_im2col_circ3')
         w2 = _c(conv_w).view(D, 3 * C)
         K3 = 3 * C
-        if os.environ.get('DPN_EMBED_GEMM16') != '1':
+        c16 = getattr(share, 'conv16', None) if share is not None else None
+        if c16 is not None and c16[5].data_ptr() == w2.data_ptr():
+            # emb = xu . w2^T on the planes dpn_enc_prep split (f16 hi+lo MFMA, per-row scales): sixteen K-slices, added in order by the assemble
+            xs, xe, ws, we, Kp, _ = c16
+            n_parts = 16
+            emb_parts = torch.empty((n_parts, B * T, D), dtype=torch.float32, device=dev)
+            L.check(lib.dpn_conv16(_p(xs), _p(xe), _p(ws), _p(we), B * T, D, Kp, n_parts, _p(emb_parts), _s()), 'dpn_conv16')
+        elif os.environ.get('DPN_EMBED_GEMM16') != '1':
             # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one exact-fp32 MFMA launch (24 us)
             parts = 16
             ks = (K3 + parts - 1) // parts
@@ -826,7 +833,7 @@ def _stack_fits(layers, norm, projection):
 
 class EncoderPrep:
     """dpn_enc_prep's outputs for one forward of the whole encoder: weight images, im2col rows, lead-time encodings."""
-    __slots__ = ('wpack', 'xu', 'te', 'pe_extra', 'embed')
+    __slots__ = ('wpack', 'xu', 'te', 'pe_extra', 'embed', 'conv16')
 
 
 def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
@@ -851,6 +858,7 @@ def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
     q.n_mats, q.weights, q.packed, q.status_dev = len(mats), ctypes.cast(arr, ctypes.c_void_p), _p(out.wpack), _p(enc_status(dev))
     q.x, q.T, q.C, q.batch, q.xu = _p(x), T, C, B, _p(out.xu)
     q.h, q.freqs_a, q.n_a, q.out_a = _p(hh), _p(fa), fa.numel(), _p(te)
+    out.conv16 = None
     out.pe_extra = None
     if extra_freqs is not None:
         fb = _c(extra_freqs)
@@ -858,6 +866,19 @@ def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
         q.freqs_b, q.n_b, q.out_b = _p(fb), fb.numel(), _p(out.pe_extra)
     L.check(lib.dpn_enc_prep(ctypes.byref(q), _s()), 'dpn_enc_prep')
     out.te = te.view(-1) if B == 1 else te
+    conv = emb_module.value_embedding.tokenConv
+    if os.environ.get('DPN_CONV16') == '1' and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and tuple(conv.weight.shape[1:]) == (C, 3):
+        # EXPERIMENT: the token convolution's operands split into f16 hi / lo fragment images with one power-of-two scale per row (dpn_conv16).
+        # Measured: the GEMM 23.7 -> 11.2 us, the split 12-16 us -- no gain; not the product path.
+        Kp, n_out = int(lib.dpn_conv16_kp(3 * C)), conv.weight.shape[0]
+        if (B * T + 16) * Kp * 4 < 2 ** 31 - 8192 and Kp <= 29 * 256:
+            xs = torch.empty(((B * T + 15) // 16 * 16, 2 * Kp), dtype=torch.float16, device=dev)      # fragment images: 16-row strips x (Kp / 32) blocks x 2 KB
+            ws = torch.empty(((n_out + 15) // 16 * 16, 2 * Kp), dtype=torch.float16, device=dev)
+            xe = torch.empty(B * T, dtype=torch.int32, device=dev)
+            we = torch.empty(n_out, dtype=torch.int32, device=dev)
+            cw = _c(conv.weight.detach())
+            L.check(lib.dpn_conv16_split(_p(x), T, C, B, _p(cw), n_out, _p(xs), _p(xe), _p(ws), _p(we), _s()), 'dpn_conv16_split')
+            out.conv16 = (xs, xe, ws, we, Kp, cw)
     return out
 
 

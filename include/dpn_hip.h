@@ -228,6 +228,19 @@ typedef struct DpnEncPrep {
 } DpnEncPrep;
 int dpn_enc_prep(const DpnEncPrep* p, void* stream);
 
+/* EXPERIMENT (DPN_CONV16=1): the token convolution (model/embed.py:45-47) on f16 hi+lo MFMA with operands split once per step.
+ * dpn_conv16_split: each im2col row (of x [batch*T][C], circular, as dpn_im2col_circ3) and each weight row [conv_n][3C] scaled by a power of two
+ * (row maximum into [8, 16): biased exponents in xe / we) and written as f16 hi and lo MFMA-fragment images: per (16-row strip, 32-k block)
+ * 2 KB = [hi | lo][lane = (k % 32) / 8 * 16 + row % 16][8 f16]; xs holds ceil(batch*T / 16) strips, ws ceil(conv_n / 16), each of Kp / 32 blocks,
+ * Kp = dpn_conv16_kp(3C) (zero-filled behind 3C). */
+int dpn_conv16_split(const float* x, int T, int C, int batch, const float* conv_w, int conv_n, void* xs, int32_t* xe, void* ws, int32_t* we, void* stream);
+/* dpn_conv16, the GEMM on those images: parts[s][m][n] = sum over the s-th K-slice of x(m, k) w(n, k), fp32,
+ * scales undone (M = batch*T rows, N = conv_n, `slices` K-slices of whole 32-k blocks, at most 16 blocks each; dpn_embed_assemble adds the
+ * slices in order).  f16 hi+lo,
+ * three products, fp32 accumulate (fp32-class); a row's scale depends on that row only, so a field's result does not depend on its batch. */
+int64_t dpn_conv16_kp(int K);
+int dpn_conv16(const void* xs, const int32_t* xe, const void* ws, const int32_t* we, int M, int N, int Kp, int slices, float* parts, void* stream);
+
 /* Forward.  tail = 1:  x1 = norm1(x + o Wo^T + bo);  pre = x1 Wc1^T + bc1;  act = gelu(pre);  x2 = norm2(x1 + act Wc2^T + bc2)
  *                      (o = the attention output, x = the layer input; x1, xhat1, rstd1, pre, act, x2, xhat2, rstd2 are written);
  *           next = 1:  y0, y1, y2 = t Wn0^T + bn0, ...   the NEXT layer's q / k / v projections of t = x2 (tail = 1) or t = xin (tail = 0);
