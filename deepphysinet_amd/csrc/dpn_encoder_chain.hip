@@ -1072,15 +1072,24 @@ DEV float wave_absmax_uniform(float m) {         // maximum over the 64 lanes as
 }
 DEV int exp_bits(float m) { const int e = (__builtin_bit_cast(int, m) >> 23) & 0xff; return e < 13 ? 13 : e; }
 
-__global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
-    __shared__ __attribute__((aligned(16))) char xf[2][4][2][1024];          // [buffer][n-tile][hi | lo][lane x 16 B]
-    __shared__ int xe[2][4];
+// Tile: kWgWaves waves, each a 16-column strip of G against ALL kWgWaves 16-column tiles of X: a lane splits 16 values per block for
+// 3 kWgWaves MFMAs.  Four waves (64 x 64): ~150 VALU per 12 MFMAs.  Eight waves (128 x 128, -DDPN_WG_WAVES=8) halve the split work per MFMA
+// and were measured SLOWER -- 27.5 against 23.1 us for the 25 problems of 287 rows (tools/wgrad16_bench.py) -- each wave then reads 16 KB of
+// LDS per block for 24 MFMAs (the bound dpn_conv16 met with the same wave tile).
+#ifndef DPN_WG_WAVES
+#define DPN_WG_WAVES 4
+#endif
+constexpr int kWgWaves = DPN_WG_WAVES, kWgTile = 16 * kWgWaves;
+__global__ __launch_bounds__(64 * kWgWaves) void dpn_wgrad16_kernel(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) char xf[2][kWgWaves][2][1024];   // [buffer][n-tile][hi | lo][lane x 16 B]
+    __shared__ int xe[2][kWgWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int z = blockIdx.z;
     if (z >= a.n * a.slices) {                   // ride-along job: LayerNorm parameter sums (fixed order over the row blocks)
         if (blockIdx.x || blockIdx.y) return;
         const WgJob& j = a.job[z - a.n * a.slices];
         float s1 = 0.f, s2 = 0.f;
+        if (tid >= 256) return;
 #pragma unroll 8
         for (int b = 0; b < j.nblocks; ++b) { s1 += j.partial[(int64_t)b * 512 + tid]; s2 += j.partial[(int64_t)b * 512 + 256 + tid]; }
         j.out_a[tid] = s1;
@@ -1089,7 +1098,7 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
     }
     const int pi = z / a.slices, sl = z - pi * a.slices;
     const WgProblem& p = a.p[pi];
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * kWgTile, n0 = blockIdx.x * kWgTile;
     if (m0 >= p.M || n0 >= p.N) return;
     const int r_begin = sl * a.rows_per_slice, r_end = min(p.rows, r_begin + a.rows_per_slice);
     const int nk = r_end > r_begin ? (r_end - r_begin + 31) / 32 : 0;
@@ -1162,10 +1171,10 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
         mask1(g_mode, gok, ks, gd);
         mask1(x_mode, xok, ks, xd);
     };
-    f32x4 am[4], ac[4];
+    f32x4 am[kWgWaves], ac[kWgWaves];
+    int eg_cur = 13, ex_mine = 13, ex_seen[kWgWaves];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { am[t] = (f32x4)0.f; ac[t] = (f32x4)0.f; }
-    int eg_cur = 13, ex_mine = 13, ex_seen[4] = {13, 13, 13, 13};
+    for (int t = 0; t < kWgWaves; ++t) { am[t] = (f32x4)0.f; ac[t] = (f32x4)0.f; ex_seen[t] = 13; }
     float bsum = 0.f;
     const bool want_b = blockIdx.x == 0 && p.db != nullptr;
 #pragma unroll
@@ -1186,7 +1195,7 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
             if (eg > eg_cur) {
                 const int dd = max(eg_cur - eg, -200);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < kWgWaves; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { am[t][j] = __builtin_ldexpf(am[t][j], dd); ac[t][j] = __builtin_ldexpf(ac[t][j], dd); }
                 eg_cur = eg;
@@ -1204,7 +1213,7 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
             if (ks + kWgDepth < nk) fetch(ks + kWgDepth, gv[d], xv[d]);      // refill the slot: kWgDepth blocks ahead
             barrier_lds();                                                   // (LDS only: a __syncthreads() would drain the rows in flight)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < kWgWaves; ++t) {
                 const int et = xe[buf][t];
                 if (et > ex_seen[t]) {
                     const int dd = max(ex_seen[t] - et, -200);
@@ -1227,7 +1236,7 @@ __global__ __launch_bounds__(256) void dpn_wgrad16_kernel(WgArgs a) {
     float* out = direct ? p.dW : a.partials + p.part_off + (int64_t)sl * ((int64_t)p.M * p.N + (p.db ? p.M : 0));
     const int ldo = direct ? p.ldw : p.N;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < kWgWaves; ++t) {
         const int sh = eg_cur + ex_seen[t] - 280;                            // (eg - 140) + (ex - 140)
         const int col = n0 + t * 16 + c;
 #pragma unroll
@@ -1488,8 +1497,8 @@ static int gemm16_launch(int n, const DpnGemm16Problem* problems, int n_jobs, co
         const int64_t per = (int64_t)q.M * q.N + (q.asum ? q.M : 0);
         off += (int64_t)slices * per;
         per_max = per_max > per ? per_max : per;
-        gx = gx > (q.N + 63) / 64 ? gx : (q.N + 63) / 64;
-        gy = gy > (q.M + 63) / 64 ? gy : (q.M + 63) / 64;
+        gx = gx > (q.N + kWgTile - 1) / kWgTile ? gx : (q.N + kWgTile - 1) / kWgTile;
+        gy = gy > (q.M + kWgTile - 1) / kWgTile ? gy : (q.M + kWgTile - 1) / kWgTile;
         max_k = max_k > q.K ? max_k : q.K;
     }
     a.rows_per_slice = ((max_k + slices - 1) / slices + 31) / 32 * 32;
@@ -1498,7 +1507,7 @@ static int gemm16_launch(int n, const DpnGemm16Problem* problems, int n_jobs, co
         a.job[i] = WgJob{jobs[i].partial, jobs[i].out_a, jobs[i].out_b, jobs[i].n_blocks, 0};
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(dpn_wgrad16_kernel, dim3(gx, gy, n * slices + n_jobs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dpn_wgrad16_kernel, dim3(gx, gy, n * slices + n_jobs), dim3(64 * kWgWaves), 0, s, a);
     if (slices > 1 && n > 0 && reduce)
         hipLaunchKernelGGL(dpn_wgrad16_reduce_kernel, dim3((unsigned)((per_max + 255) / 256), n), dim3(256), 0, s, a);
     return (int)hipGetLastError();
