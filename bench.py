@@ -36,7 +36,7 @@ import torch
 ALG_FLOP_FWD_JAC = 11_218_944          # algorithmic FLOP per collocation point, fwd + Jacobian
 ALG_FLOP_STEP = 31_887_360             # fwd + Jacobian + bwd
 EXEC_MAC_FWD = 409_600                 # MACs per point per net actually issued by dpn_fwd_kernel
-EXEC_MAC_BWD1 = 163_840                # backward stage 1: w1 Z0 (192 x 256) + w2 Z1 (256 x 256) + Wd G6 (192 x 256) per point per net
+EXEC_MAC_BWD1 = 49_152                 # backward stage 1: w1 Z0 (192 x 256) per point per net (round 5: the Z products are gone, csrc dpn_finish_gside_kernel)
 MFMA_PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12                      # HBM3E, MI355X_MICROARCH.md
 # HBM bytes per launch of the two roofline kernels come from the rocprofv3 PMC passes committed in profiles/ (bench.py cannot run PMC
@@ -168,6 +168,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
     ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi clock / socket power samples (about 5 s)')
+    ap.add_argument('--no-lead-probe', action='store_true', help='skip the 8-lead probe of the configs[2] code path (about 1 s of GPU work)')
     ap.add_argument('--encoder-fp8', nargs='?', const='1', default=None, choices=['1', 'mx'],
                     help='BASELINE configs[4]: the encoder layers\' forward GEMMs on fp8 (OCP e4m3) MFMA, bf16x2 Jacobian path; OFF by default -- it moves '
                          'the PDE losses by 1e-2 ... 2e-1 (tests/test_gpu_parity.py::test_config4_fp8_encoder_workload) and buys no time.  '
@@ -208,13 +209,17 @@ def main():
         return m, opt
 
     batch = synth_batch(args.points, dev, seed=1 + rank)
-    if args.leads > 1:                             # configs[2]: distinct field samples / lead times, one step
-        many = [synth_batch(args.points, dev, seed=1000 * (1 + rank) + b) for b in range(args.leads)]
-        lead = {k: torch.stack([m_[k].reshape(-1) for m_ in many]) for k in ('x', 'y', 't', 'f')}
-        lead['coord_data'] = torch.stack([m_['coord_data'] for m_ in many])
-        lead['field_data'] = torch.cat([m_['field_data'] for m_ in many], dim=0)
-        lead['forecast_h'] = torch.arange(args.leads, device=dev, dtype=torch.float32).mul_(24.0 / 360.0).view(-1, 1, 1)
-        del many
+    lead_batches = {}
+
+    def make_leads(n_leads):                       # configs[2]: distinct field samples / lead times, one step
+        many = [synth_batch(args.points, dev, seed=1000 * (1 + rank) + b) for b in range(n_leads)]
+        lb = {k: torch.stack([m_[k].reshape(-1) for m_ in many]) for k in ('x', 'y', 't', 'f')}
+        lb['coord_data'] = torch.stack([m_['coord_data'] for m_ in many])
+        lb['field_data'] = torch.cat([m_['field_data'] for m_ in many], dim=0)
+        lb['forecast_h'] = torch.arange(n_leads, device=dev, dtype=torch.float32).mul_(24.0 / 360.0).view(-1, 1, 1)
+        lead_batches[n_leads] = lb
+        return lb
+    lead = make_leads(args.leads) if args.leads > 1 else None
     crit = torch.nn.MSELoss()
     # N > 1 (or DPN_BENCH_SPLIT_STEP=1 on one GPU, to time the same code path): three graph segments with a bucket all-reduce behind each
     split_step = world > 1 or one_rank_rccl or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1'
@@ -222,7 +227,7 @@ def main():
     # RCCL group on the single-GPU test box, profiles/; the default keeps the collectives host-issued between four segment graphs)
     one_graph_collectives = os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') == '1' and split_step and (world > 1 or one_rank_rccl)
 
-    def make_step(m, opt):
+    def make_step(m, opt, n_leads):
         """One GPU: [whole] = zero_grad + place_one_batch + backward + clip + Adam, one callable (one hipGraph).
         N > 1: the StagedPdeStep segments (each its own hipGraph) with the bucket all-reduce queued behind each, then the optimiser."""
         lf = m.train_cfg['losses']['loss_factor']
@@ -230,9 +235,10 @@ def main():
 
         def whole():
             opt.zero_grad(set_to_none=True)
-            if args.leads > 1:
-                loss, _ = m.place_lead_batch(lead['x'], lead['y'], lead['t'], lead['f'], lead['field_data'], lead['coord_data'],
-                                             lead['forecast_h'], crit, lf)
+            if n_leads > 1:
+                lb = lead_batches[n_leads]
+                loss, _ = m.place_lead_batch(lb['x'], lb['y'], lb['t'], lb['f'], lb['field_data'], lb['coord_data'],
+                                             lb['forecast_h'], crit, lf)
             else:
                 loss = m.place_one_batch(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'],
                                          batch['forecast_h'], crit, lf, 0, 0, dev)
@@ -243,18 +249,32 @@ def main():
         if not split_step:
             return [whole], None
         from deepphysinet_amd.interface.interface_physics import StagedPdeStep
-        staged = StagedPdeStep(m, opt, lead if args.leads > 1 else batch, lf, lead_batch=args.leads > 1)
+        staged = StagedPdeStep(m, opt, lead_batches[n_leads] if n_leads > 1 else batch, lf, lead_batch=n_leads > 1)
         return list(staged.stages) + [opt.step], staged
 
-    def run(prec, steps, warmup, use_graph):
+    def run(prec, steps, warmup, use_graph, leads=None, blocks=10, steady=True):
+        """Build model + optimiser, capture the step, measure.  Protocol:
+          1. `first_block`: `warmup` untimed steps, then `steps` timed ones, straight after the capture -- what rounds 1-4 reported.  The GPU has
+             been idle through the capture; its clock ramps over the first tens of milliseconds, so a 20-step block is taken ON
+             the ramp.
+          2. pre-warm: the captured step replayed untimed until at least 0.5 s have passed AND two consecutive 20-replay blocks agree within 1 %
+             (at most 4 s): `prewarm_s`, `prewarm_replays`.
+          3. `blocks` timed blocks of `steps` replays each, every block bracketed by barrier + synchronize; per block the MAX over ranks;
+             `ms_per_step` = the median block / steps.
+        Returns a dict."""
         nonlocal sync
+        n_leads = args.leads if leads is None else leads
         m, opt = build(prec)
         if world > 1:
             D.broadcast_parameters(m.physics_net)      # DDP's wrap-time broadcast (the seeds already agree; this makes it a fact)
         sync = D.GradientAllReduce(opt, single_rank_too=one_rank_rccl) if (world > 1 or one_rank_rccl) else None
+        if dog is not None:
+            dog.sync = sync
+            dog.beat('model built')
         coll['gradient_buckets_mb'] = [round((b - a) * 4 / 2 ** 20, 2) for a, b in opt.bucket_bounds]
-        segments, staged = make_step(m, opt)
+        segments, staged = make_step(m, opt, n_leads)
         n_reduce = len(segments) - 1 if split_step else 0     # segment i completes the layout buckets staged.stage_buckets[i]; the last segment is the optimiser
+        rec = {'capture_error': None, 'step_form': None}
 
         def eager():
             for i, seg in enumerate(segments):
@@ -263,9 +283,70 @@ def main():
                     sync.reduce_bucket(*staged.stage_buckets[i])
                     if i == n_reduce - 1:
                         sync.wait()
+
+        def capture_one_graph():
+            # the whole step INCLUDING its bucket all-reduces as one hipGraph (RCCL kernels are capturable; ProcessGroupNCCL forks its
+            # communication stream off the capture stream, so each all-reduce becomes a parallel branch behind its segment and joins in
+            # front of the optimiser): one replay per step instead of four replays + three host-issued collectives
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                for i, seg in enumerate(segments):
+                    seg()
+                    if i < n_reduce:
+                        sync.reduce_bucket(*staged.stage_buckets[i])
+                        if i == n_reduce - 1:
+                            sync.wait()
+            return [g]
+
+        def capture_segments():
+            graphs, pool = [], None
+            for seg in segments:              # one capture stream (torch's default) and one memory pool for all segments:
+                g = torch.cuda.CUDAGraph()    # the autograd graph built in segment 0 is walked in segments 1 and 2
+                # thread_local: the process group's watchdog thread queries events while we capture
+                with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local' if sync is not None else 'global'):
+                    seg()
+                pool = g.pool()
+                graphs.append(g)
+            return graphs
+
+        def replayer(graphs, wait_events=None):
+            if len(graphs) == 1:
+                return graphs[0].replay
+
+            def fn():
+                for i, g in enumerate(graphs):
+                    g.replay()
+                    if sync is not None and i < n_reduce:
+                        sync.reduce_bucket(*staged.stage_buckets[i])         # queued behind segment i, runs under segments i+1..
+                        if i == n_reduce - 1:
+                            sync.wait(wait_events)    # the optimiser segment waits for every bucket
+            return fn
+
+        def all_agree(ok):
+            """Every rank must take the same step form (a rank replaying one graph with captured collectives against a rank issuing them from
+            the host would deadlock): the AND of the ranks' flags."""
+            if world == 1:
+                return bool(ok)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            return bool(int(flag.item()))
+
+        def block_time(fn, k):
+            if dog is not None:
+                dog.beat('a block of %d steps' % k)
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            return time.perf_counter() - t0
+
         graphs = None
-        capturable = use_graph
-        if capturable:
+        if use_graph:
             try:
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
@@ -274,65 +355,90 @@ def main():
                         eager()
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
-                graphs, pool = [], None
-                if one_graph_collectives:
-                    # the whole step INCLUDING its bucket all-reduces as one hipGraph (RCCL kernels are capturable; ProcessGroupNCCL forks
-                    # its communication stream off the capture stream, so each all-reduce becomes a parallel branch behind its segment
-                    # and joins in front of the optimiser): one replay per step instead of four replays + three host-issued collectives
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                        for i, seg in enumerate(segments):
-                            seg()
-                            if i < n_reduce:
-                                sync.reduce_bucket(*staged.stage_buckets[i])
-                                if i == n_reduce - 1:
-                                    sync.wait()
-                    graphs.append(g)
-                else:
-                    for seg in segments:              # one capture stream (torch's default) and one memory pool for all segments:
-                        g = torch.cuda.CUDAGraph()    # the autograd graph built in segment 0 is walked in segments 1 and 2
-                        # thread_local: the process group's watchdog thread queries events while we capture
-                        with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local' if sync is not None else 'global'):
-                            seg()
-                        pool = g.pool()
-                        graphs.append(g)
+                graphs = capture_one_graph() if one_graph_collectives else capture_segments()
+                rec['step_form'] = 'one graph, collectives captured' if one_graph_collectives else ('%d segment graphs, collectives issued from the host' % len(graphs) if split_step else 'one graph')
             except Exception as e:                 # noqa
+                rec['capture_error'] = '%s: %s' % (type(e).__name__, str(e)[:400])
                 if rank == 0:
-                    print('[bench] hipGraph capture failed (%s: %s); running eager' % (type(e).__name__, str(e)[:200]), file=sys.stderr)
+                    print('[bench] hipGraph capture failed (%s); running eager' % rec['capture_error'], file=sys.stderr)
                 graphs = None
                 torch.cuda.synchronize()
                 m, opt = build(prec)
                 sync = D.GradientAllReduce(opt, single_rank_too=one_rank_rccl) if (world > 1 or one_rank_rccl) else None
-                segments, staged = make_step(m, opt)
-        if graphs is None:
-            fn = eager
-        elif len(graphs) == 1:
-            fn = graphs[0].replay
-        else:
-            def fn():
-                for i, g in enumerate(graphs):
-                    g.replay()
-                    if sync is not None and i < n_reduce:
-                        sync.reduce_bucket(*staged.stage_buckets[i])         # queued behind segment i, runs under segments i+1..
-                        if i == n_reduce - 1:
-                            sync.wait()               # the optimiser segment waits for every bucket
+                segments, staged = make_step(m, opt, n_leads)
+            if world > 1 and not all_agree(graphs is not None):          # one rank failed to capture: everybody runs eager
+                graphs = None
+                rec['capture_error'] = rec['capture_error'] or 'another rank failed to capture'
+        fn = eager if graphs is None else replayer(graphs)
+        # N > 1 over RCCL: pick between "segment graphs + host-issued collectives" and "one graph with the collectives captured" by a 20-replay
+        # self-measurement (the two forms swap places from box to box on a one-rank group and nobody has timed them on
+        # xGMI).  Every failure on any rank keeps the segment form.  DPN_BENCH_CAPTURE_COLLECTIVES=0/1 pins the choice.
+        if (graphs is not None and split_step and not one_graph_collectives and os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') is None
+                and sync is not None and torch.distributed.get_backend() == 'nccl' and (world > 1 or os.environ.get('DPN_BENCH_TRY_FORMS') == '1')):
+            trial = {'segments_ms': None, 'one_graph_ms': None, 'error': None}
+            one = None
+            try:
+                one = capture_one_graph()
+            except Exception as e:                 # noqa
+                trial['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+                torch.cuda.synchronize()
+            if all_agree(one is not None):
+                f2 = replayer(one)
+                for f_ in (fn, f2):
+                    for _ in range(5):
+                        f_()
+                t_seg, t_one = block_time(fn, 20), block_time(f2, 20)
+                both = torch.tensor([t_seg, t_one], dtype=torch.float64, device=dev)
+                if world > 1:
+                    torch.distributed.all_reduce(both, op=torch.distributed.ReduceOp.MAX)
+                t_seg, t_one = float(both[0]), float(both[1])
+                trial['segments_ms'], trial['one_graph_ms'] = t_seg / 20 * 1e3, t_one / 20 * 1e3
+                if t_one < 0.99 * t_seg:
+                    graphs, fn = one, f2
+                    rec['step_form'] = 'one graph, collectives captured (chosen by the start-up trial)'
+                else:
+                    rec['step_form'] += ' (kept by the start-up trial)'
+            elif trial['error'] is None:
+                trial['error'] = 'another rank failed to capture the collectives'
+            rec['step_form_trial'] = trial
+
+        # 1. the first block, cold (rounds 1-4's protocol)
         for _ in range(warmup):
             fn()
+        first = block_time(fn, steps)
+        # 2. pre-warm to a steady clock
+        prewarm_s, prewarm_replays = 0.0, 0
+        if steady:
+            last = None
+            while prewarm_s < 4.0:
+                dt_ = block_time(fn, 20)
+                prewarm_s += dt_
+                prewarm_replays += 20
+                if last is not None and prewarm_s >= 0.5 and abs(dt_ - last) <= 0.01 * last:
+                    break
+                last = dt_
+        # 3. the timed blocks
+        times = []
+        while len(times) < blocks and (len(times) < 3 or sum(times) < 8.0):
+            times.append(block_time(fn, steps))
+        tt = torch.tensor([first] + times, dtype=torch.float64)
+        mine = sorted(times)[len(times) // 2] / steps * 1e3
+        per_rank = None
         if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
+            on = dev if torch.distributed.get_backend() == 'nccl' else 'cpu'
+            tt = tt.to(on)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tt.item())
-        return m, dt, graphs is not None, fn
+            tt = tt.cpu()
+            every = [None] * world
+            torch.distributed.all_gather_object(every, mine)
+            per_rank = {'ms_per_step': [round(v, 4) for v in every], 'min': min(every), 'max': max(every), 'slowest_rank': int(max(range(world), key=lambda r: every[r])),
+                        'fastest_rank': int(min(range(world), key=lambda r: every[r]))}
+        first, times = float(tt[0]), [float(v) for v in tt[1:]]
+        med = sorted(times)[len(times) // 2]
+        rec.update({'model': m, 'optimizer': opt, 'dt': med, 'graphed': graphs is not None, 'fn': fn, 'first_block_s': first, 'block_s': times,
+                    'prewarm_s': prewarm_s, 'prewarm_replays': prewarm_replays, 'per_rank': per_rank, 'staged': staged, 'graphs': graphs,
+                    'n_reduce': n_reduce, 'replayer': replayer})
+        return rec
 
     def collective_info():
         """Who took part: backend, world size, every rank's device (index, PCI bus id, name) gathered over the process group itself, and the
@@ -359,9 +465,16 @@ def main():
 
     sync = None
     coll = collective_info()
-    m, dt, graphed, step_fn = run(args.prec, args.steps, args.warmup, not args.no_graph)
+    # N > 1: a rank that stops making progress ends the job with its rank and the bucket it last queued named (exit code 13)
+    dog = D.Watchdog(float(os.environ.get('DPN_BENCH_WATCHDOG_S', '300')), rank) if world > 1 else None
+    from deepphysinet_amd import config as C
+    rec = run(args.prec, args.steps, args.warmup, not args.no_graph)
+    if dog is not None:
+        dog.stop()                                 # the timed region is over: what follows (rooflines on rank 0, the final barrier) has no collectives in flight
+    m, dt, graphed, step_fn = rec['model'], rec['dt'], rec['graphed'], rec['fn']
     ms_per_step = dt / args.steps * 1e3
     pts_per_s = args.points * args.leads * world * args.steps / dt
+    n_segments = len(rec['graphs']) if rec['graphs'] else (4 if split_step else 1)
 
     out = {
         'metric': 'collocation-points/sec (fwd+PDE-Jacobian+bwd)', 'value': pts_per_s, 'unit': 'points/s', 'n_gpus': world,
@@ -376,14 +489,38 @@ def main():
                                 'point kernels field after field), six PDE residual losses, fwd+Jacobian+bwd+clip+Adam' % (args.leads, args.points)),
                    'leads': args.leads,
                    'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world,
-                   'step_segments': (1 if one_graph_collectives else 4) if split_step else 1,     # three backward segments + the optimiser
-                   'collectives_in_graph': bool(one_graph_collectives)},
-        'timed_seconds': dt,
-        **({'warning': 'timed region %.3f s < 0.2 s: ms_per_step is still a mean over %d graph replays, but GPU-utilisation samplers '
-                       'see almost nothing; use --steps >= 200' % (dt, args.steps)} if dt < 0.2 else {}),
+                   'step_segments': n_segments,           # N > 1: three backward segments + the optimiser, or one graph with the collectives captured
+                   'step_form': rec['step_form'], 'collectives_in_graph': bool(split_step and graphed and n_segments == 1),
+                   'graph_branches': C.FROZEN.no_branches is False},
+        # ms_per_step is the MEDIAN of `timed_blocks` blocks of `steps` replays each, taken after the clock has settled (`prewarm_*`); the first block
+        # -- `warmup` + `steps` replays straight after the capture, the protocol of rounds 1-4 -- is reported beside it
+        'timed_seconds': sum(rec['block_s']), 'timed_blocks': len(rec['block_s']),
+        'block_ms_per_step': [round(b_ / args.steps * 1e3, 5) for b_ in rec['block_s']],
+        'first_block_ms': rec['first_block_s'] / args.steps * 1e3, 'prewarm_s': round(rec['prewarm_s'], 3), 'prewarm_replays': rec['prewarm_replays'],
         'algorithmic_tflops_step': pts_per_s * ALG_FLOP_STEP / 1e12,
         'collective': coll,
+        'switches': C.snapshot(),                   # every DPN_* variable of the environment + the frozen switches that differ from their defaults
     }
+    if rec['capture_error']:
+        out['capture_error'] = rec['capture_error']
+    if rec.get('step_form_trial'):
+        coll['step_form_trial'] = rec['step_form_trial']
+    if rec['per_rank']:
+        coll['per_rank'] = rec['per_rank']
+    if sync is not None and rec['graphs'] is not None and len(rec['graphs']) > 1:
+        # how long the optimiser segment actually WAITS for each bucket's all-reduce (an event pair around every wait, 20 replays): the part of
+        # the collectives that the backward segments did not hide
+        evs = []
+        probe = rec['replayer'](rec['graphs'], wait_events=evs)
+        for _ in range(20):
+            probe()
+        torch.cuda.synchronize()
+        nb = max(1, rec['n_reduce'])
+        per = [[] for _ in range(nb)]
+        for i, (e0, e1) in enumerate(evs):
+            per[i % nb].append(e0.elapsed_time(e1) * 1e3)
+        coll['exposed_us'] = [round(sorted(v)[len(v) // 2], 1) if v else None for v in per]
+        coll['exposed_us_note'] = 'median over 20 replays of the time the optimiser segment waits for bucket i (HIP events around each wait)'
     if args.encoder_fp8:
         out['config']['encoder_fp8'] = 'mx (E8M0 scale per 32 k, v_mfma_scale_f32_32x32x64_f8f6f4)' if args.encoder_fp8 == 'mx' else 'per-row scales, v_mfma_f32_32x32x16_fp8_fp8'
         out['dtype'] += '; encoder forward GEMMs fp8 e4m3 MFMA (configs[4])'
@@ -499,16 +636,17 @@ def main():
             # the kernel alone, back to back: the clock the socket's power cap leaves it, and the dense peak AT that clock (peak above = 2.4 GHz)
             sustained['peak_at_this_clock_tflops'] = MFMA_PEAK_BF16 / 1e12 * sustained['sclk_mhz'] / 2400.0
             roof['kernel_back_to_back'] = sustained
-        # operands of the four products per point per net: M2 (0/1 bf16, one plane: 512 B) + Z, M2 + Z1, M2 + G6, T1 + Z0
-        # = 3 x 512 + 2304 B of bf16 (the 2304 x2 in the hi+lo mode); v is not an operand any more (affine in m2: csrc SavedView)
-        w_bytes = ws.sizes.n_pad * 6 * (3 * 512 + 2304 * ns)
+        # operands of the three products per point per net: M2 (0/1 bf16, one plane: 512 B) + Z1, M2 + G6, T1 + Z0
+        # = 2 x 512 + 1792 B of bf16 (the 1792 x2 in the hi+lo mode); neither v (affine in m2: csrc SavedView) nor Z (linear in Z1, G6, g:
+        # dpn_finish_gside_kernel) is an operand any more
+        w_bytes = ws.sizes.n_pad * 6 * (2 * 512 + 1792 * ns)
         roof_hbm = {'bound': 'hbm', 'kernel': 'dpn_wgrad_kernel<%d>' % ns,
                     'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': w_bytes / (w_ms * 1e-3) / HBM_PEAK, 'kernel_ms': w_ms, 'algorithmic_bytes': w_bytes,
                     'traffic': pmc_traffic('dpn_wgrad_kernel', prec, args.points)[0], 'bwd_points_kernel_ms': b_ms}
-        # backward stage 1 (dpn_bwd_tiles_kernel / dpn_bwd_kernel): per point and net it writes the K-layout operands of the four weight-gradient
-        # products -- Z1, Z (256 columns) and Z0, G6 (192 columns), each hi (+ lo) bf16 -- and reads 40 B of cotangents: bound by its HBM writes
-        b_bytes = ws.sizes.n_pad * 6 * (2 * 512 + 2 * 384) * ns
+        # backward stage 1 (dpn_bwd_tiles_kernel / dpn_bwd_kernel): per point and net it writes the K-layout operands of the three weight-gradient
+        # products -- Z1 (256 columns) and Z0, G6 (192 columns), each hi (+ lo) bf16 -- and reads 40 B of cotangents: bound by its HBM writes
+        b_bytes = ws.sizes.n_pad * 6 * (512 + 2 * 384) * ns
         b_traffic = pmc_traffic('dpn_bwd_tiles_kernel' if ns == 2 else 'dpn_bwd_kernel', prec, args.points)[0]
         roof_hbm['bwd_stage1_kernel'] = {'bound': 'hbm', 'kernel': 'dpn_bwd_tiles_kernel<2>' if ns == 2 else 'dpn_bwd_kernel<1>',
                                          'achieved': b_bytes / (b_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
@@ -526,10 +664,12 @@ def main():
             out['power'] = sample_power(steps_, 2.0)          # the whole step replayed back to back (after the timed region)
         if not args.no_alt and world == 1:
             alt = 'bf16x2' if args.prec == 'bf16' else 'bf16'
-            del m
+            del m, step_fn
+            rec.clear()
             torch.cuda.empty_cache()
-            m2, dt2, _, _ = run(alt, max(5, args.steps // 3), 3, not args.no_graph)
             st2 = max(5, args.steps // 3)
+            rec2 = run(alt, st2, 3, not args.no_graph, blocks=3)
+            m2, dt2 = rec2['model'], rec2['dt']
             out['other_precision_mode'] = {'mode': alt, 'value': args.points * args.leads * st2 / dt2, 'ms_per_step': dt2 / st2 * 1e3,
                                            'parity': 'PDE losses within 1e-4 of the fp32 reference' if alt == 'bf16x2' else
                                                      'plain bf16 operands: PDE losses within 5e-2 (measured 1e-3 ... 2e-2), not the parity-grade mode'}
@@ -537,6 +677,27 @@ def main():
                 r2, _ = kernel_rooflines(m2, alt)
                 out['other_precision_mode']['roofline'] = {k: r2[k] for k in ('kernel', 'frac', 'kernel_ms', 'achieved', 'executed_mfma_frac_of_peak')}
             del m2
+            rec2.clear()
+        if not args.no_lead_probe and world == 1 and args.leads == 1:
+            # BASELINE configs[2]-shaped evidence in the same line: 8 forecast-lead field samples x the same points in ONE
+            # captured step, a few replays -- points/s, whether the parameters stayed finite, the step's fraction of the bf16 peak
+            rec.clear()
+            torch.cuda.empty_cache()
+            nl = 8
+            make_leads(nl)
+            rec3 = run(args.prec, 3, 1, not args.no_graph, leads=nl, blocks=3, steady=False)
+            m3, dt3 = rec3['model'], rec3['dt']
+            v3 = args.points * nl * 3 / dt3
+            out['lead_batch_probe'] = {'leads': nl, 'points_per_step': args.points * nl, 'ms_per_step': dt3 / 3 * 1e3, 'value': v3, 'unit': 'points/s',
+                                       'steps': 3, 'blocks': len(rec3['block_s']), 'hip_graph': rec3['graphed'],
+                                       'parameters_finite': bool(all(bool(torch.isfinite(p_).all()) for p_ in m3.physics_net.parameters())),
+                                       'step_frac_of_peak': v3 * ALG_FLOP_STEP / MFMA_PEAK_BF16,
+                                       'note': 'configs[2] itself (61 leads) is `bench.py --leads 61`; this probe is the same code path at 8 leads'}
+            if rec3['capture_error']:
+                out['lead_batch_probe']['capture_error'] = rec3['capture_error']
+            del m3
+            rec3.clear()
+            lead_batches.pop(nl, None)
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(args.cpu_threads or min(32, os.cpu_count() or 1))   # more threads only add OpenMP overhead on these small ops
             cpu_model = None

@@ -116,6 +116,7 @@ EXPORTS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_wgrad': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_wgrad_finish': (c_int, [POINTER(DpnNetPtrs), c_void_p, c_int64, c_int, c_void_p, POINTER(DpnNetGradPtrs), c_void_p]),
+    'dpn_wgrad_finish_parts': (c_int, [POINTER(DpnNetPtrs), c_void_p, c_int64, c_int, c_void_p, POINTER(DpnNetGradPtrs), c_int, c_void_p]),
     'dpn_smooth_l1': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'dpn_sgemm': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                           c_void_p, c_int64, c_void_p]),

@@ -702,12 +702,15 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // Backward, stage 1 (per-point cotangent streams -> operands of the weight-gradient reductions), tile-split form.  Same arithmetic and same
-// operand layout as dpn_bwd_kernel (bit-identical Z0, Z1, Z, G6, gnet); decomposition as dpn_fwd_tiles_kernel: 64 points per workgroup, wave
+// operand layout as dpn_bwd_kernel (bit-identical Z0, Z1, G6, gnet); decomposition as dpn_fwd_tiles_kernel: 64 points per workgroup, wave
 // w owns tiles 2w, 2w+1 of both column tiles, the cotangent fragments are shared through LDS, the weights come L2 -> VGPR.
 //   Z0 = g pe + sum_c gJ_c d pe / d xi_c                      -> X, K-layout rows (operand of dw1 = T1^T Z0)
-//   Z1 = m1 (.) (w1 Z0 + g b1)                                -> X, K-layout rows (operand of dw2 = V^T Z1)
-//   Z  = w2 Z1 + Wd (g pe6) + g (b2 + bd + e), channel per lane (SWAP orientation: the activation fragments are the A operand), stored as is
-//   G6 = g pe6                                                -> X, K-layout rows (operand of dWd = V^T G6)
+//   Z1 = m1 (.) (w1 Z0 + g b1)                                -> K-layout rows (operand of S1 = M2^T Z1)
+//   G6 = g pe6                                                -> K-layout rows (operand of S2 = M2^T G6)
+// Round 5: Z = w2 Z1 + Wd G6 + g (b2 + bd + e) is no longer formed.  It existed only as the Y operand of G = M2^T Z, and being linear in
+// (Z1, G6, g) that product is S1 w2^T + S2 Wd^T + (M2^T g) (x) cvec: one exact-fp32 GEMM per net behind the reduction
+// (dpn_finish_gside_kernel) instead of 114 688 of this kernel's 163 840 MACs per point and net, a 1-KB row written per point and net, and a
+// fourth points-reduction product reading it back.
 template <int NS>
 __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
     using C = ts::Cfg<NS>;
@@ -754,15 +757,6 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
         const int64_t pt = (tile0 + h) * 32 + j;
         ov.gnet[(int64_t)net * a.n_pad + pt] = (pt < a.n) ? a.g_out[pt * 6 + net] : 0.f;
     }
-    // cotangents of the 16 points this lane holds in the channel-per-lane (SWAP) accumulator layout, per column tile
-    float g16[2][16];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t q = (tile0 + p) * 32 + drow32(r, h);
-            g16[p][r] = (q < a.n) ? a.g_out[q * 6 + net] : 0.f;
-        }
     // ---------------- Z0 -> X (k-steps 0..11) and K-layout rows: wave w builds the (column tile of Z0, point tile) units 3w .. 3w+2
     Frag<NS> Z0f[3][2];
     // the K-layout hand-over of a unit set {f[uu][0], f[uu][1]} (three units x NS planes) spread over a 12-k-step multiply loop
@@ -793,9 +787,8 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
     TS_STAMP(1);
     ts::barrier_lds();
     TS_STAMP(2);
-    // ---------------- Z1 = m1 (.) (w1 Z0 + g b1) -> X (+ K-layout rows)
+    // ---------------- Z1 = m1 (.) (w1 Z0 + g b1) -> K-layout rows
     f32x16 acc[2][2];
-    Frag<NS> F[2][2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -809,111 +802,29 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
     ts::gemm<NS, 12, 2, false, ts::NoSide, false>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
 #endif
     TS_STAMP(3);
-    ts::gemm_head<NS, 16, 2>(chunk(kS1 + 2 * w * 16), lane, H);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+            Frag<NS> F0, F1;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const u32 bits = m1w[p] >> (16 * t + r);
-                frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, (bits & 1u) ? acc[t][p][r] : 0.f, (bits & 2u) ? acc[t][p][r + 1] : 0.f);
+                frag_set2<NS>(r < 8 ? F0 : F1, (r & 7) >> 1, (bits & 1u) ? acc[t][p][r] : 0.f, (bits & 2u) ? acc[t][p][r + 1] : 0.f);
             }
-#if !TS_DEFER_SAVES
-            ts::save_tile_k<NS, NS>(ov.Z1, net, tile0 + p, 2 * w + t, lane, I, false, F[t][p][0], F[t][p][1]);
-#endif
+            ts::save_tile_k<NS, NS>(ov.Z1, net, tile0 + p, 2 * w + t, lane, I, false, F0, F1);
         }
     TS_STAMP(4);
-    ts::barrier_lds();                                        // everybody is done reading Z0
+    // ---------------- G6 = g pe6 -> K-layout rows: units as for Z0
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
+        const int u = 3 * w + uu, ct = u >> 1, p = u & 1;
+        const float gp = p ? g[1] : g[0];
+        const int64_t pcp = p ? pc[1] : pc[0];
+        Frag<NS> f0, f1;
+        ts::pe6_frag<NS>(f0, a, 2 * ct, h, pcp, gp);
+        ts::pe6_frag<NS>(f1, a, 2 * ct + 1, h, pcp, gp);
+        ts::save_tile_k<NS, NS>(ov.G6, net, tile0 + p, ct, lane, I, false, f0, f1);
+    }
     TS_STAMP(5);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) ts::x_store<NS>(xl, 4 * w + 2 * t + kk, p, F[t][p][kk]);
-    TS_STAMP(6);
-    ts::barrier_lds();
-    TS_STAMP(7);
-    // ---------------- Z = w2 Z1 + Wd (g pe6) + g (b2 + bd + e): channel per lane (SWAP), acc[t][p] = [points of column tile p][channels of tile 2w+t]
-    {
-        const int rr = (j & 3) + 4 * (j >> 3), hh = (j >> 2) & 1;   // natural-order read of cvec for channel 32T + j from the [h][T][r] permuted vector
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float cv = vec[kVecCvec * 256 + hh * 128 + (2 * w + t) * 16 + rr];
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][p][r] = g16[p][r] * cv;
-        }
-    }
-#if TS_DEFER_SAVES
-    {
-        auto side = [&](const int ks) __attribute__((always_inline)) {             // Z1 (still in F): 4 x NS plane units over the 16 k-steps
-#pragma unroll
-            for (int u = 0; u < 4 * NS; ++u) {
-                const int tp = u / NS, s_ = u % NS;
-                if (ks == (16 / (4 * NS)) * u + 1)
-                    ts::save_plane_k(ov.Z1, net, NS, s_, tile0 + (tp & 1), 2 * w + (tp >> 1), lane, I, false, F[tp >> 1][tp & 1][0].w[s_], F[tp >> 1][tp & 1][1].w[s_]);
-            }
-        };
-        ts::gemm<NS, 16, 2, true, decltype(side), false>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc, side);
-    }
-#else
-    ts::gemm<NS, 16, 2, true, ts::NoSide, false>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
-#endif
-    TS_STAMP(8);
-    ts::gemm_head<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), lane, H);
-    Frag<NS> f6[3][2];
-    {   // G6 = g pe6 -> X (k-steps 0..11) and K-layout rows: units as for Z0
-#pragma unroll
-        for (int uu = 0; uu < 3; ++uu) {
-            const int u = 3 * w + uu, ct = u >> 1, p = u & 1;
-            const float gp = p ? g[1] : g[0];
-            const int64_t pcp = p ? pc[1] : pc[0];
-            ts::pe6_frag<NS>(f6[uu][0], a, 2 * ct, h, pcp, gp);
-            ts::pe6_frag<NS>(f6[uu][1], a, 2 * ct + 1, h, pcp, gp);
-#if !TS_DEFER_SAVES
-            ts::save_tile_k<NS, NS>(ov.G6, net, tile0 + p, ct, lane, I, false, f6[uu][0], f6[uu][1]);
-#endif
-        }
-        TS_STAMP(9);
-        ts::barrier_lds();                                    // everybody is done reading Z1
-        TS_STAMP(10);
-#pragma unroll
-        for (int uu = 0; uu < 3; ++uu) {
-            const int u = 3 * w + uu, ct = u >> 1, p = u & 1;
-            ts::x_store<NS>(xl, 2 * ct, p, f6[uu][0]);
-            ts::x_store<NS>(xl, 2 * ct + 1, p, f6[uu][1]);
-        }
-        TS_STAMP(11);
-        ts::barrier_lds();
-        TS_STAMP(12);
-    }
-#if TS_DEFER_SAVES
-    {
-        auto side = [&](const int ks) __attribute__((always_inline)) { side_units(ov.G6, f6, ks); };
-        ts::gemm<NS, 12, 2, true, decltype(side), false>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc, side);
-    }
-#else
-    ts::gemm<NS, 12, 2, true, ts::NoSide, false>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc);
-#endif
-    TS_STAMP(13);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                f32x16 d = acc[t][p];
-                if (s == 1) {
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const u32 hi = pack2(acc[t][p][r], acc[t][p][r + 1]);
-                        d[r] = acc[t][p][r] - bf_lo(hi); d[r + 1] = acc[t][p][r + 1] - bf_hi(hi);
-                    }
-                }
-                store_d_as_k(ov.Z, net, NS, s, tile0 + p, 2 * w + t, lane, d);
-            }
-    TS_STAMP(14);
 }

@@ -597,7 +597,7 @@ static int features_prepass() {        // latched at the first call: dpn_sizes a
 static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_pad, ns) + (features_prepass() ? feature_bytes(n_pad, ns) : 0); }
 
 struct OperandView {     // written by dpn_bwd_points
-    KMat Z1, Z;          // [6][NS] x 256
+    KMat Z1;             // [6][NS] x 256   (round 5: Z is not an operand any more, dpn_finish_gside_kernel)
     KMat Z0, G6;         // [6][NS] x 192   (G6 = gout * pe6)
     float* gnet;         // [6][n_pad]  per-net cotangent of the normalised field, zero for padding points
 };
@@ -607,13 +607,12 @@ DEV OperandView operand_view(void* base, int64_t n_pad, int ns) {
     const int64_t m256 = (int64_t)kNets * ns * n_pad * 512, m192 = (int64_t)kNets * ns * n_pad * 384;
     const int64_t tiles32 = n_pad / 32;
     o.Z1 = KMat{b, tiles32, 8};
-    o.Z = KMat{b + m256, tiles32, 8};
-    o.Z0 = KMat{b + 2 * m256, tiles32, 6};
-    o.G6 = KMat{b + 2 * m256 + m192, tiles32, 6};
-    o.gnet = reinterpret_cast<float*>(b + 2 * m256 + 2 * m192);
+    o.Z0 = KMat{b + m256, tiles32, 6};
+    o.G6 = KMat{b + m256 + m192, tiles32, 6};
+    o.gnet = reinterpret_cast<float*>(b + m256 + 2 * m192);
     return o;
 }
-static int64_t operand_bytes(int64_t n_pad, int ns) { return 2 * (int64_t)kNets * ns * n_pad * 512 + 2 * (int64_t)kNets * ns * n_pad * 384 + (int64_t)kNets * n_pad * 4 + 1024; }
+static int64_t operand_bytes(int64_t n_pad, int ns) { return (int64_t)kNets * ns * n_pad * 512 + 2 * (int64_t)kNets * ns * n_pad * 384 + (int64_t)kNets * n_pad * 4 + 1024; }
 
 // ------------------------------------------------------------------------------------------------ forward + Jacobian
 struct FwdArgs {
@@ -1103,17 +1102,10 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
     const uint4 m1v = sv.m1[((int64_t)net * tiles32 + tile32) * 64 + L.lane];
     const u32 m1w[4] = {m1v.x, m1v.y, m1v.z, m1v.w};
     if (h == 0) ov.gnet[(int64_t)net * a.n_pad + tile32 * 32 + L.j] = g;
-    // cotangents of the 16 points this lane holds in the channel-per-lane (SWAP) accumulator layout
-    float g16[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t p = tile32 * 32 + drow32(r, h);
-        g16[r] = (p < a.n) ? a.g_out[p * 6 + net] : 0.f;
-    }
 
     Pipe<NS> pipe;
     __syncthreads();
-    pipe.init(pk, lds_w, 24);
+    pipe.init(pk, lds_w, 8);                      // the w1 chunks only (round 5: the w2 / Wd products of Z are gone)
     pipe.prime();
 
     f32x16 acc[8];
@@ -1144,41 +1136,13 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
         }
         epi1(7);
     }
-    // ---------------- Z = w2 Z1 + Wd (g pe6) + g (b2 + bd + e), computed channel-per-lane (SWAP) and stored as is
+    // ---------------- G6 = g pe6 (operand of S2 = M2^T G6).  Z = w2 Z1 + Wd G6 + g cvec is NOT formed any more (round 5): it is linear in
+    // (Z1, G6, g), so M2^T Z = S1 w2^T + S2 Wd^T + mvec (x) cvec is one exact-fp32 GEMM per net behind the reduction (dpn_finish_gside_kernel)
     {
         Frag<NS> g6[12];
         build_pe6<NS>(L, cd6, g6, g);
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct) store_tile_k<NS, NS>(ov.G6, net, tile32, ct, L, g6[2 * ct], g6[2 * ct + 1], false);
-        // natural-order read of cvec for channel 32T + j from the [h][T][r] permuted vector
-        const int w = L.j, rr = (w & 3) + 4 * (w >> 3), hh = (w >> 2) & 1;
-        auto epiz = [&](const int T) __attribute__((always_inline)) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                f32x16 d = acc[T];
-                if (s == 1) {
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const u32 hi = pack2(acc[T][r], acc[T][r + 1]);
-                        d[r] = acc[T][r] - bf_lo(hi); d[r + 1] = acc[T][r + 1] - bf_hi(hi);
-                    }
-                }
-                store_d_as_k(ov.Z, net, NS, s, tile32, T, L.lane, d);
-            }
-        };
-#pragma unroll
-        for (int T = 0; T < 8; ++T) {
-            const float cv = lds_read_f32(lds_vec + (kVecCvec * 256 + hh * 128 + T * 16 + rr) * 4);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[T][r] = g16[r] * cv;
-            DPN_STEP(8 + T, 16, true, actA, acc[T], (void)0);
-        }
-#pragma unroll
-        for (int T = 0; T < 8; ++T) {
-            if (T == 0) DPN_STEP(16 + T, 12, true, g6, acc[T], (void)0);
-            else DPN_STEP(16 + T, 12, true, g6, acc[T], epiz(T - 1));
-        }
-        epiz(7);
         pipe.drain();
     }
 }
@@ -1198,9 +1162,9 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 // 32-point tiles (SplitPlan below says how many ranges each product is cut into) and writes one partial sum per range;
 // dpn_finish_* add the ranges in a fixed order.  Operands are already MFMA fragments in global memory (K-layout, written by
 // dpn_fwd / dpn_bwd_points), so a tile travels global -> LDS as a plain byte image.
-constexpr int kPartFloats = 65536 * 2 + 49152 * 2 + 7 * 256;       // per (split, net)
-DPN_HD int part_off(int prod) { return prod == 0 ? 0 : prod == 1 ? 65536 : prod == 2 ? 131072 : 180224; }
-constexpr int kPartVec = 229376;                                    // mvec, q, mv1, db1, [sum g], q1, q6
+constexpr int kPartFloats = 65536 + 49152 * 2 + 7 * 256;           // per (split, net)
+DPN_HD int part_off(int prod) { return prod == 1 ? 0 : prod == 2 ? 65536 : 114688; }
+constexpr int kPartVec = 163840;                                    // -, -, mv1, db1, [sum g], q1, q6 (slots 0, 1 were product 0's mvec, q)
 
 struct WgradArgs {
     int64_t n, n_pad;
@@ -1246,9 +1210,9 @@ struct WgradShape {
 template <int NS>
 constexpr int wgrad_lds_bytes() {
     int m = 0;
-    const int v[4] = {WgradShape<NS, 0>::RING * WgradShape<NS, 0>::kSlot, WgradShape<NS, 1>::RING * WgradShape<NS, 1>::kSlot,
-                      WgradShape<NS, 2>::RING * WgradShape<NS, 2>::kSlot, WgradShape<NS, 3>::RING * WgradShape<NS, 3>::kSlot};
-    for (int k = 0; k < 4; ++k) m = v[k] > m ? v[k] : m;
+    const int v[3] = {WgradShape<NS, 1>::RING * WgradShape<NS, 1>::kSlot, WgradShape<NS, 2>::RING * WgradShape<NS, 2>::kSlot,
+                      WgradShape<NS, 3>::RING * WgradShape<NS, 3>::kSlot};
+    for (int k = 0; k < 3; ++k) m = v[k] > m ? v[k] : m;
     return m;
 }
 
@@ -1270,7 +1234,8 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
     const char* xb = (PROD == 3) ? sv.T1.base : sv.M2.base;                                      // 8 column tiles
-    const char* yb = (PROD == 0) ? ov.Z.base : (PROD == 1) ? ov.Z1.base : (PROD == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
+    static_assert(PROD >= 1 && PROD <= 3, "products: 1 = M2^T Z1, 2 = M2^T G6, 3 = T1^T Z0");
+    const char* yb = (PROD == 1) ? ov.Z1.base : (PROD == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
     const float* gnet = ov.gnet + (int64_t)net * a.n_pad;
 
     // every wave issues PER_TILE DMA instructions per tile: piece q = wave + 8*j of the (X planes, Y planes) image, + its own g copy.
@@ -1445,7 +1410,6 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
         const float v = vecA[m] + __shfl_xor(vecA[m], 32);
         if (wn == (nct == 8 ? m : m % 3) && h == 0) {
             const int rr = wm * 128 + 32 * m + i;
-            if (PROD == 0) part[kPartVec + 0 * 256 + rr] = v;          // mvec
             if (PROD == 1) part[kPartVec + 2 * 256 + rr] = v;          // mv1 (= mvec again: the hyper-network's half of the reduction does not wait for P0)
             if (PROD == 3) part[kPartVec + 3 * 256 + rr] = v;          // db1
         }
@@ -1455,7 +1419,7 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
         if (lane == 0) part[kPartVec + 4 * 256] = gs;
     }
     if (PROD != 3 && active) {
-        const int qo = kPartVec + (PROD == 0 ? 1 : PROD == 1 ? 5 : 6) * 256;             // q = colsum(Z), q1 = colsum(Z1), q6 = colsum(G6)
+        const int qo = kPartVec + (PROD == 1 ? 5 : 6) * 256;                             // q1 = colsum(Z1), q6 = colsum(G6)
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
             const float v = vecB[n2] + __shfl_xor(vecB[n2], 32);
@@ -1467,25 +1431,31 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
 template <int NS>
 __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[wgrad_lds_bytes<NS>()];
-    int prod = 0, split = blockIdx.x;                                   // workgroup -> (product, point range): uniform scalar walk
+    int prod = 1, split = blockIdx.x;                                   // workgroup -> (product, point range): uniform scalar walk
     while (prod < 3 && split >= a.splits[prod]) { split -= a.splits[prod]; ++prod; }
-    if (prod == 0) wgrad_body<NS, 0>(a, lds, split);
-    else if (prod == 1) wgrad_body<NS, 1>(a, lds, split);
+    if (prod == 1) wgrad_body<NS, 1>(a, lds, split);
     else if (prod == 2) wgrad_body<NS, 2>(a, lds, split);
     else wgrad_body<NS, 3>(a, lds, split);
 }
 
 // ------------------------------------------------------------------------------------------------ backward, stage 3
+// Round 5: two halves.  (1) dpn_finish_rows_kernel -> dpn_finish_vside_kernel: what the hyper-network's backward waits for (d w1b1, d w2b2,
+// d evec; dWd, d bd ride in the same launch).  (2) dpn_finish_gside_kernel -> dpn_finish_fc2_kernel: gradients of static tensors only
+// (cat_fc1.fc.0 / fc.2, out_fc) -- the host may run them on a side branch beside the encoder's backward chain (dpn_wgrad_finish_parts).
 struct FinishArgs {
     DpnNetPtrs net[kNets];
     DpnNetGradPtrs grad[kNets];
     const char* packed;
     const float* partials;
-    float* scratch_r;       // [6][256] r vector (lives in the partials buffer tail, like the three below)
-    float* scratch_s1;      // [6][256][256] diag(u) M2^T Z1, natural order          (dpn_finish_rows_kernel -> dpn_finish_vside_fc2_kernel)
-    float* scratch_s2;      // [6][256][192] diag(u) M2^T G6
-    float* scratch_mv;      // [6][256]      diag(u) M2^T g
-    int splits[4], ns;      // point ranges per product, as dpn_wgrad_kernel cut them
+    float* scratch_s1;      // [6][256][256] S1 = M2^T Z1, natural order             (dpn_finish_rows_kernel -> vside, gside)
+    float* scratch_s2;      // [6][256][192] S2 = M2^T G6
+    float* scratch_mv;      // [6][256]      mvec = M2^T g
+    float* scratch_u;       // [6][256]      u = W2^T wo, natural order
+    float* scratch_q1;      // [6][256]      colsum(Z1)
+    float* scratch_q6;      // [6][256]      colsum(G6) (192 used)
+    float* scratch_sg;      // [8]           sum g per net
+    float* scratch_rp;      // [6][8][256]   per column tile: sum_i W1[o][i] G[o][i]      (gside -> fc2)
+    int splits[4], ns;      // point ranges per product, as dpn_wgrad_kernel cut them (splits[0] = 0: the product M2^T Z is gone)
     int64_t n;
 };
 
@@ -1508,7 +1478,7 @@ DEV int slot_of_pe6(int orig) {
 // loads in flight at once (a loop of load -> wait -> add, which is what hipcc makes of the obvious code, costs one HBM round trip per
 // range and per sum: 40 in a row per thread).  Ranges beyond ks[q] re-read the last one and are not added; the additions keep the
 // range order, so the result does not depend on how the loads are grouped.
-constexpr int kMaxSplits = 16;                  // choose_plan() never returns more for one product
+constexpr int kMaxSplits = 20;                  // choose_plan() never returns more for one product
 template <int NQ, int MAXS>
 DEV void part_sums_n(const float* partials, const int (&ks)[NQ], int net, const int (&off)[NQ], float (&out)[NQ]) {
     float v[MAXS][NQ];
@@ -1531,66 +1501,66 @@ DEV void part_sums(const float* partials, const int (&ks)[NQ], int net, const in
     int most = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) most = ks[q] > most ? ks[q] : most;
-    if (most <= 12) part_sums_n<NQ, 12>(partials, ks, net, off, out);       // single bf16: at most 11 ranges per product
-    else part_sums_n<NQ, kMaxSplits>(partials, ks, net, off, out);          // hi+lo: 13 for dw1
+    if (most <= 12) part_sums_n<NQ, 12>(partials, ks, net, off, out);
+    else if (most <= 16) part_sums_n<NQ, 16>(partials, ks, net, off, out);
+    else part_sums_n<NQ, kMaxSplits>(partials, ks, net, off, out);
 }
 
-// one block per (output row o, net): reduces the splits, un-permutes, writes dW1, d(w1b1) rows, r[o] and row o of the two mask-side sums
+// one block per (output row o, net): reduces the point ranges, un-permutes: rows o of S1, S2 and of d(w1b1); the row's vector entries
 __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
     const int o = blockIdx.x, net = blockIdx.y, i = threadIdx.x;
-    const DpnNetPtrs& P = a.net[net];
     const DpnNetGradPtrs& Gd = a.grad[net];
     const int so = slot_of_ch(o), si = slot_of_ch(i);
-    __shared__ float red[256];
-    // u[o] = (W2^T wo)[o] from the packed vectors ([h][T][r] order)
-    const float* vec = reinterpret_cast<const float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
-    const int T = o >> 5, w = o & 31, hh = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);
-    const float uo = vec[kVecU * 256 + hh * 128 + T * 16 + r];
-    // thread 0 also owns the row's three vector entries: fetched with everything else, not after the reduction
-    float rowv[3] = {0.f, 0.f, 0.f};
-    if (i == 0) {
-        const int offv[3] = {kPartVec + 0 * 256 + so, kPartVec + 2 * 256 + so, kPartVec + 3 * 256 + so};     // written by products 0, 1, 3
-        const int ksv[3] = {a.splits[0], a.splits[1], a.splits[3]};
-        part_sums<3>(a.partials, ksv, net, offv, rowv);
+    // thread 0..4 also own the row's vector entries: fetched with everything else, not after the reduction
+    float rowv[1] = {0.f};
+    const bool has_vec = i < 4 || (i == 4 && o == 0);
+    if (has_vec) {
+        // mv1 = M2^T g and db1 = T1^T g (row slot so), q1 = colsum(Z1) (column slot of channel o), q6 = colsum(G6) (PE6 channel o), sum g
+        const int offv[1] = {i == 0 ? kPartVec + 2 * 256 + so : i == 1 ? kPartVec + 3 * 256 + so : i == 2 ? kPartVec + 5 * 256 + so
+                             : i == 3 ? kPartVec + 6 * 256 + slot_of_pe6(o < kPe ? o : 0) : kPartVec + 4 * 256};
+        const int ksv[1] = {i == 1 ? a.splits[3] : i == 3 ? a.splits[2] : a.splits[1]};
+        part_sums<1>(a.partials, ksv, net, offv, rowv);
     }
-    const int off2[2] = {part_off(0) + so * 256 + i, part_off(1) + so * 256 + si};      // Z's columns are in natural order (SWAP output)
-    float g2[2];
-    const int ks2[2] = {a.splits[0], a.splits[1]};
-    part_sums<2>(a.partials, ks2, net, off2, g2);
-    const float Goi = g2[0];
-    a.scratch_s1[((int64_t)net * 256 + o) * 256 + i] = uo * g2[1];
-    Gd.W1[o * 256 + i] = uo * Goi;
-    red[i] = P.W1[o * 256 + i] * Goi;
     if (i < kPe) {
-        const int offp[2] = {part_off(2) + so * 192 + slot_of_pe6(i), part_off(3) + so * 192 + slot_of_pe3(i)};
-        float gp[2];
-        const int ksp[2] = {a.splits[2], a.splits[3]};
-        part_sums<2>(a.partials, ksp, net, offp, gp);
-        a.scratch_s2[((int64_t)net * 256 + o) * kPe + i] = uo * gp[0];
-        Gd.w1b1[o * Gd.ld_w1b1 + i] = gp[1];
-    }
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (i < s) red[i] += red[i + s];
-        __syncthreads();
+        const int off3[3] = {part_off(1) + so * 256 + si, part_off(2) + so * 192 + slot_of_pe6(i), part_off(3) + so * 192 + slot_of_pe3(i)};
+        const int ks3[3] = {a.splits[1], a.splits[2], a.splits[3]};
+        float g3[3];
+        part_sums<3>(a.partials, ks3, net, off3, g3);
+        a.scratch_s1[((int64_t)net * 256 + o) * 256 + i] = g3[0];
+        a.scratch_s2[((int64_t)net * 256 + o) * kPe + i] = g3[1];
+        Gd.w1b1[o * Gd.ld_w1b1 + i] = g3[2];
+    } else {
+        const int off1[1] = {part_off(1) + so * 256 + si};
+        const int ks1[1] = {a.splits[1]};
+        float g1[1];
+        part_sums<1>(a.partials, ks1, net, off1, g1);
+        a.scratch_s1[((int64_t)net * 256 + o) * 256 + i] = g1[0];
     }
     if (i == 0) {
-        const float mvec = rowv[0], mv1 = rowv[1], db1 = rowv[2];
-        a.scratch_mv[net * 256 + o] = uo * mv1;
-        a.scratch_r[net * 256 + o] = red[0] + P.bf1[o] * mvec;
-        Gd.bf1[o] = uo * mvec;
-        Gd.w1b1[o * Gd.ld_w1b1 + 192] = db1;
+        // u[o] = (W2^T wo)[o] from the packed vectors ([h][T][r] order)
+        const float* vec = reinterpret_cast<const float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
+        const int T = o >> 5, w = o & 31, hh = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);
+        a.scratch_u[net * 256 + o] = vec[kVecU * 256 + hh * 128 + T * 16 + r];
+        a.scratch_mv[net * 256 + o] = rowv[0];
     }
+    if (i == 1) Gd.w1b1[o * Gd.ld_w1b1 + 192] = rowv[0];
+    if (i == 2) a.scratch_q1[net * 256 + o] = rowv[0];
+    if (i == 3 && o < kPe) a.scratch_q6[net * 256 + o] = rowv[0];
+    if (i == 4 && o == 0) a.scratch_sg[net] = rowv[0];
 }
 
 // The factor that turns the mask-side sums into the gradients that used to need v per point (SavedView):
-//   d(w2b2)[o][i] = sum_j W1[j][o] S1[j][i] + 2 wo[o] q1[i]        S1 = diag(u) M2^T Z1   (i < 256),  column 256: S1 -> diag(u) M2^T g, q1 -> sum g
-//   dWd[o][i]     = sum_j W1[j][o] S2[j][i] + 2 wo[o] q6[i]        S2 = diag(u) M2^T G6
+//   d(w2b2)[o][i] = sum_j W1[j][o] u[j] S1[j][i] + 2 wo[o] q1[i]        S1 = M2^T Z1   (i < 256),  column 256: S1 -> M2^T g, q1 -> sum g
+//   dWd[o][i]     = sum_j W1[j][o] u[j] S2[j][i] + 2 wo[o] q6[i]        S2 = M2^T G6
 // and d evec = d bd = column 256.  One workgroup per 32 x 32 output tile: grid (8 row tiles x 15 column tiles [8 of d w2, the vector, 6 of
 // dWd], 6 nets); the four waves take 64 of the 256 j each on the exact-fp32 matrix instruction (operands straight from global memory: both
 // are contiguous along the lane index) and their partial tiles are added in a fixed order through LDS.
 DEV f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-DEV void finish_vside_body(const FinishArgs& a, const int bx, float (&red)[4][16][64], float (&qs)[32]) {
+constexpr int kVsideBlocks = 8 * 15;
+__global__ __launch_bounds__(256) void dpn_finish_vside_kernel(FinishArgs a) {
+    __shared__ float red[4][16][64];
+    __shared__ float qs[32];
+    const int bx = blockIdx.x;
     const int rt = bx & 7, ctile = bx >> 3, net = blockIdx.y;
     const int kind = ctile < 8 ? 0 : ctile == 8 ? 1 : 2;                  // d w2 | vector column | dWd
     const DpnNetPtrs& P = a.net[net];
@@ -1598,29 +1568,25 @@ DEV void finish_vside_body(const FinishArgs& a, const int bx, float (&red)[4][16
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, kh = lane >> 5;
     const int o0 = 32 * rt, n0 = kind == 0 ? 32 * ctile : kind == 2 ? 32 * (ctile - 9) : 0, ncol = kind == 0 ? 256 : kind == 2 ? kPe : 1;
     const float* B = kind == 0 ? a.scratch_s1 + (int64_t)net * 65536 : kind == 2 ? a.scratch_s2 + (int64_t)net * 256 * kPe : a.scratch_mv + net * 256;
+    const float* U = a.scratch_u + net * 256;
     const int ldb = ncol;
     const bool colok = n0 + col < ncol;
-    // the rank-one term's column factor: q1 / q6 / sum g over the point ranges (loads in flight under the products)
-    float qv[1] = {0.f};
-    if (wv == 0 && colok) {
-        const int i = n0 + col;
-        const int offq[1] = {kind == 0 ? kPartVec + 5 * 256 + slot_of_ch(i) : kind == 2 ? kPartVec + 6 * 256 + slot_of_pe6(i) : kPartVec + 4 * 256};
-        const int ksq[1] = {kind == 2 ? a.splits[2] : a.splits[1]};
-        part_sums<1>(a.partials, ksq, net, offq, qv);
-    }
+    // the rank-one term's column factor: q1 / q6 / sum g
+    float qv = 0.f;
+    if (wv == 0 && colok) qv = kind == 0 ? a.scratch_q1[net * 256 + n0 + col] : kind == 2 ? a.scratch_q6[net * 256 + n0 + col] : a.scratch_sg[net];
     f32x16 acc = (f32x16)0.f;
     float av[32], bv[32];
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) {
         const int j = 64 * wv + 2 * kk + kh;
-        av[kk] = P.W1[j * 256 + o0 + col];
+        av[kk] = P.W1[j * 256 + o0 + col] * U[j];
         bv[kk] = colok ? B[(int64_t)j * ldb + n0 + col] : 0.f;
     }
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) acc = mfma_f32_32x32x2(av[kk], bv[kk], acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wv][r][lane] = acc[r];
-    if (wv == 0 && kh == 0) qs[col] = qv[0];
+    if (wv == 0 && kh == 0) qs[col] = qv;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1635,42 +1601,91 @@ DEV void finish_vside_body(const FinishArgs& a, const int bx, float (&red)[4][16
     }
 }
 
-// one block per (row o', net): dW2 = wo (x) r, dbf2, dwo, dbo
-DEV void finish_fc2_body(const FinishArgs& a, const int op, float* red) {
-    const int net = blockIdx.y, o = threadIdx.x;
+// G = M2^T Z without Z (round 5).  Z = Z1 w2^T + G6 Wd^T + g cvec^T is linear in the three per-point operands, so
+//   G[o][i] = sum_j S1[o][j] w2[i][j] + sum_k S2[o][k] Wd[i][k] + mvec[o] cvec[i]          cvec = b2 + bd + e
+// -- a 256 x 256 x 448 exact-fp32 GEMM per net on the sums dpn_wgrad_kernel produces anyway.  From it d cat_fc1.fc.0.weight = diag(u) G and the
+// per-tile parts of r[o] = sum_i W1[o][i] G[o][i] (+ bf1 mvec, added by dpn_finish_fc2_kernel).  One workgroup per 32 x 32 tile of G; wave wv
+// takes j in [64 wv, 64 wv + 64) and k in [48 wv, 48 wv + 48); lane (col, kh) holds four consecutive reduction indices per load of its row.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void dpn_finish_gside_kernel(FinishArgs a) {
+    __shared__ float red[4][16][64];
+    const int bx = blockIdx.x, net = blockIdx.y;
+    const int rt = bx & 7, ct = bx >> 3;
     const DpnNetPtrs& P = a.net[net];
     const DpnNetGradPtrs& Gd = a.grad[net];
-    float sq[2] = {0.f, 0.f};
-    if (o == 0) {
-        const int offv[2] = {kPartVec + 4 * 256, kPartVec + 1 * 256 + op};       // sum g: product 1; q: product 0
-        const int ksv[2] = {a.splits[1], a.splits[0]};
-        part_sums<2>(a.partials, ksv, net, offv, sq);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, kh = lane >> 5;
+    const int o0 = 32 * rt, i0 = 32 * ct;
+    const float* S1 = a.scratch_s1 + ((int64_t)net * 256 + o0 + col) * 256;
+    const float* S2 = a.scratch_s2 + ((int64_t)net * 256 + o0 + col) * kPe;
+    const float* w2 = P.w2b2 + (int64_t)(i0 + col) * P.ld_w2b2;
+    const float* Wd = P.Wd + (i0 + col) * kPe;
+    f32x4u a1[8], b1[8], a2[6], b2[6];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int k = 64 * wv + 8 * m + 4 * kh;
+        a1[m] = *reinterpret_cast<const f32x4u*>(S1 + k);
+        b1[m] = *reinterpret_cast<const f32x4u*>(w2 + k);
     }
-    const float r = a.scratch_r[net * 256 + o];
-    const float wop = P.wo[op];
-    Gd.W2[op * 256 + o] = wop * r;
-    red[o] = P.W2[op * 256 + o] * r;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        const int k = 48 * wv + 8 * m + 4 * kh;
+        a2[m] = *reinterpret_cast<const f32x4u*>(S2 + k);
+        b2[m] = *reinterpret_cast<const f32x4u*>(Wd + k);
+    }
+    f32x16 acc = (f32x16)0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma_f32_32x32x2(a1[m][e], b1[m][e], acc);
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma_f32_32x32x2(a2[m][e], b2[m][e], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv][r][lane] = acc[r];
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (o < s) red[o] += red[o + s];
-        __syncthreads();
-    }
-    if (o == 0) {
-        const float s = sq[0], q = sq[1];
-        Gd.bf2[op] = wop * s;
-        Gd.wo[op] = red[0] + P.bf2[op] * s + 2.f * q;
-        if (op == 0) Gd.bo[0] = s;
+    const int i = i0 + col;
+    const float cv = P.w2b2[(int64_t)i * P.ld_w2b2 + 256] + P.bd[i] + P.evec[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wv + 4 * q;                                         // element (r, lane) of the tile: row drow32(r, kh), column col
+        const int o = o0 + drow32(r, kh);
+        const float G = ((red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane])) + a.scratch_mv[net * 256 + o] * cv;
+        Gd.W1[o * 256 + i] = a.scratch_u[net * 256 + o] * G;
+        float rp = P.W1[o * 256 + i] * G;                                 // this tile's part of r[o]: the 32 columns sit on the 32 lanes of a half-wave
+#pragma unroll
+        for (int sft = 16; sft > 0; sft >>= 1) rp += __shfl_xor(rp, sft);
+        if (col == 0) a.scratch_rp[((int64_t)net * 8 + ct) * 256 + o] = rp;
     }
 }
 
-// ONE launch for the two independent consumers of dpn_finish_rows_kernel's results: blocks 0..119 = the W1^T diag(u) factor (what the
-// hyper-network's backward waits for), blocks 120..375 = the rank-1 fc.2 gradients -- side by side instead of one behind the other
-constexpr int kVsideBlocks = 8 * 15;
-__global__ __launch_bounds__(256) void dpn_finish_vside_fc2_kernel(FinishArgs a) {
-    __shared__ float red[4][16][64];
-    __shared__ float qs[32];
-    if ((int)blockIdx.x < kVsideBlocks) finish_vside_body(a, blockIdx.x, red, qs);
-    else finish_fc2_body(a, blockIdx.x - kVsideBlocks, &red[0][0][0]);
+// one block per (row o', net): r, then dW2 = wo (x) r, dbf2, dwo (with colsum(Z) = w2 q1 + Wd q6 + sum g cvec), dbo, dbf1
+__global__ __launch_bounds__(256) void dpn_finish_fc2_kernel(FinishArgs a) {
+    __shared__ float red[2][256];
+    const int net = blockIdx.y, op = blockIdx.x, o = threadIdx.x;
+    const DpnNetPtrs& P = a.net[net];
+    const DpnNetGradPtrs& Gd = a.grad[net];
+    const float* rp = a.scratch_rp + (int64_t)net * 8 * 256 + o;
+    const float mv = a.scratch_mv[net * 256 + o];
+    const float r = (((rp[0] + rp[256]) + (rp[512] + rp[768])) + ((rp[1024] + rp[1280]) + (rp[1536] + rp[1792]))) + P.bf1[o] * mv;
+    const float wop = P.wo[op];
+    Gd.W2[op * 256 + o] = wop * r;
+    red[0][o] = P.W2[op * 256 + o] * r;
+    red[1][o] = a.scratch_q1[net * 256 + o] * P.w2b2[(int64_t)op * P.ld_w2b2 + o] + (o < kPe ? a.scratch_q6[net * 256 + o] * P.Wd[op * kPe + o] : 0.f);
+    if (op == 0) Gd.bf1[o] = a.scratch_u[net * 256 + o] * mv;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (o < s) { red[0][o] += red[0][o + s]; red[1][o] += red[1][o + s]; }
+        __syncthreads();
+    }
+    if (o == 0) {
+        const float sg = a.scratch_sg[net];
+        const float cv = P.w2b2[(int64_t)op * P.ld_w2b2 + 256] + P.bd[op] + P.evec[op];
+        const float zsum = red[1][0] + sg * cv;                           // colsum(Z)[op]
+        Gd.bf2[op] = wop * sg;
+        Gd.wo[op] = red[0][0] + P.bf2[op] * sg + 2.f * zsum;
+        if (op == 0) Gd.bo[0] = sg;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ small fp32 GEMM
@@ -2256,24 +2271,27 @@ static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 // profiles/round3_wgrad_plans.txt): 10,11,10,11 327 us, 11,11,9,11 303 us, 10,10,9,13 277 us, 10,10,8,14 277 us, 9,9,8,16 280 us --
 // a plateau at 5.0 TB/s.  Single bf16 (rings of four and five): 10,11,10,11 156 us, 10,10,9,13 160-163 us.
 struct SplitPlan { int s[4]; int most; };
+// Round 5: three products (s[0] = 0: M2^T Z is gone, dpn_finish_gside_kernel).  The 42 ranges per net go to them in the proportions the
+// four-product plans had found (hi+lo 10,10,9,13 -> 13,12,17; single bf16 10,11,10,11 -> 14,13,15).
 static inline SplitPlan choose_plan(int64_t n_pad, int ns) {
     int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
     SplitPlan p;
-    if (c >= 10) p = (ns == 2) ? SplitPlan{{10, 10, 9, 13}, 13} : SplitPlan{{10, 11, 10, 11}, 11};
-    else p = SplitPlan{{(int)c, (int)c, (int)c, (int)c}, (int)c};
+    if (c >= 10) p = (ns == 2) ? SplitPlan{{0, 13, 12, 17}, 17} : SplitPlan{{0, 14, 13, 15}, 15};
+    else p = SplitPlan{{0, (int)c, (int)c, (int)c}, (int)c};
 #ifdef DPN_EXPERIMENT_SPLITS                     // timing experiments only: DPN_WGRAD_PLAN="9,12,10,11"
     if (const char* e = getenv("DPN_WGRAD_PLAN")) {
         if (sscanf(e, "%d,%d,%d,%d", &p.s[0], &p.s[1], &p.s[2], &p.s[3]) == 4) {
             p.most = 1;
-            for (int k = 0; k < 4; ++k) { if (p.s[k] < 1) p.s[k] = 1; if (p.s[k] > kMaxSplits) p.s[k] = kMaxSplits; if (p.s[k] > p.most) p.most = p.s[k]; }
+            p.s[0] = 0;
+            for (int k = 1; k < 4; ++k) { if (p.s[k] < 1) p.s[k] = 1; if (p.s[k] > kMaxSplits) p.s[k] = kMaxSplits; if (p.s[k] > p.most) p.most = p.s[k]; }
         }
     }
 #endif
     return p;
 }
 #endif  // DPN_HAS_REST
-constexpr int64_t kFinishScratchFloats = kNets * 256 + (int64_t)kNets * 65536 + (int64_t)kNets * 256 * 192 + kNets * 256;   // r | S1 | S2 | mv (FinishArgs)
+constexpr int64_t kFinishScratchFloats = (int64_t)kNets * 65536 + (int64_t)kNets * 256 * 192 + 4 * kNets * 256 + 8 + (int64_t)kNets * 8 * 256;   // S1 | S2 | mv | u | q1 | q6 | sum g | r parts (FinishArgs)
 static inline int ck(hipError_t e) { return (int)e; }
 
 extern "C" {
@@ -2445,15 +2463,18 @@ int dpn_wgrad(int64_t n, int prec, const float* g_out, const void* saved, const 
 #endif
     (void)g_out;   // the per-net cotangents were staged into `operands` by dpn_bwd_points
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid(plan.s[0] + plan.s[1] + plan.s[2] + plan.s[3], kNets);
+    const dim3 grid(plan.s[1] + plan.s[2] + plan.s[3], kNets);
     if (prec == 1) hipLaunchKernelGGL(dpn_wgrad_kernel<1>, grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL(dpn_wgrad_kernel<2>, grid, dim3(512), 0, s, a);
     return ck(hipGetLastError());
 }
 
-int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
-                     const DpnNetGradPtrs grads[DPN_NETS], void* stream) {
-    if (!nets || !packed || !partials || !grads || n <= 0 || (prec != 1 && prec != 2)) return -1;
+// parts: bit 0 = the hyper-network's half (dpn_finish_rows_kernel, dpn_finish_vside_kernel: d w1b1, d w2b2, d evec; dWd, d bd), bit 1 = the half
+// that ends in static tensors only (dpn_finish_gside_kernel, dpn_finish_fc2_kernel: d cat_fc1.fc.0 / fc.2, d out_fc) and reads what half 0 left in
+// the scratch tail of `partials`: same stream, or another one ordered behind half 0 (a side branch beside the encoder's backward)
+int dpn_wgrad_finish_parts(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
+                           const DpnNetGradPtrs grads[DPN_NETS], int parts, void* stream) {
+    if (!nets || !packed || !partials || !grads || n <= 0 || (prec != 1 && prec != 2) || !(parts & 3)) return -1;
     FinishArgs a;
     for (int k = 0; k < kNets; ++k) { a.net[k] = nets[k]; a.grad[k] = grads[k]; }
     a.packed = reinterpret_cast<const char*>(packed);
@@ -2463,14 +2484,29 @@ int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_
     a.ns = prec;
     a.n = n;
     // scratch in the tail of the partials buffer (dpn_sizes)
-    a.scratch_r = const_cast<float*>(a.partials) + (int64_t)plan.most * kNets * kPartFloats;
-    a.scratch_s1 = a.scratch_r + kNets * 256;
+    a.scratch_s1 = const_cast<float*>(a.partials) + (int64_t)plan.most * kNets * kPartFloats;
     a.scratch_s2 = a.scratch_s1 + (int64_t)kNets * 65536;
     a.scratch_mv = a.scratch_s2 + (int64_t)kNets * 256 * 192;
+    a.scratch_u = a.scratch_mv + kNets * 256;
+    a.scratch_q1 = a.scratch_u + kNets * 256;
+    a.scratch_q6 = a.scratch_q1 + kNets * 256;
+    a.scratch_sg = a.scratch_q6 + kNets * 256;
+    a.scratch_rp = a.scratch_sg + 8;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(dpn_finish_vside_fc2_kernel, dim3(kVsideBlocks + 256, kNets), dim3(256), 0, s, a);
+    if (parts & 1) {
+        hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(dpn_finish_vside_kernel, dim3(kVsideBlocks, kNets), dim3(256), 0, s, a);
+    }
+    if (parts & 2) {
+        hipLaunchKernelGGL(dpn_finish_gside_kernel, dim3(64, kNets), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
+    }
     return ck(hipGetLastError());
+}
+
+int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n, int prec, const void* partials,
+                     const DpnNetGradPtrs grads[DPN_NETS], void* stream) {
+    return dpn_wgrad_finish_parts(nets, packed, n, prec, partials, grads, 3, stream);
 }
 
 int dpn_sgemm(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,

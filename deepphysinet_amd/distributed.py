@@ -32,7 +32,11 @@ def init_from_env(backend=None, force=False):
         try:
             if backend == 'nccl':
                 torch.cuda.set_device(local)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            import datetime
+            # a collective that never completes (a rank died, a link is down) must END the job with the rank named, not hang it: the process
+            # group's own timeout (DPN_PG_TIMEOUT_S, default 600 s) backs the host-side watchdog below
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=float(os.environ.get('DPN_PG_TIMEOUT_S', '600'))))
             if backend == 'nccl':
                 # the first collective is where a wrong IPC mode shows (hipIpcGetMemHandle: invalid argument): fail HERE, with the setting named
                 probe = torch.ones(1, device=torch.device('cuda', local))
@@ -71,8 +75,45 @@ def _all_reduce_mean(flat, world, group, async_op):
     return None
 
 
+class Watchdog:
+    """Host-side progress watchdog of a multi-rank loop: `beat(what)` after every unit of progress; when no beat arrives for `timeout_s`
+    the thread prints which rank is stuck, in what (the label of the last beat and the last bucket a GradientAllReduce queued), and ends
+    the PROCESS with exit code 13 -- the launcher (torch.distributed.run) then tears the other ranks down.  It never re-executes anything
+    (a process that has touched the GPU must not exec on this platform); it only exits."""
+
+    def __init__(self, timeout_s=300.0, rank=0, sync=None, out=None):
+        import sys
+        import threading
+        import time
+        self.timeout_s, self.rank, self.sync = float(timeout_s), rank, sync
+        self.out = out or sys.stderr
+        self._last, self._what, self._stop = time.monotonic(), 'start', threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def beat(self, what=''):
+        import time
+        self._last, self._what = time.monotonic(), what
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        import time
+        while not self._stop.wait(min(1.0, self.timeout_s / 4)):
+            idle = time.monotonic() - self._last
+            if idle > self.timeout_s:
+                bucket = getattr(self.sync, 'last_queued', None)
+                print('[deepphysinet_amd.distributed] rank %d made no progress for %.0f s (last: %s; last all-reduce queued: %s) -- a collective '
+                      'is not completing; exiting with code 13' % (self.rank, idle, self._what,
+                                                                    'buckets %s of the flat gradient buffer' % (bucket,) if bucket else 'none'),
+                      file=self.out, flush=True)
+                os._exit(13)
+
+
 class GradientAllReduce:
     def __init__(self, optimizer=None, bucket_mb=32.0, group=None, single_rank_too=False):
+        self.last_queued = None
         self.opt = optimizer
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
         self.group = group
@@ -109,14 +150,24 @@ class GradientAllReduce:
             return
         self._check_layout()
         a, b = self.opt.bucket_bounds[i][0], self.opt.bucket_bounds[(i + 1 if end is None else end) - 1][1]
+        self.last_queued = (i, i + 1 if end is None else end)
         w = _all_reduce_mean(self.opt.flat_gradients()[a:b], dist.get_world_size(self.group), self.group, async_op)
         if w is not None and async_op:
             self._work.append(w)
 
-    def wait(self):
-        """The current stream waits for every queued bucket."""
+    def wait(self, events=None):
+        """The current stream waits for every queued bucket.  events (a list): a HIP event pair is recorded around each bucket's wait and
+        appended to it -- the time between the two on the waiting stream is the part of that all-reduce the backward pass did NOT hide
+        (bench.py: `collective.exposed_us`)."""
         for w in self._work:
-            w.wait()
+            if events is not None and torch.cuda.is_available():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                w.wait()
+                e1.record()
+                events.append((e0, e1))
+            else:
+                w.wait()
         self._work = []
 
     # ---- entry point ---------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
+from . import branch, config
 from .grad_arena import new_grad
 
 
@@ -155,7 +156,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
         # BASELINE configs[4] experiment, off in the product: the six forward GEMMs of the layer on the fp8 matrix cores (csrc/dpn_fp8.hip)
         # ('1': per-row scales, v_mfma_f32_32x32x16_fp8_fp8; 'mx': one E8M0 scale per 32 k, v_mfma_scale_f32_32x32x64_f8f6f4)
-        fp8_mode = os.environ.get('DPN_ENCODER_FP8')
+        fp8_mode = config.FROZEN.encoder_fp8
         fp8 = fp8_mode in ('1', 'mx')
 
         def gemm8(M, N, K, A, W, bias, C, epi=0, aux_out=None):
@@ -288,7 +289,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
             n_parts = 16
             emb_parts = torch.empty((n_parts, B * T, D), dtype=torch.float32, device=dev)
             L.check(lib.dpn_conv16(_p(xs), _p(xe), _p(ws), _p(we), B * T, D, Kp, n_parts, _p(emb_parts), _s()), 'dpn_conv16')
-        elif os.environ.get('DPN_EMBED_GEMM16') != '1':
+        elif not config.FROZEN.embed_gemm16:
             # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one exact-fp32 MFMA launch (24 us)
             parts = 16
             ks = (K3 + parts - 1) // parts
@@ -309,7 +310,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
             # level; not the product path.  What would pay is operands split ONCE -- by dpn_enc_prep, per-row scales -- and a load-only
             # kernel; at 64 x 64 tiles that GEMM moves 74 MB through L2 for 1 GFLOP.)
             tiles = ((B * T + 63) // 64) * ((D + 63) // 64)
-            n_parts = int(os.environ.get('DPN_EMBED_PARTS', '0')) or max(1, min(38, 456 // tiles))
+            n_parts = config.FROZEN.embed_parts or max(1, min(38, 456 // tiles))
             q = L.DpnGemm16Problem()
             emb_parts = torch.empty((n_parts, B * T, D), dtype=torch.float32, device=dev)
             q.A, q.B, q.C, q.M, q.N, q.K, q.ldc = _p(xu), _p(w2), _p(emb_parts), B * T, D, K3, D
@@ -325,7 +326,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
         ctx.n_tok, ctx.w_shape, ctx.tok_shape, ctx.B = n_tok, conv_w.shape, token.shape, B
         ctx.params = (conv_w, conv_b)
         ctx.share = share
-        if share is not None and B == 1 and os.environ.get('DPN_EMBED_OWN_WGRAD') != '1':
+        if share is not None and B == 1 and not config.FROZEN.embed_own_wgrad:
             # one field: the encoder stack's backward computes the token convolution's weight gradient inside ITS weight-gradient launch
             # (dW = (d x0 rows of the field tokens)^T xu: both operands exist there) and hands it back through `share`
             share.embed = dict(xu=xu, n_tok=n_tok, conv_w=conv_w, conv_b=conv_b, token=token, grads=None, g_tok=None)
@@ -347,7 +348,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
             g_tok = g_tok.view(ctx.tok_shape) if g_tok is not None else g3[:, :ctx.n_tok].reshape(ctx.tok_shape)
             return None, dw.view(ctx.w_shape), db, g_tok, None, None, None, None, None, None
         dw, db = new_grad(ctx.params[0], (D, K3)), new_grad(ctx.params[1])
-        if os.environ.get('DPN_ENCODER_UNFUSED') == '1':
+        if config.FROZEN.encoder_unfused:
             batch = []
             _wgrad(batch, D, K3, n, g_emb, D, xu, K3, dw, db)
             if batch:
@@ -403,7 +404,7 @@ class _HeadsFn(torch.autograd.Function):
         dev = m3.device
         heads = torch.empty((B, 256, HEADS_COLS), dtype=torch.float32, device=dev)
         evec = torch.empty((B, 6, 256), dtype=torch.float32, device=dev)
-        mode = os.environ.get('DPN_HEADS_PER_FIELD', '0')         # A/B measurements: 1 = the per-field launches of rounds 1-3; fwd / bwd = only that pass per field
+        mode = config.FROZEN.heads_per_field         # A/B measurements: 1 = the per-field launches of rounds 1-3; fwd / bwd = only that pass per field
         ctx.per_field_bwd = B > 1 and mode in ('1', 'bwd')
         if B > 1 and mode not in ('1', 'fwd'):
             # B fields: ONE launch over all of them (it was one per field: 61 launches of 15 us at configs[2]).  The encoder output of the
@@ -482,7 +483,7 @@ class _HeadsFn(torch.autograd.Function):
         # d meta as NP accumulated-term problems side by side, joined by dpn_sum_parts: 6 two-term problems (with the 12 weight gradients and
         # the 6 outer products exactly the 24 problems a launch takes).  Same box, 300-step runs, three times each: NP = 2 1.614 ms per
         # step, 3 1.591, 4 1.614 (rounds 1-3), 6 1.580
-        NP = int(os.environ.get('DPN_HEADS_DMETA_PARTS', '6'))
+        NP = config.FROZEN.heads_dmeta_parts
         if NP not in (1, 2, 3, 4, 6, 12):
             raise ValueError('DPN_HEADS_DMETA_PARTS must divide the twelve heads (1, 2, 3, 4, 6 or 12), got %d' % NP)
         parts = torch.empty((NP, 256, 256), dtype=torch.float32, device=dev)
@@ -647,7 +648,7 @@ class _EncoderStackFn(torch.autograd.Function):
         n_mats = 6 * nl + (1 if final else 0)                        # 6 l + (q, k, v, o, c1, c2), then the projection
         if wpack is None:                                            # (encoder_prep has packed them when the whole encoder runs fused)
             wpack = enc_pack(_stack_matrices(lay, fin))
-        rt = int(os.environ.get('DPN_ENC_ROW_TILES', '0')) or (1 if n <= 2048 else 2)
+        rt = config.FROZEN.enc_row_tiles or (1 if n <= 2048 else 2)
         stream = _s()
 
         def fwd(**kw):
@@ -663,7 +664,7 @@ class _EncoderStackFn(torch.autograd.Function):
         for l in range(nl):
             p_ = lay[l]
             o, P = new(n, D), new(B * 8, 288, 288)
-            attn = lib.dpn_attn_fwd if os.environ.get('DPN_ATTN_FWD') == 'fp32' else lib.dpn_attn16_fwd      # (round 3's exact-fp32 kernel: A/B runs)
+            attn = lib.dpn_attn_fwd if config.FROZEN.attn_fwd_fp32 else lib.dpn_attn16_fwd      # (round 3's exact-fp32 kernel: A/B runs)
             L.check(attn(_p(q), _p(k), _p(v), Lt, B, _p(o), _p(P), stream), 'dpn_attn_fwd')
             x1, xhat1, rstd1, pre, act, x2, xhat2, rstd2 = new(n, D), new(n, D), new(n), new(n, D), new(n, D), new(n, D), new(n, D), new(n)
             kw = dict(tail=1, o=o, x=x, m_o=6 * l + 3, m_c1=6 * l + 4, m_c2=6 * l + 5, bo=p_[7], g1=p_[8], be1=p_[9], bc1=p_[11], bc2=p_[13],
@@ -735,6 +736,30 @@ class _EncoderStackFn(torch.autograd.Function):
             jobs.append((partial, dg, db, nb))
             grads[slot_g], grads[slot_b] = dg, db
         res = dq = dk = dv = None
+        from . import grad_arena
+        miss0 = grad_arena.misses[0]
+        # Per-layer weight gradients on the side branch (branch.py): a layer's (G, X) pairs are complete once its attention backward is queued,
+        # four launches before the chain ends; only the token convolution's product (it needs d x0) stays behind the last launch.  Only for a
+        # single field's row count (batches cut the reductions into slices: their own second launch) and only while every gradient so far is a
+        # fresh slot of the optimiser's flat buffer (autograd keeps such a view as param.grad without touching it on the main stream).
+        may_fork = branch.enabled() and n <= 2048
+
+        def flush(on_side):
+            nonlocal batch, jobs, keep
+            if on_side and not (may_fork and grad_arena.misses[0] == miss0):
+                return                                               # no branch: everything in ONE launch at the end, as before
+            while batch or jobs:
+                b_, batch = batch[:L.WGRAD_MAX_PROBLEMS], batch[L.WGRAD_MAX_PROBLEMS:]
+                j_, jobs = jobs[:L.GEMM_MAX_JOBS], jobs[L.GEMM_MAX_JOBS:]
+                if on_side:
+                    # keep: the operands (G, X, LayerNorm partials) -- NOT the gradient outputs: they are slots of the optimiser's flat buffer
+                    # (persistent), and a second reference would make autograd copy each of them instead of keeping the view as param.grad
+                    with branch.side(keep=tuple(keep)):
+                        wgrad16(b_, j_)
+                else:
+                    keep.append(wgrad16(b_, j_))
+            if on_side:
+                keep = []
         for l in range(nl - 1, -1, -1):
             x, q, k, v, o, P, x1, xhat1, rstd1, pre, act, xhat2, rstd2 = lsaved[l]
             gs2, dpre, gs1, do = new(n, D), new(n, D), new(n, D), new(n, D)
@@ -765,6 +790,7 @@ class _EncoderStackFn(torch.autograd.Function):
             wgrad(base + 2, base + 3, D, dk, x)
             wgrad(base + 4, base + 5, D, dv, x)
             res = gs1
+            flush(True)
         dx0 = new(n, D)
         emb = getattr(ctx.share, 'embed', None) if ctx.share is not None else None
         if emb is not None and B == 1 and n < 1024 and emb.get('token') is not None:
@@ -784,10 +810,7 @@ class _EncoderStackFn(torch.autograd.Function):
             emb['grads'] = (dwt, dbt)
         # every weight gradient of the stack and the LayerNorm parameter sums: ONE launch (dpn_wgrad16; plus its slice reduction for batches
         # of fields)
-        while batch or jobs:
-            b_, batch = batch[:L.WGRAD_MAX_PROBLEMS], batch[L.WGRAD_MAX_PROBLEMS:]
-            j_, jobs = jobs[:L.GEMM_MAX_JOBS], jobs[L.GEMM_MAX_JOBS:]
-            keep.append(wgrad16(b_, j_))
+        flush(False)
         del keep
         return (dx0, None, None, None, None, None, None, *grads)
 
@@ -819,7 +842,7 @@ def _layer_fits(layer):
 
 
 def _stack_fits(layers, norm, projection):
-    if os.environ.get('DPN_ENCODER_FP8') in ('1', 'mx') or os.environ.get('DPN_ENCODER_UNFUSED') == '1' or len(layers) < 1:
+    if config.FROZEN.encoder_fp8 or config.FROZEN.encoder_unfused or len(layers) < 1:
         return False
     if not all(_layer_fits(l_) and not getattr(l_.attention.inner_attention, 'output_attention', False) for l_ in layers):
         return False
@@ -867,7 +890,7 @@ def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
     L.check(lib.dpn_enc_prep(ctypes.byref(q), _s()), 'dpn_enc_prep')
     out.te = te.view(-1) if B == 1 else te
     conv = emb_module.value_embedding.tokenConv
-    if os.environ.get('DPN_CONV16') == '1' and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and tuple(conv.weight.shape[1:]) == (C, 3):
+    if config.FROZEN.conv16 and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and tuple(conv.weight.shape[1:]) == (C, 3):
         # EXPERIMENT: the token convolution's operands split into f16 hi / lo fragment images with one power-of-two scale per row (dpn_conv16).
         # Measured: the GEMM 23.7 -> 11.2 us, the split 12-16 us -- no gain; not the product path.
         Kp, n_out = int(lib.dpn_conv16_kp(3 * C)), conv.weight.shape[0]
@@ -908,7 +931,7 @@ def encoder_stack_fused(x, layers, norm=None, projection=None, wpack=None, share
     modules do not fit the kernels (8 heads x 32, d_ff = 256, gelu, affine LayerNorms with eps 1e-5, L <= 288)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 256 and x.shape[1] <= 288 and len(layers) >= 1):
         return None
-    if os.environ.get('DPN_ENCODER_FP8') in ('1', 'mx') or os.environ.get('DPN_ENCODER_UNFUSED') == '1':
+    if config.FROZEN.encoder_fp8 or config.FROZEN.encoder_unfused:
         return None
     if not all(_layer_fits(l_) and not getattr(l_.attention.inner_attention, 'output_attention', False) for l_ in layers):
         return None

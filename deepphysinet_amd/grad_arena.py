@@ -20,6 +20,7 @@ param_epoch = [0]     # bumped by every fused optimiser step (parameters rewritt
 captured_step = [False]   # a fused optimiser step was captured in a hipGraph: its replays rewrite the parameters WITHOUT bumping param_epoch,
                           # so parameter-keyed caches (PhysicsNet.encode_field(use_cache=True)) may only be trusted inside a capture
 _slots = {}          # param data_ptr -> (weakref(owner), weakref(param), offset, numel)
+misses = [0]         # new_grad calls that did NOT get an arena slot (branch.py forks a gradient launch only when every output is a fresh slot)
 
 
 def register(owner, params, offsets):
@@ -60,4 +61,5 @@ def new_grad(param_like, shape=None):
     s = slot_of(param_like)
     if s is not None:
         return s.view(shape)
+    misses[0] += 1
     return torch.empty(shape, dtype=torch.float32, device=param_like.device)

@@ -17,6 +17,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
+from . import branch, config
 from .grad_arena import new_grad, slot_of
 
 # configs/DeepPhysiNet_NCEP_cfg.py:64-76 -- order u10, v10, pres, t2, q2, rio (network output order)
@@ -150,12 +151,15 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     return out_n, jac_n
 
 
-def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics, into=None):
+def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics, into=None, fork=False, keep=()):
     """Weight gradients from per-point cotangents.  Returns (g_heads [256,2700], g_evec [6,256], [48 static grads]); `into` = the same
     triple preallocated by the caller (a batch of fields writes each field's gradients side by side).
 
-    (A two-stream form -- the static tensors' products on a side stream beside the encoder's backward chain -- was built and measured in
-    round 3: no gain, profiles/round3_two_stream_wgrad.txt; removed.)"""
+    fork (callers inside an autograd backward pass): the finish stage's second half -- G = S1 w2^T + S2 Wd^T + ..., the gradients of
+    cat_fc1.fc.0 / fc.2 and out_fc, static tensors that nothing in the backward pass reads -- goes to the side branch (branch.py) and runs
+    beside the hyper-network's and the encoder's backward; `keep` = what that branch reads through raw pointers besides the buffers here.
+
+    (Round 3 had tried a two-stream form with half of dpn_wgrad itself on the side stream: no gain, profiles/round3_two_stream_wgrad.txt.)"""
     lib = L.load()
     n = coord_data.shape[0]
     dev = coord_data.device
@@ -180,7 +184,16 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
         g_heads, g_evec, g_stat = into
     garr = _net_ptrs(g_heads, g_evec, g_stat, cls=L.DpnNetGradPtrs)
     L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
-    L.check(lib.dpn_wgrad_finish(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, _stream()), 'dpn_wgrad_finish')
+    # (only when every static gradient is a freshly leased slot of the optimiser's flat buffer: autograd then keeps the view as param.grad without
+    # touching it; a gradient it would have to ADD to an existing one on the main stream must be complete when the node returns)
+    if fork and arena and branch.enabled():
+        L.check(lib.dpn_wgrad_finish_parts(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, 1, _stream()), 'dpn_wgrad_finish')
+        # keep: what the branch READS (not the 48 gradient slots: they are persistent, and a second reference to a returned gradient makes
+        # autograd copy it instead of keeping the view as param.grad)
+        with branch.side(keep=(partials, ws.packed, statics) + tuple(keep)):
+            L.check(lib.dpn_wgrad_finish_parts(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, 2, _stream()), 'dpn_wgrad_finish')
+    else:
+        L.check(lib.dpn_wgrad_finish(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, _stream()), 'dpn_wgrad_finish')
     return g_heads, g_evec, g_stat
 
 
@@ -266,7 +279,7 @@ class _PointFieldsFn(torch.autograd.Function):
         if not any(ctx.needs_input_grad[6:]):
             return (None, None, None, None, g_pe) + (None,) * (3 + len(st))
         nets = _net_ptrs(hd_, ev_, st)
-        ghd, gev, gst = _backward_points(ctx.cfg, ctx.ws, nets, x_, y_, t_, pe_, cd_, g, None, st)
+        ghd, gev, gst = _backward_points(ctx.cfg, ctx.ws, nets, x_, y_, t_, pe_, cd_, g, None, st, fork=True, keep=(hd_, ev_))
         return (None, None, None, None, g_pe, None, ghd, gev, *gst)
 
 
@@ -317,7 +330,7 @@ class _PdeLossFn(torch.autograd.Function):
         L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), _ptr(gl), _ptr(gt), None,
                                  _ptr(g_out), _ptr(g_jxi), _stream()), 'dpn_residual(grad)')
         nets = _net_ptrs(hd_, ev_, st)
-        ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st)
+        ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st, fork=True, keep=(hd_, ev_))
         return (None, None, None, None, None, None, ghd, gev, *gst)
 
 
@@ -334,7 +347,6 @@ class _PdeLossBatchFn(torch.autograd.Function):
     at 61 this way; the 61-field step 80.5 -> 78.6 ms on the same box.  A
     cotangent on the individual loss terms (not only on the totals) takes the general path: forward again, field by field."""
 
-    EAGER = os.environ.get('DPN_BATCH_EAGER_BACKWARD', '1') == '1'
 
     @staticmethod
     def _static_layout():
@@ -357,7 +369,7 @@ class _PdeLossBatchFn(torch.autograd.Function):
         # Function.forward always runs with grad mode off: the caller's mode arrives as an argument (pde_losses_batch), so that a no-grad
         # evaluation (validation, place_lead_batch scoring) neither saves state nor runs each field's point backward
         need_grad = bool(grad_enabled) and any(v.requires_grad for v in (heads, evec) + tuple(statics))
-        eager = need_grad and _PdeLossBatchFn.EAGER
+        eager = need_grad and config.FROZEN.batch_eager_backward
         losses7 = torch.empty((B, 7), dtype=torch.float32, device=dev)
         sums = torch.empty(((n + 255) // 256) * 6, dtype=torch.float64, device=dev)
         geo, ph = cfg.geometry(), cfg.physics()
@@ -509,7 +521,7 @@ class _StepLossFn(torch.autograd.Function):
             L.check(lib.dpn_smooth_l1(_ptr(out_n[n_inter:]), _ptr(lab_), n_m, ctx.beta, ctx.margin_factor / (6.0 * n_m), None,
                                       _ptr(g_out[n_inter:]), 1, _ptr(_f32c(g_data).reshape(1)), _stream()), 'dpn_smooth_l1(grad)')
         nets = _net_ptrs(hd_, ev_, st)
-        ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st)
+        ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st, fork=True, keep=(hd_, ev_))
         return (None,) * 10 + (ghd, gev, *gst)
 
 

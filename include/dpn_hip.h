@@ -131,10 +131,18 @@ int dpn_bwd_points(const float* x, const float* y, const float* t, const float* 
 /* Backward, stage 2: weight-gradient reductions over points (split-K partial sums). */
 int dpn_wgrad(int64_t n_points, int prec, const float* g_out, const void* saved, const void* operands, void* partials, void* stream);
 
-/* Backward, stage 3: reduce the partial sums, undo the fragment permutations, apply the 256 x 256 factor W1^T diag(u) to the two mask-side
- * sums (d w2b2, d Wd: csrc SavedView) and assemble every gradient of DpnNetPtrs (incl. the rank-1 cat_fc1.fc.2 gradients). */
+/* Backward, stage 3: reduce the partial sums, undo the fragment permutations and assemble every gradient of DpnNetPtrs from the three
+ * points-reduction products S1 = M2^T Z1, S2 = M2^T G6, dw1 = T1^T Z0 and their vector sums (interface_physics.py:506, the backward of
+ * variable_net.py:49-87):  d w2b2 / d Wd = W1^T diag(u) S + 2 wo (x) colsum (csrc SavedView);  d cat_fc1.fc.0.weight = diag(u) G with
+ * G = M2^T Z = S1 w2^T + S2 Wd^T + (M2^T g) (x) (b2 + bd + e) -- Z itself is never formed per point (csrc dpn_finish_gside_kernel);
+ * the rank-1 cat_fc1.fc.2 / out_fc gradients follow from r = rowdot(W1, G) + bf1 (.) M2^T g. */
 int dpn_wgrad_finish(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n_points, int prec,
                      const void* partials, const DpnNetGradPtrs grads[DPN_NETS], void* stream);
+/* The same in two halves.  parts bit 0: what the hyper-network's backward waits for (d w1b1, d w2b2, d evec; d Wd and d bd ride along);
+ * parts bit 1: the gradients of cat_fc1.fc.0 / fc.2 and out_fc (static tensors only).  Half 1 reads what half 0 left in the scratch tail of
+ * `partials`: issue it on the same stream, or on another one ordered behind half 0 (a branch beside the encoder's backward chain). */
+int dpn_wgrad_finish_parts(const DpnNetPtrs nets[DPN_NETS], const void* packed, int64_t n_points, int prec,
+                           const void* partials, const DpnNetGradPtrs grads[DPN_NETS], int parts, void* stream);
 
 /* SmoothL1(beta) data loss on the normalised fields (losses/weights_loss.py:17-20): per-block sums -> loss_sum[ceil(6N/256)] (fp64,
  * written not accumulated; the caller adds them in a fixed order), g_out = scale * dSmoothL1 (may be NULL). */

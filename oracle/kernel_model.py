@@ -153,7 +153,14 @@ def residuals(out_n, jn, f, with_clip=True, factors=O.LOSS_FACTOR):
 
 
 def phase_b(W, S, pe, dpe, pe6, gout, gjxi, prec):
-    """Parameter gradients of one net from per-point cotangents gout [N] (on out) and gjxi [N,3] (on J_xi)."""
+    """Parameter gradients of one net from per-point cotangents gout [N] (on out) and gjxi [N,3] (on J_xi).
+
+    Round 5: every product with the second ReLU mask on the X side factors through the mask-side sums
+        S1 = M2^T Z1 [256, 256],  S2 = M2^T (g pe6) [256, 192],  mvec = M2^T g,   q1 = colsum(Z1), q6 = colsum(g pe6), sg = sum g
+    (the only points-reduction GEMMs left besides dw1 = T1^T Z0):
+      * Z = Z1 w2^T + (g pe6) Wd^T + g cvec^T is LINEAR in (Z1, g pe6, g), so G = M2^T Z = S1 w2^T + S2 Wd^T + mvec (x) cvec and
+        colsum(Z) = q1 w2^T + q6 Wd^T + sg cvec: neither Z nor the product M2^T Z is ever formed per point (csrc: dpn_finish_gside);
+      * v = W1^T (m2 (.) u) + 2 wo is affine in the mask (round 3), so V^T Z1 = W1^T diag(u) S1 + 2 wo (x) q1, likewise with g pe6."""
     w1, b1, w2 = W['w1b1'][:, :192], W['w1b1'][:, 192], W['w2b2'][:, :256]
     N = pe.shape[0]
     pt = (dpe * gjxi[:, None, None, :]).reshape(N, -1)                 # sum_c gJ_c * dpe_c  (disjoint channels)
@@ -161,20 +168,23 @@ def phase_b(W, S, pe, dpe, pe6, gout, gjxi, prec):
     Z1 = S['m1'] * (mm(Z0, w1.T, prec) + gout[:, None] * b1)
     gpe6 = gout[:, None] * pe6
     cvec = W['w2b2'][:, 256] + W['bd'] + W['e']
-    Z = mm(Z1, w2.T, prec) + mm(gpe6, W['Wd'].T, prec) + gout[:, None] * cvec
-    G = mm(S['m2'].T, Z, prec)                                          # [256 o, 256 i]
+    S1 = mm(S['m2'].T, Z1, prec)                                        # [256 o, 256 j]
+    S2 = mm(S['m2'].T, gpe6, prec)                                      # [256 o, 192 k]
     mvec = S['m2'].T @ gout
+    q1, q6, sg = Z1.sum(0), gpe6.sum(0), gout.sum()
+    G = S1 @ w2.T + S2 @ W['Wd'].T + mvec[:, None] * cvec[None, :]      # = M2^T Z, exact-fp32 GEMM once per net
+    zsum = w2 @ q1 + W['Wd'] @ q6 + sg * cvec                           # = colsum(Z)
     u = S['u']
-    sg = gout.sum()
     r = (W['W1'] * G).sum(1) + W['bf1'] * mvec
-    gcvec = S['v'].T @ gout
+    W1u = W['W1'].T * u[None, :]                                        # W1^T diag(u)
+    gcvec = W1u @ mvec + 2.0 * W['wo'] * sg                             # = V^T g
     grads = {
         'W1': u[:, None] * G, 'bf1': u * mvec,
         'W2': W['wo'][:, None] * r[None, :], 'bf2': W['wo'] * sg,
-        'wo': W['W2'] @ r + W['bf2'] * sg + 2.0 * Z.sum(0), 'bo': sg,
+        'wo': W['W2'] @ r + W['bf2'] * sg + 2.0 * zsum, 'bo': sg,
         'w1b1': torch.cat([mm(S['t1'].T, Z0, prec), (S['t1'].T @ gout)[:, None]], 1),
-        'w2b2': torch.cat([mm(S['v'].T, Z1, prec), gcvec[:, None]], 1),
-        'Wd': mm(S['v'].T, gpe6, prec), 'bd': gcvec, 'e': gcvec,
+        'w2b2': torch.cat([W1u @ S1 + 2.0 * W['wo'][:, None] * q1[None, :], gcvec[:, None]], 1),
+        'Wd': W1u @ S2 + 2.0 * W['wo'][:, None] * q6[None, :], 'bd': gcvec, 'e': gcvec,
     }
     return grads
 

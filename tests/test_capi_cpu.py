@@ -41,9 +41,9 @@ def test_sizes_host_function():
     assert lib.dpn_sizes(37265, 2, ctypes.byref(sz2)) == 0
     assert sz2.saved > sz.saved and sz2.operands > sz.operands
     # point ranges of the weight-gradient kernel: a per-product plan that fills one round of the chip at full size (42 workgroups per
-    # net: 10,11,10,11 ranges in single bf16, 10,10,9,13 in the hi+lo mode), one range per 16 tiles below that
-    # k_splits (the most ranges one product is cut into) dimensions the partial-sum buffer
-    assert sz.k_splits == 11 and sz2.k_splits == 13
+    # net over the three products M2^T Z1, M2^T G6, T1^T Z0: 14,13,15 ranges in single bf16, 13,12,17 in the hi+lo mode), one range per 16
+    # tiles below that; k_splits (the most ranges one product is cut into) dimensions the partial-sum buffer
+    assert sz.k_splits == 15 and sz2.k_splits == 17
     small = _lib.DpnSizes()
     assert lib.dpn_sizes(1037, 2, ctypes.byref(small)) == 0 and small.k_splits == 2
     assert lib.dpn_sizes(256, 1, ctypes.byref(small)) == 0 and small.k_splits == 1

@@ -267,3 +267,29 @@ def test_rank_aware_sample_callable_is_used_as_is():
     assert list(d._epoch_samples({'samples': own}, 5, 0, 2)) == ['r0'] and calls[-1] == (5, 0, 2)
     every = lambda epoch: ['a', 'b', 'c']
     assert list(d._epoch_samples({'samples': every}, 0, 1, 2)) == ['b', 'b'] or list(d._epoch_samples({'samples': every}, 0, 1, 2)) == ['b', 'a']
+
+
+def test_watchdog_ends_a_stuck_rank_with_its_name_and_bucket():
+    """bench.py --gpus N / the data-parallel loop: a collective that never completes must end the job with the stuck rank and the bucket it last
+    queued named (exit code 13), not hang it.  The watchdog only ever EXITS the process -- no exec."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, time; sys.path.insert(0, %r)\n'
+            'from deepphysinet_amd.distributed import Watchdog\n'
+            'class S: last_queued = (2, 3)\n'
+            'w = Watchdog(0.4, rank=5, sync=S())\n'
+            'w.beat("a block of 20 steps")\n'
+            'time.sleep(30)\n' % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 13, (r.returncode, r.stderr[-500:])
+    assert 'rank 5' in r.stderr and 'a block of 20 steps' in r.stderr and '(2, 3)' in r.stderr
+    # a loop that keeps beating is left alone, and stop() ends the thread
+    code2 = ('import sys, time; sys.path.insert(0, %r)\n'
+             'from deepphysinet_amd.distributed import Watchdog\n'
+             'w = Watchdog(0.5, rank=0)\n'
+             'for _ in range(12):\n'
+             '    time.sleep(0.1); w.beat("x")\n'
+             'w.stop(); time.sleep(1.0); print("alive")\n' % ROOT)
+    r2 = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0 and 'alive' in r2.stdout, (r2.returncode, r2.stderr[-500:])

@@ -544,14 +544,11 @@ def test_lead_batch_backward_paths_agree():
 
     def run(eager, through_terms):
         heads, evec = heads0.clone().requires_grad_(True), evec0.clone().requires_grad_(True)
-        old = PP._PdeLossBatchFn.EAGER
-        PP._PdeLossBatchFn.EAGER = eager
-        try:
+        from deepphysinet_amd import config
+        with config.override(batch_eager_backward=eager):
             losses, totals = PP.pde_losses_batch(cfg, x, y, t, f, cd, heads, evec, statics)
             obj = (losses.sum(dim=1) * wts).sum() if through_terms else (totals * wts).sum()
             got = torch.autograd.grad(obj, [heads, evec, statics[0], statics[2]])
-        finally:
-            PP._PdeLossBatchFn.EAGER = old
         return [v.detach().clone() for v in got]
 
     base = run(False, False)                                 # state parked, cotangents known before the point backward runs
@@ -1103,17 +1100,10 @@ def test_config4_fp8_encoder_workload():
     m = _model('bf16x2')
     g = _gpu(inp)
     got = {}
-    old = os.environ.get('DPN_ENCODER_FP8')
-    try:
-        for fp8 in ('0', '1'):
-            os.environ['DPN_ENCODER_FP8'] = fp8
-            with torch.no_grad():
-                got[fp8] = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).double().cpu().numpy()
-    finally:
-        if old is None:
-            os.environ.pop('DPN_ENCODER_FP8', None)
-        else:
-            os.environ['DPN_ENCODER_FP8'] = old
+    from deepphysinet_amd import config
+    for fp8 in ('0', '1'):
+        with config.override(encoder_fp8='1' if fp8 == '1' else ''), torch.no_grad():
+            got[fp8] = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).double().cpu().numpy()
     err_prod = np.abs(got['0'] - ref['parts']) / np.abs(ref['parts'])
     err_fp8 = np.abs(got['1'] - ref['parts']) / np.abs(ref['parts'])
     assert np.all(np.isfinite(got['1']))
@@ -1132,7 +1122,7 @@ def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n, prec):
     per SIMD owns 32 points and all output tiles, weights shared through an LDS-DMA ring) and the tile-split form (the default: output
     tiles split over the waves, activations shared through LDS, weights L2 -> VGPR, two workgroups per CU; csrc/dpn_fwd_tiles.h).  Both run
     the same products in the same order per output tile, so everything they hand to the later kernels -- the saved state T1, M2, m1,
-    the Jacobian, the operands Z1, Z, Z0, G6, gnet -- must agree BIT FOR BIT (the fields differ in the order the four waves' partial sums
+    the Jacobian, the operands Z1, Z0, G6, gnet -- must agree BIT FOR BIT (the fields differ in the order the four waves' partial sums
     are added: 1e-6).  Ragged sizes: 1037 = 16 full 64-point workgroups + 13 points, 70 = one full + 6 points."""
     import ctypes
     from deepphysinet_amd import _lib as L, point_path as PP

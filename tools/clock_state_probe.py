@@ -40,7 +40,7 @@ def layer_filler(B, unfused, reps):
     x = torch.randn(B, 287, 256, device=dev)
 
     def run():
-        os.environ['DPN_ENCODER_UNFUSED'] = '1' if unfused else '0'
+        __import__('deepphysinet_amd.config').config.set_switches(encoder_unfused=bool(unfused))
         with torch.no_grad():
             for _ in range(reps):
                 layer(x)

@@ -19,7 +19,7 @@ h = b['forecast_h'].repeat(B, 1, 1)
 layers = list(net.encoder.attn_layers)
 lib = L.load()
 with torch.no_grad():
-    os.environ["DPN_CONV16"] = "1"
+    __import__('deepphysinet_amd.config').config.set_switches(conv16=True)
     prep = E.encoder_prep(field, h, net.enc_embedding, None, layers, net.encoder.norm, net.projection)
     xs, xe, ws, we, Kp, cw = prep.conv16
     T, D = field.shape[1], cw.shape[0]

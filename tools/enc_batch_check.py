@@ -18,7 +18,7 @@ h = (torch.arange(B, device=dev, dtype=torch.float32).reshape(B, 1, 1) * 24.0) /
 gy = torch.randn(B, 287, 256, device=dev) * (10.0 ** (spread * (torch.rand(B, 1, 1, device=dev) - 0.5)))
 res = {}
 for mode in ('1', '0'):
-    os.environ['DPN_ENCODER_UNFUSED'] = mode
+    __import__('deepphysinet_amd.config').config.set_switches(encoder_unfused=(mode == '1'))
     m.physics_net.zero_grad(set_to_none=True)
     y = m.physics_net.meta_net(field, h)
     (y * gy).sum().backward()

@@ -35,7 +35,7 @@ def timed(fn, reps=20):
 
 
 def run(fp8, prec, leads):
-    os.environ['DPN_ENCODER_FP8'] = '1' if fp8 else '0'
+    __import__('deepphysinet_amd.config').config.set_switches(encoder_fp8='1' if fp8 else '')
     torch.manual_seed(1)
     m = builder_models(**ncep_config(), precision=prec).to(dev)
     b = synth_batch(n, dev, seed=1)
@@ -76,5 +76,5 @@ for prec in ('bf16x2',):
         'encoder_fwd_ms_61_fields': {'fp32_mfma': ref['encoder_fwd_ms_61_fields'], 'fp8_mfma': f8['encoder_fwd_ms_61_fields']},
         'step_ms_configs1_eager': {'fp32_mfma': ref['step_ms_configs1_eager'], 'fp8_mfma': f8['step_ms_configs1_eager']},
     }
-os.environ['DPN_ENCODER_FP8'] = '0'
+__import__('deepphysinet_amd.config').config.set_switches(encoder_fp8='')
 print(json.dumps(res, indent=1))

@@ -37,13 +37,13 @@ res = {'note': 'encoder forward (four layers x six GEMMs on 61 x 287 = 17 507 ro
 out = {}
 with torch.no_grad():
     for mode in ('0', '1', 'mx'):
-        os.environ['DPN_ENCODER_FP8'] = mode
+        __import__('deepphysinet_amd.config').config.set_switches(encoder_fp8=mode if mode in ('1', 'mx') else '')
         meta1 = m.physics_net.meta_net(b['field_data'], b['forecast_h']).clone()
         losses = m.pde_loss_terms(b['x'], b['y'], b['t'], b['f'], b['field_data'], b['coord_data'], b['forecast_h']).cpu().double()
         out[mode] = {'meta': meta1, 'losses': losses,
                      'ms_1_field': timed(lambda: m.physics_net.meta_net(b['field_data'], b['forecast_h']), 20),
                      'ms_61_fields': timed(lambda: m.physics_net.meta_net(many, fh), 5)}
-os.environ['DPN_ENCODER_FP8'] = '0'
+__import__('deepphysinet_amd.config').config.set_switches(encoder_fp8='')
 names = {'0': 'fp32_mfma', '1': 'fp8_mfma_per_row_scales', 'mx': 'fp8_mx_mfma_k64'}
 for mode in ('0', '1', 'mx'):
     o = out[mode]

@@ -19,7 +19,7 @@ crit = torch.nn.MSELoss()
 lf = m.train_cfg['losses']['loss_factor']
 res = {}
 for mode in ('1', '0'):
-    os.environ['DPN_HEADS_PER_FIELD'] = mode
+    __import__('deepphysinet_amd.config').config.set_switches(heads_per_field=mode)
     m.physics_net.zero_grad(set_to_none=True)
     with torch.no_grad():
         hw = m.physics_net.field_weights(field, fh)
