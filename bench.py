@@ -35,7 +35,8 @@ import torch
 
 ALG_FLOP_FWD_JAC = 11_218_944          # algorithmic FLOP per collocation point, fwd + Jacobian
 ALG_FLOP_STEP = 31_887_360             # fwd + Jacobian + bwd
-EXEC_MAC_FWD = 409_600                 # MACs per point per net actually issued by dpn_fwd_kernel
+EXEC_MAC_FWD = 278_528                 # MACs per point per net issued by dpn_fwd_tiles_kernel: five GEMMs (w1, A = W1 w2, B = W1 Wd, A^T, w1^T; csrc/dpn_layout.h)
+EXEC_MAC_FWD_RING = 409_600            # ... by the ring kernel dpn_fwd_kernel (plain bf16): the seven GEMMs of variable_net.py:49-87
 EXEC_MAC_BWD1 = 49_152                 # backward stage 1: w1 Z0 (192 x 256) per point per net (round 5: the Z products are gone, csrc dpn_finish_gside_kernel)
 MFMA_PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12                      # HBM3E, MI355X_MICROARCH.md
@@ -168,6 +169,9 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--no-alt', action='store_true', help='skip the short run of the other precision mode')
     ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi clock / socket power samples (about 5 s)')
+    ap.add_argument('--blocks', type=int, default=10, help='timed blocks of --steps replays each; ms_per_step is the median block')
+    ap.add_argument('--no-prewarm', action='store_true', help='skip the untimed replays that bring the clock to a steady state (their number depends on timing: '
+                                                              'a run that must do a fixed number of optimiser steps -- tests comparing two runs -- switches them off)')
     ap.add_argument('--no-lead-probe', action='store_true', help='skip the 8-lead probe of the configs[2] code path (about 1 s of GPU work)')
     ap.add_argument('--encoder-fp8', nargs='?', const='1', default=None, choices=['1', 'mx'],
                     help='BASELINE configs[4]: the encoder layers\' forward GEMMs on fp8 (OCP e4m3) MFMA, bf16x2 Jacobian path; OFF by default -- it moves '
@@ -252,7 +256,7 @@ def main():
         staged = StagedPdeStep(m, opt, lead_batches[n_leads] if n_leads > 1 else batch, lf, lead_batch=n_leads > 1)
         return list(staged.stages) + [opt.step], staged
 
-    def run(prec, steps, warmup, use_graph, leads=None, blocks=10, steady=True):
+    def run(prec, steps, warmup, use_graph, leads=None, blocks=None, steady=None):
         """Build model + optimiser, capture the step, measure.  Protocol:
           1. `first_block`: `warmup` untimed steps, then `steps` timed ones, straight after the capture -- what rounds 1-4 reported.  The GPU has
              been idle through the capture; its clock ramps over the first tens of milliseconds, so a 20-step block is taken ON
@@ -264,6 +268,8 @@ def main():
         Returns a dict."""
         nonlocal sync
         n_leads = args.leads if leads is None else leads
+        blocks = args.blocks if blocks is None else blocks
+        steady = (not args.no_prewarm) if steady is None else steady
         m, opt = build(prec)
         if world > 1:
             D.broadcast_parameters(m.physics_net)      # DDP's wrap-time broadcast (the seeds already agree; this makes it a fact)
@@ -419,7 +425,7 @@ def main():
                 last = dt_
         # 3. the timed blocks
         times = []
-        while len(times) < blocks and (len(times) < 3 or sum(times) < 8.0):
+        while len(times) < blocks and (len(times) < min(3, blocks) or sum(times) < 8.0):
             times.append(block_time(fn, steps))
         tt = torch.tensor([first] + times, dtype=torch.float64)
         mine = sorted(times)[len(times) // 2] / steps * 1e3
@@ -472,6 +478,20 @@ def main():
     if dog is not None:
         dog.stop()                                 # the timed region is over: what follows (rooflines on rank 0, the final barrier) has no collectives in flight
     m, dt, graphed, step_fn = rec['model'], rec['dt'], rec['graphed'], rec['fn']
+    pde_losses_out = finite_out = None             # evaluated NOW: nothing below may add optimiser steps in front of them
+    if rank == 0 and args.leads == 1:
+        with torch.no_grad():                      # the six scaled PDE-loss scalars of the timed workload (SURVEY 8d asks for them next to the rate)
+            terms = m.pde_loss_terms(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'], batch['forecast_h'])
+        pde_losses_out = dict(zip(('motion_u', 'motion_v', 'continuous', 'energy', 'vapor', 'gas'), [float(v) for v in terms.cpu()]))
+
+    if rank == 0 and args.leads > 1:               # configs[2]: the six scalars averaged over the fields, and whether the run stayed finite
+        with torch.no_grad():
+            _, terms = m.place_lead_batch(lead['x'], lead['y'], lead['t'], lead['f'], lead['field_data'], lead['coord_data'], lead['forecast_h'], crit,
+                                          m.train_cfg['losses']['loss_factor'])
+        tm = terms.float().mean(dim=0).cpu()
+        pde_losses_out = dict(zip(('motion_u', 'motion_v', 'continuous', 'energy', 'vapor', 'gas'), [float(v) for v in tm]))
+        finite_out = bool(all(bool(torch.isfinite(p_).all()) for p_ in m.physics_net.parameters()))
+
     ms_per_step = dt / args.steps * 1e3
     pts_per_s = args.points * args.leads * world * args.steps / dt
     n_segments = len(rec['graphs']) if rec['graphs'] else (4 if split_step else 1)
@@ -491,7 +511,7 @@ def main():
                    'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world,
                    'step_segments': n_segments,           # N > 1: three backward segments + the optimiser, or one graph with the collectives captured
                    'step_form': rec['step_form'], 'collectives_in_graph': bool(split_step and graphed and n_segments == 1),
-                   'graph_branches': C.FROZEN.no_branches is False},
+                   'graph_branches': list(C.FROZEN.branches)},
         # ms_per_step is the MEDIAN of `timed_blocks` blocks of `steps` replays each, taken after the clock has settled (`prewarm_*`); the first block
         # -- `warmup` + `steps` replays straight after the capture, the protocol of rounds 1-4 -- is reported beside it
         'timed_seconds': sum(rec['block_s']), 'timed_blocks': len(rec['block_s']),
@@ -501,6 +521,10 @@ def main():
         'collective': coll,
         'switches': C.snapshot(),                   # every DPN_* variable of the environment + the frozen switches that differ from their defaults
     }
+    if pde_losses_out is not None:
+        out['pde_losses'] = pde_losses_out
+    if finite_out is not None:
+        out['parameters_finite'] = finite_out
     if rec['capture_error']:
         out['capture_error'] = rec['capture_error']
     if rec.get('step_form_trial'):
@@ -524,19 +548,6 @@ def main():
     if args.encoder_fp8:
         out['config']['encoder_fp8'] = 'mx (E8M0 scale per 32 k, v_mfma_scale_f32_32x32x64_f8f6f4)' if args.encoder_fp8 == 'mx' else 'per-row scales, v_mfma_f32_32x32x16_fp8_fp8'
         out['dtype'] += '; encoder forward GEMMs fp8 e4m3 MFMA (configs[4])'
-
-    if rank == 0 and args.leads == 1:
-        with torch.no_grad():                      # the six scaled PDE-loss scalars of the timed workload (SURVEY 8d asks for them next to the rate)
-            terms = m.pde_loss_terms(batch['x'], batch['y'], batch['t'], batch['f'], batch['field_data'], batch['coord_data'], batch['forecast_h'])
-        out['pde_losses'] = dict(zip(('motion_u', 'motion_v', 'continuous', 'energy', 'vapor', 'gas'), [float(v) for v in terms.cpu()]))
-
-    if rank == 0 and args.leads > 1:               # configs[2]: the six scalars averaged over the fields, and whether the run stayed finite
-        with torch.no_grad():
-            _, terms = m.place_lead_batch(lead['x'], lead['y'], lead['t'], lead['f'], lead['field_data'], lead['coord_data'], lead['forecast_h'], crit,
-                                          m.train_cfg['losses']['loss_factor'])
-        tm = terms.float().mean(dim=0).cpu()
-        out['pde_losses'] = dict(zip(('motion_u', 'motion_v', 'continuous', 'energy', 'vapor', 'gas'), [float(v) for v in tm]))
-        out['parameters_finite'] = bool(all(bool(torch.isfinite(p_).all()) for p_ in m.physics_net.parameters()))
 
     def kernel_rooflines(m, prec):
         """`roofline` (dpn_fwd_kernel, MFMA-bound: the dominant kernel) and `roofline_hbm_kernel` (dpn_wgrad_kernel) of the workload in
@@ -624,14 +635,14 @@ def main():
         traffic, source = pmc_traffic('dpn_fwd_tiles_kernel' if ns == 2 else 'dpn_fwd_kernel', prec, args.points)
         fwd_name = 'dpn_fwd_kernel<1>'
         if ns == 2:
-            fwd_name = 'dpn_fwd_tiles_kernel<2>' + (' (+ dpn_features_kernel<2>, the opt-in feature pre-pass)' if os.environ.get('DPN_FEATURES_PREPASS', '0') in ('1', '2') else '')
+            fwd_name = 'dpn_fwd_tiles_kernel<2>'
         roof = {'bound': 'mfma', 'kernel': fwd_name,
                 'achieved': ach / 1e12, 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_BF16,
                 'traffic': traffic, 'traffic_source': source, 'kernel_ms': k_ms,
                 'algorithmic_flop_per_point': ALG_FLOP_FWD_JAC,
                 'algorithmic_bytes': args.points * 136,          # 40 B in + 96 B out per point: the kernel is MFMA-bound
-                'executed_mfma_tflops': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / 1e12,
-                'executed_mfma_frac_of_peak': args.points * 6 * EXEC_MAC_FWD * 2 * nsplit / (k_ms * 1e-3) / MFMA_PEAK_BF16}
+                'executed_mfma_tflops': args.points * 6 * (EXEC_MAC_FWD if ns == 2 else EXEC_MAC_FWD_RING) * 2 * nsplit / (k_ms * 1e-3) / 1e12,
+                'executed_mfma_frac_of_peak': args.points * 6 * (EXEC_MAC_FWD if ns == 2 else EXEC_MAC_FWD_RING) * 2 * nsplit / (k_ms * 1e-3) / MFMA_PEAK_BF16}
         if sustained is not None:
             # the kernel alone, back to back: the clock the socket's power cap leaves it, and the dense peak AT that clock (peak above = 2.4 GHz)
             sustained['peak_at_this_clock_tflops'] = MFMA_PEAK_BF16 / 1e12 * sustained['sclk_mhz'] / 2400.0

@@ -102,6 +102,8 @@ EXPORTS = {
     'dpn_version': (c_int, []),
     'dpn_sizes': (c_int, [c_int64, c_int, POINTER(DpnSizes)]),
     'dpn_pack_weights': (c_int, [POINTER(DpnNetPtrs), c_int, c_void_p, c_void_p]),
+    'dpn_fwd_form': (c_int, [c_int, c_int]),
+    'dpn_pack_weights_form': (c_int, [POINTER(DpnNetPtrs), c_int, c_int, c_void_p, c_void_p]),
     'dpn_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
                         c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_fwd_ref': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,

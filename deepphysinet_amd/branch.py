@@ -14,7 +14,11 @@ pass joins by itself when the engine has finished that pass (`queue_callback`, t
 finalisation): the caller of `loss.backward()` / `torch.autograd.grad(...)` sees every gradient complete on its stream, as without branches.
 Forks outside a backward pass must call `join()` themselves before the results are used.
 
-`DPN_NO_BRANCHES=1` (read at import: `config.FROZEN`) runs everything on the main stream -- the A/B switch for measurements.
+Which branches are taken is a frozen switch (`config.FROZEN.branches`, DPN_BRANCHES=finish,wgrad16; default: NONE).  Measured (round 5, same box,
+profiles/round5_branches_ab.txt): a fork / join pair inside a hipGraph costs 10-16 us of idle chain on this runtime and the kernels that then run side
+by side slow each other -- the captured step takes 1.211 ms without branches, 1.253 ms with the finish stage's static half (29 us of kernels) on the
+side branch, 1.289 ms with the encoder's weight gradients there as well; five forks (one per layer) 1.407 against 1.301 ms.  The mechanism stays
+(correct, tested) for runtimes where a fork is cheap; the product path does not take it.
 """
 import torch
 
@@ -23,8 +27,10 @@ from . import config
 _tab = {}       # device index -> _Dev.  One Python thread per rank drives the GPU; autograd's worker thread and the caller share this table
 
 
-def enabled():
-    return not config.FROZEN.no_branches
+def enabled(which=None):
+    """Is the side branch `which` ('finish', 'wgrad16') taken?  (no argument: is any)"""
+    b = config.FROZEN.branches
+    return bool(b) if which is None else which in b
 
 
 class _Dev:

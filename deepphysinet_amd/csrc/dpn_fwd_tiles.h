@@ -242,15 +242,6 @@ DEV void save_tile_k(const KMat& m, const int net, const int64_t tile32, const i
     }
 }
 
-// ---- positional features, evaluated once per point (not once per point and net) by dpn_features_kernel and stored behind the saved state:
-// per 64-point workgroup tile  [pe3 image 24 NS KB | pe6 image 24 NS KB | dpe table 48 KB]
-//   pe3 / pe6 image : the LDS X image of the features' B fragments, [k-step 12][column tile 2][hi | lo][64 lanes][16 B] -- the forward kernel
-//                     copies it 16 bytes per thread and step, linearly
-//   dpe table       : d pe3 / d xi in the accumulator layout of the gpe tiles, [coordinate 3][tile 2][column tile 2][64 lanes][16 floats]:
-//                     element 2 rp = freq * cos, 2 rp + 1 = -freq * sin of the lane's angle rp (what the Jacobian contraction multiplies by)
-template <int NS> constexpr int feat_pe_bytes() { return 12 * 2 * NS * 1024; }
-template <int NS> constexpr int feat_tile_bytes() { return 2 * feat_pe_bytes<NS>() + 3 * 2 * 2 * 64 * 64; }
-
 // the coordinate features of k-step ks (0..11) for the lane's point: one B fragment (hi [+ lo])
 template <int NS, class Args>
 DEV void pe3_frag(Frag<NS>& f, const Args& a, const int ks, const int h, const int64_t pc) {
@@ -275,6 +266,22 @@ DEV void pe6_frag(Frag<NS>& f, const Args& a, const int ks, const int h, const i
         float s, co;
         ts_sincos<NS>(v * a.freqs[32 + 8 * (ks & 1) + 4 * h + q], s, co);
         frag_set2<NS>(f, q, g * s, g * co);
+    }
+}
+// the same, and dot += sum over the fragment's eight features of feature * bv[slot] (bv: a 192-vector in PE6 slot order 16 ks + 8 h + e, in LDS)
+template <int NS, class Args>
+DEV void pe6_frag_dot(Frag<NS>& f, const Args& a, const int ks, const int h, const int64_t pc, const float* bv, float& dot) {
+    const float v = a.coord_data[pc * 6 + (ks >> 1)];
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(bv + 16 * ks + 8 * h);
+    const f32x4 b0 = b4[0], b1 = b4[1];
+    const float bb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s, co;
+        ts_sincos<NS>(v * a.freqs[32 + 8 * (ks & 1) + 4 * h + q], s, co);
+        frag_set2<NS>(f, q, s, co);
+        dot = fmaf(s, bb[2 * q], dot);
+        dot = fmaf(co, bb[2 * q + 1], dot);
     }
 }
 // backward: Z0 = g * pe + gJ_c * d pe / d xi_c for k-step ks (coordinate c = ks >> 2), build_pe3<BWD> of the ring kernels
@@ -313,42 +320,6 @@ DEV void dpe_tile(float (&d)[16], const Args& a, const int c, const int t, const
 }
 }  // namespace ts
 
-template <int NS>
-__global__ __launch_bounds__(256) void dpn_features_kernel(FwdArgs a, char* feat) {      // a.feat_table_only: the dpe table alone
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int64_t tile0 = (int64_t)blockIdx.x * 2;
-    char* ft = feat + (int64_t)blockIdx.x * ts::feat_tile_bytes<NS>();
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int64_t pt = (tile0 + p) * 32 + j;
-        const int64_t pc = pt < a.n ? pt : (a.n - 1);
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            if (a.feat_table_only) break;
-            const int ks = 3 * w + kk;
-            Frag<NS> f3, f6;
-            ts::pe3_frag<NS>(f3, a, ks, h, pc);
-            ts::pe6_frag<NS>(f6, a, ks, h, pc);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                *reinterpret_cast<u32x4*>(ft + ((ks * 2 + p) * NS + s) * 1024 + lane * 16) = f3.w[s];
-                *reinterpret_cast<u32x4*>(ft + ts::feat_pe_bytes<NS>() + ((ks * 2 + p) * NS + s) * 1024 + lane * 16) = f6.w[s];
-            }
-        }
-        if (w < 3) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float d[16];
-                ts::dpe_tile<NS>(d, a, w, t, h, pc);
-                f32x4* o = reinterpret_cast<f32x4*>(ft + 2 * ts::feat_pe_bytes<NS>() + (((w * 2 + t) * 2 + p) * 64 + lane) * 64);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = f32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
-            }
-        }
-    }
-}
-
 // Experiment build (-DDPN_TIMELINE -DTS_TIMELINE, tools/tiles_timeline.py): lane 0 of every wave writes the shader clock at the phase
 // boundaries below to a.timeline[workgroup][wave][stamp]
 #if defined(TS_TIMELINE) && defined(DPN_TIMELINE)
@@ -357,6 +328,13 @@ __global__ __launch_bounds__(256) void dpn_features_kernel(FwdArgs a, char* feat
 #define TS_STAMP(I) do { } while (0)
 #endif
 
+// Round 5: FIVE GEMMs per point and net instead of seven.  W1 (cat_fc1.fc.0.weight) only ever multiplies c = w2 h1 + Wd pe6 + cvec, and its
+// transpose only ever meets w2^T on the way back, so the two static-times-hyper products are formed ONCE per net and step,
+//     A = W1 w2 [256, 256],   B = W1 Wd [256, 192]        (exact fp32, dpn_pack_weights: csrc FusedForm)
+// and   pre2 = A h1 + B pe6 + (W1 cvec + bf1),    wo . c = (w2^T wo) . h1 + (Wd^T wo) . pe6 + wo . cvec,    y = A^T (m2 (.) u) + 2 w2^T wo:
+// neither c nor v = d out / d c is formed per point.  409 600 -> 278 528 executed MACs per point and net, and the weight stream a workgroup
+// pulls out of L2 per 64 points shrinks from 800 to 544 KB (x NS).  What the backward pass needs (m1, M2, T1 = m1 (.) y) is unchanged; its
+// formulas are in the original parameters (dpn_finish_*).  Identity and operand rounding: tools/precision_fused_algebra.py.
 template <int NS>
 __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     using C = ts::Cfg<NS>;
@@ -394,9 +372,6 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     const ts::Ident I = ts::make_ident(j, h);
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     const bool save = a.saved != nullptr;
-    // features of this workgroup's 64 points: evaluated here, or -- DPN_FEATURES_PREPASS=1, a measured experiment -- once per point by
-    // dpn_features_kernel (stored behind the saved state)
-    const char* ft = a.feat ? a.feat + (int64_t)blockIdx.x * ts::feat_tile_bytes<NS>() : nullptr;
     const int64_t tiles32 = a.n_pad / 32;
     auto chunk = [&](const int kb) __attribute__((always_inline)) { return pk + (long)kb * 1024 * NS; };
 
@@ -419,35 +394,42 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     };
 
     ts::Head<NS, 2> H;
-    ts::gemm_head<NS, 12, 2>(chunk(kS0 + 2 * w * 12), lane, H);
-    // ---------------- coordinate features pe3 -> X (k-steps 0..11)
-    const bool ft_pe = ft && !a.feat_table_only;
-    if (ft_pe) {                             // linear copy of the stored image: 16 bytes per thread and step, all loads in flight at once
-        constexpr int kSteps = ts::feat_pe_bytes<NS>() / 4096;
-        u32x4 v[kSteps];
+    ts::gemm_head<NS, 12, 2>(chunk(kF0 + 2 * w * 12), lane, H);
+    // ---------------- coordinate features pe3 -> X (k-steps 0..11): this thread builds k-steps 3w .. 3w+2 of both column tiles
 #pragma unroll
-        for (int i = 0; i < kSteps; ++i) v[i] = reinterpret_cast<const u32x4*>(ft)[threadIdx.x + 256 * i];
+    for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-        for (int i = 0; i < kSteps; ++i) reinterpret_cast<u32x4*>(lds)[threadIdx.x + 256 * i] = v[i];
-    } else {                                 // this thread builds k-steps 3w .. 3w+2 of both column tiles
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                Frag<NS> f;
-                ts::pe3_frag<NS>(f, a, 3 * w + kk, h, pc[p]);
-                ts::x_store<NS>(xl, 3 * w + kk, p, f);
-            }
-    }
+        for (int p = 0; p < 2; ++p) {
+            Frag<NS> f;
+            ts::pe3_frag<NS>(f, a, 3 * w + kk, h, pc[p]);
+            ts::x_store<NS>(xl, 3 * w + kk, p, f);
+        }
     TS_STAMP(1);
     ts::barrier_lds();
-    // ---------------- L1: pre1 = w1 . pe + b1 ; h1 = relu -> X ; relu mask bits -> m1w
+    // ---------------- L1: pre1 = w1 . pe + b1 ; h1 = relu -> X ; relu mask bits -> m1w ; hdot = (w2^T wo) . h1 (this wave's 64 channels)
     u32 m1w[2] = {0u, 0u};
     init_all(kVecB1, 1.0f);
     TS_STAMP(2);
-    ts::gemm<NS, 12, 2>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
+    ts::gemm<NS, 12, 2>(chunk(kF0 + 2 * w * 12), xl, lane, H, acc);
     TS_STAMP(3);
-    ts::gemm_head<NS, 16, 2>(chunk(kS1 + 2 * w * 16), lane, H);
+    float hdot[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {            // hdot first, on max(pre1, 0) by v_med3 (no compare result shared with the mask loop below)
+        const f32x4* av = reinterpret_cast<const f32x4*>(vec + kVecA2 * 256 + h * 128 + (2 * w + t) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 aq = av[q];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                hdot[p] = fmaf(aq[0], __builtin_amdgcn_fmed3f(acc[t][p][4 * q], 0.f, __builtin_inff()), hdot[p]);
+                hdot[p] = fmaf(aq[1], __builtin_amdgcn_fmed3f(acc[t][p][4 * q + 1], 0.f, __builtin_inff()), hdot[p]);
+                hdot[p] = fmaf(aq[2], __builtin_amdgcn_fmed3f(acc[t][p][4 * q + 2], 0.f, __builtin_inff()), hdot[p]);
+                hdot[p] = fmaf(aq[3], __builtin_amdgcn_fmed3f(acc[t][p][4 * q + 3], 0.f, __builtin_inff()), hdot[p]);
+            }
+        }
+    }
+    asm volatile("" : "+v"(hdot[0]), "+v"(hdot[1]));      // the dot products are finished BEFORE the next layer's first weight fragments are requested (register pressure)
+    ts::gemm_head<NS, 16, 2>(chunk(kFA + 2 * w * 16), lane, H);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -472,69 +454,34 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
     x_store_all();
     TS_STAMP(5);
     ts::barrier_lds();
-    // ---------------- L2: c = w2 . h1 + Wd . pe6 + (b2 + bd + e) -> X ; cdot = wo . c
-    init_all(kVecCvec, 1.0f);
+    // ---------------- pre2 = A h1 + B pe6 + (W1 cvec + bf1)
+    init_all(kVecC2, 1.0f);
     TS_STAMP(6);
-    ts::gemm<NS, 16, 2>(chunk(kS1 + 2 * w * 16), xl, lane, H, acc);
+    ts::gemm<NS, 16, 2>(chunk(kFA + 2 * w * 16), xl, lane, H, acc);
     TS_STAMP(7);
-    ts::gemm_head<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), lane, H);
-    if (ft_pe) {   // data features pe6: copy of the stored image
-        constexpr int kSteps = ts::feat_pe_bytes<NS>() / 4096;
-        u32x4 v[kSteps];
-#pragma unroll
-        for (int i = 0; i < kSteps; ++i) v[i] = reinterpret_cast<const u32x4*>(ft + ts::feat_pe_bytes<NS>())[threadIdx.x + 256 * i];
-    TS_STAMP(8);
-        ts::barrier_lds();                   // everybody is done reading h1
-#pragma unroll
-        for (int i = 0; i < kSteps; ++i) reinterpret_cast<u32x4*>(lds)[threadIdx.x + 256 * i] = v[i];
-    TS_STAMP(9);
-        ts::barrier_lds();
-    } else {    // data features pe6 (SineCosPE(6,16) of coord_data): k-steps 3w .. 3w+2 of both column tiles, built while the accumulators wait
+    ts::gemm_head<NS, 12, 2>(chunk(kFB + 2 * w * 12), lane, H);
+    float ddot[2] = {0.f, 0.f};              // (Wd^T wo) . pe6 over this wave's k-steps
+    {   // data features pe6 (SineCosPE(6,16) of coord_data): k-steps 3w .. 3w+2 of both column tiles, built while the accumulators wait
         Frag<NS> f6[3][2];
+        const float* bv = vec + kVecBv * 256;
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) ts::pe6_frag<NS>(f6[kk][p], a, 3 * w + kk, h, pc[p]);
-    TS_STAMP(8);
+            for (int p = 0; p < 2; ++p) ts::pe6_frag_dot<NS>(f6[kk][p], a, 3 * w + kk, h, pc[p], bv, ddot[p]);
+        TS_STAMP(8);
         ts::barrier_lds();                   // everybody is done reading h1
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
             for (int p = 0; p < 2; ++p) ts::x_store<NS>(xl, 3 * w + kk, p, f6[kk][p]);
-    TS_STAMP(9);
+        TS_STAMP(9);
         ts::barrier_lds();
     }
     TS_STAMP(10);
-    ts::gemm<NS, 12, 2>(chunk(kS1 + 128 + 2 * w * 12), xl, lane, H, acc);
+    ts::gemm<NS, 12, 2>(chunk(kFB + 2 * w * 12), xl, lane, H, acc);
     TS_STAMP(11);
-    ts::gemm_head<NS, 16, 2>(chunk(kS2 + 2 * w * 16), lane, H);
-    float cdot[2] = {0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const f32x4* wv = reinterpret_cast<const f32x4*>(vec + kVecWo * 256 + h * 128 + (2 * w + t) * 16);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 x = wv[q];
-                cdot[p] = fmaf(x[0], acc[t][p][4 * q], cdot[p]); cdot[p] = fmaf(x[1], acc[t][p][4 * q + 1], cdot[p]);
-                cdot[p] = fmaf(x[2], acc[t][p][4 * q + 2], cdot[p]); cdot[p] = fmaf(x[3], acc[t][p][4 * q + 3], cdot[p]);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, acc[t][p][r], acc[t][p][r + 1]);
-        }
-    }
-    TS_STAMP(12);
-    ts::barrier_lds();
-    x_store_all();
-    TS_STAMP(13);
-    ts::barrier_lds();
-    // ---------------- fc1: pre2 = W1 . c + bf1 ; out = u . relu(pre2) + 2 wo . c + const ; t2 = m2 (.) u -> X ; M2 -> saved
-    init_all(kVecBf1, 1.0f);
-    TS_STAMP(14);
-    ts::gemm<NS, 16, 2>(chunk(kS2 + 2 * w * 16), xl, lane, H, acc);
-    TS_STAMP(15);
-    if (save || a.jac_n) ts::gemm_head<NS, 16, 2>(chunk(kS3 + 2 * w * 16), lane, H);
+    if (save || a.jac_n) ts::gemm_head<NS, 16, 2>(chunk(kFAT + 2 * w * 16), lane, H);
+    // ---------------- out = u . relu(pre2) + 2 wo . c + const ; t2 = m2 (.) u -> X ; M2 -> saved
     float adot[2] = {0.f, 0.f};
     Frag<1> MK[2][2][2];                     // relu-2 mask as bf16 0 / 1 fragments (one plane)
 #pragma unroll
@@ -567,28 +514,28 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         }
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {            // this wave's share of the field: its 64 channels, both halves of the wave
-        float o = adot[p] + 2.0f * cdot[p];
+    for (int p = 0; p < 2; ++p) {            // this wave's share of the field: its 64 channels and its 3 k-steps of pe6, both halves of the wave
+        float o = adot[p] + 2.0f * (hdot[p] + ddot[p]);
         o += __shfl_xor(o, 32);
         if (h == 0) red[w * 64 + p * 32 + j] = o;
     }
-    TS_STAMP(16);
+    TS_STAMP(12);
     ts::barrier_lds();
     x_store_all();
-    TS_STAMP(17);
+    TS_STAMP(13);
     ts::barrier_lds();
     if (w == 0) {                            // lane (j, h) finishes point j of column tile h: the four waves' shares in a fixed order
         const int64_t pt = (tile0 + h) * 32 + j;
         if (pt < a.n) {
-            const float const0 = vec[kNumVecs * 256];
+            const float const0 = vec[kNumVecs * 256];          // wo . bf2 + bo + 2 wo . cvec
             const float o = (red[0 * 64 + h * 32 + j] + red[1 * 64 + h * 32 + j]) + (red[2 * 64 + h * 32 + j] + red[3 * 64 + h * 32 + j]);
             a.out_n[pt * 6 + net] = o + const0 + (a.ref ? a.ref : a.coord_data)[pt * 6 + net];           // + ref_data (variable_net.py:86)
         }
     }
     if (!save && !a.jac_n) return;
-    // ---------------- reverse sweep: v = W1^T t2 + 2 wo -> X (v is not saved: SavedView)
-    init_all(kVecWo, 2.0f);
-    TS_STAMP(18);
+    // ---------------- reverse sweep: y = A^T t2 + 2 w2^T wo ; t1 = m1 (.) y -> X (+ saved T1)
+    init_all(kVecA2, 2.0f);
+    TS_STAMP(14);
 #if TS_DEFER_SAVES
     {
         auto side = [&](const int ks) __attribute__((always_inline)) {            // M2: four (tile, column tile) units over the 16 k-steps
@@ -597,30 +544,14 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
             for (int u = 0; u < 4; ++u)
                 if (ks == 4 * u + 1) ts::save_plane_k(sv.M2, net, 1, 0, tile0 + (u & 1), 2 * w + (u >> 1), lane, I, zero_rows[u & 1], MK[u >> 1][u & 1][0].w[0], MK[u >> 1][u & 1][1].w[0]);
         };
-        ts::gemm<NS, 16, 2, false>(chunk(kS3 + 2 * w * 16), xl, lane, H, acc, side);
+        ts::gemm<NS, 16, 2, false>(chunk(kFAT + 2 * w * 16), xl, lane, H, acc, side);
     }
 #else
-    ts::gemm<NS, 16, 2>(chunk(kS3 + 2 * w * 16), xl, lane, H, acc);
+    ts::gemm<NS, 16, 2>(chunk(kFAT + 2 * w * 16), xl, lane, H, acc);
 #endif
-    TS_STAMP(19);
-    ts::gemm_head<NS, 16, 2>(chunk(kS4 + 2 * w * 16), lane, H);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) frag_set2<NS>(F[t][p][r >> 3], (r & 7) >> 1, acc[t][p][r], acc[t][p][r + 1]);
-        }
-    TS_STAMP(20);
-    ts::barrier_lds();
-    x_store_all();
-    TS_STAMP(21);
-    ts::barrier_lds();
-    // ---------------- y = w2^T v ; t1 = m1 (.) y -> X (+ saved T1)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { acc[t][0] = (f32x16)0.f; acc[t][1] = (f32x16)0.f; }
-    TS_STAMP(22);
-    // F (the v fragments) stays live through this loop: the next epilogue rewrites it only afterwards
+    TS_STAMP(15);
+    if (a.jac_n && w < 3) ts::gemm_head<NS, 16, 2>(chunk(kF5 + 2 * w * 16), lane, H);
+    // F (the t2 fragments) is rewritten by this epilogue: every wave has finished reading X(t2) only after the barrier below
     auto side_planes = [&](const KMat& m, const int ks) __attribute__((always_inline)) {       // 4 x NS (tile, column tile, plane) units over 16 k-steps
         if (!save) return;
 #pragma unroll
@@ -630,9 +561,6 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
                 ts::save_plane_k(m, net, NS, s_, tile0 + (tp & 1), 2 * w + (tp >> 1), lane, I, zero_rows[tp & 1], F[tp >> 1][tp & 1][0].w[s_], F[tp >> 1][tp & 1][1].w[s_]);
         }
     };
-    ts::gemm<NS, 16, 2>(chunk(kS4 + 2 * w * 16), xl, lane, H, acc);
-    TS_STAMP(23);
-    if (a.jac_n && w < 3) ts::gemm_head<NS, 16, 2>(chunk(kS5 + 2 * w * 16), lane, H);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -649,25 +577,25 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
 #endif
         }
     if (!a.jac_n) return;
-    TS_STAMP(24);
+    TS_STAMP(16);
     ts::barrier_lds();
     x_store_all();
-    TS_STAMP(25);
+    TS_STAMP(17);
     ts::barrier_lds();
     // ---------------- gpe = w1^T t1 (6 tiles: waves 0..2; both tiles of wave w belong to coordinate c = w), contracted with d(pe)/d(xi)
     if (w >= 3) return;
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc[t][0] = (f32x16)0.f; acc[t][1] = (f32x16)0.f; }
-    TS_STAMP(26);
+    TS_STAMP(18);
 #if TS_DEFER_SAVES
     {
         auto side = [&](const int ks) __attribute__((always_inline)) { side_planes(sv.T1, ks); };
-        ts::gemm<NS, 16, 2, false>(chunk(kS5 + 2 * w * 16), xl, lane, H, acc, side);
+        ts::gemm<NS, 16, 2, false>(chunk(kF5 + 2 * w * 16), xl, lane, H, acc, side);
     }
 #else
-    ts::gemm<NS, 16, 2>(chunk(kS5 + 2 * w * 16), xl, lane, H, acc);
+    ts::gemm<NS, 16, 2>(chunk(kF5 + 2 * w * 16), xl, lane, H, acc);
 #endif
-    TS_STAMP(27);
+    TS_STAMP(19);
     {
         const int c = w;
         float jc[2] = {0.f, 0.f};
@@ -676,13 +604,7 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float d[16];
-                if (ft) {
-                    const f32x4* tab = reinterpret_cast<const f32x4*>(ft + 2 * ts::feat_pe_bytes<NS>() + (((c * 2 + t) * 2 + p) * 64 + lane) * 64);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const f32x4 x = tab[q]; d[4 * q] = x[0]; d[4 * q + 1] = x[1]; d[4 * q + 2] = x[2]; d[4 * q + 3] = x[3]; }
-                } else {
-                    ts::dpe_tile<NS>(d, a, c, t, h, pc[p]);
-                }
+                ts::dpe_tile<NS>(d, a, c, t, h, pc[p]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) jc[p] = fmaf(acc[t][p][r], d[r], jc[p]);
             }
@@ -697,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
             a.jac_n[(pt * 6 + net) * 3 + c] = mine / g1 / g2;
         }
     }
-    TS_STAMP(28);
+    TS_STAMP(20);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------

@@ -125,14 +125,34 @@ struct PackArgs {
     DpnNetPtrs net[kNets];
     char* packed;
     int ns;
+    int form;              // 0: the seven-GEMM stream (ring kernels), 1: the fused five-GEMM stream (dpn_fwd_tiles_kernel; dpn_layout.h)
+    const float* fused;    // form 1: fp32 [6][256][448] rows o of [A = W1 w2 | B = W1 Wd] (made by the GEMM launch in front of this kernel)
 };
 
-DEV float pack_src(const DpnNetPtrs& P, int kb, int lane, int e) {
+DEV float pack_src(const PackArgs& a, const int net, int kb, int lane, int e) {
+    const DpnNetPtrs& P = a.net[net];
     const int i = lane & 31, h = lane >> 5;
     if (kb < kS1) {                                   // S0: w1, rows o, K = PE3 slots
         const int T = kb / 12, ks = kb % 12;
         return P.w1b1[(32 * T + i) * P.ld_w1b1 + pe3_ch(ks, h, e)];
-    } else if (kb < kS2) {                            // S1: w2 (8 tiles x 16 k-steps), then Wd (8 tiles x 12 k-steps)
+    } else if (kb >= kS5) {                           // S5: w1^T rows rho (PE slots), K over o
+        const int rel = kb - kS5, T = rel / 16, ks = rel % 16;
+        return P.w1b1[chain_ch(ks, h, e) * P.ld_w1b1 + gpe_row_to_pe3_ch(32 * T + i)];
+    }
+    if (a.form == 1) {
+        const float* F = a.fused + (long)net * kHidden * kFusedCols;
+        if (kb < kFB) {                               // FA: A rows o, K = chain(h1)
+            const int rel = kb - kFA, T = rel / 16, ks = rel % 16;
+            return F[(32 * T + i) * kFusedCols + chain_ch(ks, h, e)];
+        } else if (kb < kFAT) {                       // FB: B rows o, K = PE6 slots
+            const int rel = kb - kFB, T = rel / 12, ks = rel % 12;
+            return F[(32 * T + i) * kFusedCols + kFusedColB + pe6_ch(ks, h, e)];
+        } else {                                      // FAT: A^T rows j, K over o = chain(t2)
+            const int rel = kb - kFAT, T = rel / 16, ks = rel % 16;
+            return F[chain_ch(ks, h, e) * kFusedCols + (32 * T + i)];
+        }
+    }
+    if (kb < kS2) {                                   // S1: w2 (8 tiles x 16 k-steps), then Wd (8 tiles x 12 k-steps)
         const int rel = kb - kS1;
         if (rel < 128) return P.w2b2[(32 * (rel / 16) + i) * P.ld_w2b2 + chain_ch(rel % 16, h, e)];
         const int r2 = rel - 128;
@@ -143,47 +163,70 @@ DEV float pack_src(const DpnNetPtrs& P, int kb, int lane, int e) {
     } else if (kb < kS4) {                            // S3: W1^T rows i, K over o
         const int rel = kb - kS3, T = rel / 16, ks = rel % 16;
         return P.W1[chain_ch(ks, h, e) * kHidden + (32 * T + i)];
-    } else if (kb < kS5) {                            // S4: w2^T rows i, K over o
+    } else {                                          // S4: w2^T rows i, K over o
         const int rel = kb - kS4, T = rel / 16, ks = rel % 16;
         return P.w2b2[chain_ch(ks, h, e) * P.ld_w2b2 + (32 * T + i)];
-    } else {                                          // S5: w1^T rows rho (PE slots), K over o
-        const int rel = kb - kS5, T = rel / 16, ks = rel % 16;
-        return P.w1b1[chain_ch(ks, h, e) * P.ld_w1b1 + gpe_row_to_pe3_ch(32 * T + i)];
     }
 }
 
 // vectors in [h][T][r] order (channel 32T + drow32(r,h)); u = W2^T wo; const0 = wo.bf2 + bo
+// form 1 (dpn_layout.h): C2 = W1 cvec + bf1, A2 = w2^T wo, Bv = Wd^T wo (PE6 slot order), const0 += 2 wo.cvec
 DEV void pack_vectors(const PackArgs& a, const int net) {
     const DpnNetPtrs& P = a.net[net];
     float* vec = reinterpret_cast<float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
     const int idx = threadIdx.x;
     const int h = idx >> 7, T = (idx >> 4) & 7, r = idx & 15;
     const int ch = 32 * T + drow32(r, h);
-    // u = W2^T wo: 256 independent row reads per thread -- sixteen of them in flight at a time (the loop is latency-bound otherwise),
-    // partial sums joined in a fixed order
-    float up[4] = {0.f, 0.f, 0.f, 0.f};
+    __shared__ float red[256];
+    // u = W2^T wo (and, fused form, A2 = w2^T wo, Bv = Wd^T wo): 256 independent row reads per thread and vector -- all vectors in ONE loop, twelve to
+    // sixteen loads in flight at a time (the loop is latency-bound: a loop per vector would put three such chains in a row on this one block per
+    // net), partial sums joined in a fixed order
+    float up[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c6 = idx < kPe ? pe6_ch(idx >> 4, (idx >> 3) & 1, idx & 7) : 0;                // Bv: idx = PE6 slot 16 ks + 8 h + e (idx < 192)
+    if (a.form == 1) {
 #pragma unroll 4
-    for (int o = 0; o < kHidden; o += 4) {
+        for (int o = 0; o < kHidden; o += 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) up[j] = fmaf(P.wo[o + j], P.W2[(o + j) * kHidden + ch], up[j]);
+            for (int j = 0; j < 4; ++j) {
+                const float w = P.wo[o + j];
+                up[j] = fmaf(w, P.W2[(o + j) * kHidden + ch], up[j]);
+                a2[j] = fmaf(w, P.w2b2[(o + j) * P.ld_w2b2 + ch], a2[j]);                   // (w2^T wo)[ch]
+                bv[j] = fmaf(w, P.Wd[(o + j) * kPe + c6], bv[j]);                           // (Wd^T wo)[pe6 channel of this slot]
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int o = 0; o < kHidden; o += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) up[j] = fmaf(P.wo[o + j], P.W2[(o + j) * kHidden + ch], up[j]);
+        }
     }
     const float u = (up[0] + up[1]) + (up[2] + up[3]);
+    const float cv_nat = P.w2b2[idx * P.ld_w2b2 + kHidden] + P.bd[idx] + P.evec[idx];      // cvec[idx], natural order
     vec[kVecB1 * 256 + idx] = P.w1b1[ch * P.ld_w1b1 + kPe];
-    vec[kVecCvec * 256 + idx] = P.w2b2[ch * P.ld_w2b2 + kHidden] + P.bd[ch] + P.evec[ch];
-    vec[kVecBf1 * 256 + idx] = P.bf1[ch];
     vec[kVecU * 256 + idx] = u;
     vec[kVecWo * 256 + idx] = P.wo[ch];
-    vec[kVecB2BdE_unused * 256 + idx] = 0.f;
-    __shared__ float red[256];
-    red[idx] = P.wo[idx] * P.bf2[idx];
+    red[idx] = P.wo[idx] * (P.bf2[idx] + (a.form == 1 ? 2.0f * cv_nat : 0.f));
     __syncthreads();
+    if (a.form == 1) {
+        // (W1 cvec)[ch] = W1 b2 + W1 bd + W1 e: three columns of the GEMM launch's scratch (a pass over W1's rows here, one row per thread, is
+        // 256 uncoalesced loads in a row: it made this block the long pole of the launch, 31 us)
+        const float* Fr = a.fused + ((long)net * kHidden + ch) * kFusedCols;
+        vec[kVecC2 * 256 + idx] = ((Fr[kFusedColB2] + Fr[kFusedColBd]) + Fr[kFusedColE]) + P.bf1[ch];
+        vec[kVecA2 * 256 + idx] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+        vec[kVecBv * 256 + idx] = idx < kPe ? (bv[0] + bv[1]) + (bv[2] + bv[3]) : 0.f;
+    } else {
+        vec[kVecCvec * 256 + idx] = P.w2b2[ch * P.ld_w2b2 + kHidden] + P.bd[ch] + P.evec[ch];
+        vec[kVecBf1 * 256 + idx] = P.bf1[ch];
+        vec[kVecB2BdE_unused * 256 + idx] = 0.f;
+    }
     for (int s = 128; s > 0; s >>= 1) {
         if (idx < s) red[idx] += red[idx + s];
         __syncthreads();
     }
     if (idx == 0) {
         vec[kNumVecs * 256 + 0] = red[0] + P.bo[0];
-        vec[kNumVecs * 256 + 1] = 0.f; vec[kNumVecs * 256 + 2] = 0.f; vec[kNumVecs * 256 + 3] = 0.f;
+        vec[kNumVecs * 256 + 1] = (float)a.form; vec[kNumVecs * 256 + 2] = 0.f; vec[kNumVecs * 256 + 3] = 0.f;
     }
 }
 
@@ -191,16 +234,18 @@ DEV void pack_vectors(const PackArgs& a, const int net) {
 __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
     if (blockIdx.x == gridDim.x - 1) { pack_vectors(a, blockIdx.y); return; }      // last block column: the fp32 vectors of this net
     const int net = blockIdx.y;
-    const DpnNetPtrs& P = a.net[net];
     const int ns = a.ns;
     uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
-    const int total = kPackKB * 64;                   // (kb, lane) pairs
+    const int skip = a.form == 1 ? kS5 - kS3 : 0;     // the fused form leaves [kS3, kS5) unwritten
+    const int total = (kPackKB - skip) * 64;          // (kb, lane) pairs
     for (int u = blockIdx.x * 256 + threadIdx.x; u < total; u += (gridDim.x - 1) * 256) {     // the last block column packs the vectors
-        const int kb = u >> 6, lane = u & 63;
+        int kb = u >> 6;
+        const int lane = u & 63;
+        if (kb >= kS3) kb += skip;
         u16 hi[8], lo[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float x = pack_src(P, kb, lane, e);
+            const float x = pack_src(a, net, kb, lane, e);
             hi[e] = f2bf(x);
             lo[e] = f2bf(x - bf2f(hi[e]));
         }
@@ -583,18 +628,7 @@ DEV SavedView saved_view(void* base, int64_t n_pad, int ns) {
     return s;
 }
 DPN_HD int64_t saved_state_bytes(int64_t n_pad, int ns) { return (int64_t)kNets * ns * n_pad * 512 + (int64_t)kNets * n_pad * 512 + (int64_t)kNets * n_pad * 32; }
-// the saved state is followed by the positional features of the tile-split forward kernel (dpn_fwd_tiles.h: per 64 points the pe3 and pe6
-// fragment images and the d pe3 / d xi table, evaluated once per point instead of once per point and net)
-DPN_HD int64_t feature_bytes(int64_t n_pad, int ns) { return (n_pad / 64) * (int64_t)(2 * 12 * 2 * ns * 1024 + 3 * 2 * 2 * 64 * 64); }
-// DPN_FEATURES_PREPASS=1 (measured experiment, OFF by default): the pre-pass kernel costs 25 us (it writes 86 MB) and shortens the forward kernel
-// by 19 us -- no net gain at six nets per point; without it the features are evaluated inside the kernels, hidden behind the partner wave.
-// DPN_FEATURES_PREPASS=2: only the d pe3 / d xi table of the Jacobian contraction (29 MB; that phase is 9 % of a wave's lifetime in the
-// timeline): same-box steps 1.618-1.623 ms against 1.624 ms without -- nothing either, the phase overlaps the partner workgroup's MFMAs
-static int features_prepass() {        // latched at the first call: dpn_sizes and dpn_fwd must agree on the size of the saved buffer
-    static const int mode = [] { const char* e = getenv("DPN_FEATURES_PREPASS"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
-    return mode;
-}
-static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_pad, ns) + (features_prepass() ? feature_bytes(n_pad, ns) : 0); }
+static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_pad, ns); }
 
 struct OperandView {     // written by dpn_bwd_points
     KMat Z1;             // [6][NS] x 256   (round 5: Z is not an operand any more, dpn_finish_gside_kernel)
@@ -623,8 +657,6 @@ struct FwdArgs {
     float* out_n;
     float* jac_n;
     void* saved;
-    const char* feat;        // positional features of dpn_features_kernel (tile-split kernel, DPN_FEATURES_PREPASS=1), else null
-    int feat_table_only;     // DPN_FEATURES_PREPASS=2: `feat` holds only the d pe3 / d xi table (the features themselves are evaluated in the kernel)
     const float* ref;        // [N][6] added to the output in place of coord_data (VariableNet.forward's own ref_data argument), else null
 #ifdef DPN_TIMELINE
     unsigned* timeline;      // [blocks][6 nets][8 wave slots][64]: s_memtime (low word) at the start of every pipeline step (experiment build only)
@@ -2263,6 +2295,14 @@ __global__ void dpn_selftest_kernel(float* out) {
 
 // ------------------------------------------------------------------------------------------------ C ABI
 static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
+// hi+lo mode: the tile-split kernels (dpn_fwd_tiles.h; 64 points per workgroup, two workgroups per CU).  Caller-encoded coordinates and the
+// single-bf16 mode stay on the ring kernels.  DPN_FWD_KERNEL / DPN_BWD_KERNEL = ring | tiles override (read per call: the tests compare the two
+// decompositions inside one process).
+static inline int64_t fused_scratch_offset(int prec) { return (((int64_t)kNets * pack_bytes_per_net(prec) + 255) / 256) * 256; }
+static inline bool use_tiles(const char* knob, int prec, bool has_pe_in) {
+    const char* force = getenv(knob);
+    return (force ? (force[0] == 't') : (prec == 2)) && !has_pe_in;
+}
 #if DPN_HAS_REST
 // Point ranges per product.  One 8-wave workgroup per CU (the LDS ring fills it) and a kernel time that falls as 1 / workgroups up to
 // one round (measured, hi+lo mode, 37 265 points: 120 workgroups 671 us, 192 452 us, 240 396 us, 288 562 us -- the tail round), so
@@ -2272,12 +2312,13 @@ static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 // a plateau at 5.0 TB/s.  Single bf16 (rings of four and five): 10,11,10,11 156 us, 10,10,9,13 160-163 us.
 struct SplitPlan { int s[4]; int most; };
 // Round 5: three products (s[0] = 0: M2^T Z is gone, dpn_finish_gside_kernel).  The 42 ranges per net go to them in the proportions the
-// four-product plans had found (hi+lo 10,10,9,13 -> 13,12,17; single bf16 10,11,10,11 -> 14,13,15).
+// four-product plans had found (single bf16 10,11,10,11 -> 14,13,15) or a sweep did (hi+lo, tools/wgrad_overlap_probe.py, profiles/round5_wgrad_plans.txt:
+// 13,12,17 250 us, 12,12,18 226, 14,12,16 214, 13,11,18 215, 14,11,17 214, 12,11,19 219, 15,12,15 219, 13,13,16 215).
 static inline SplitPlan choose_plan(int64_t n_pad, int ns) {
     int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
     SplitPlan p;
-    if (c >= 10) p = (ns == 2) ? SplitPlan{{0, 13, 12, 17}, 17} : SplitPlan{{0, 14, 13, 15}, 15};
+    if (c >= 10) p = (ns == 2) ? SplitPlan{{0, 14, 12, 16}, 16} : SplitPlan{{0, 14, 13, 15}, 15};
     else p = SplitPlan{{0, (int)c, (int)c, (int)c}, (int)c};
 #ifdef DPN_EXPERIMENT_SPLITS                     // timing experiments only: DPN_WGRAD_PLAN="9,12,10,11"
     if (const char* e = getenv("DPN_WGRAD_PLAN")) {
@@ -2297,13 +2338,16 @@ static inline int ck(hipError_t e) { return (int)e; }
 extern "C" {
 
 #if DPN_HAS_REST
-int dpn_version(void) { return 1; }
+int dpn_version(void) { return 2; }
+
+// which packed form (dpn_pack_weights_form) the forward launch of this precision mode expects: 1 = fused (tile-split kernel), 0 = ring stream
+int dpn_fwd_form(int prec, int has_pe_in) { return use_tiles("DPN_FWD_KERNEL", prec, has_pe_in != 0) ? 1 : 0; }
 
 int dpn_sizes(int64_t n, int prec, DpnSizes* out) {
     if (!out || n <= 0 || (prec != 1 && prec != 2)) return -1;
     const int64_t n_pad = pad_points(n);
     out->n_pad = n_pad;
-    out->packed = (int64_t)kNets * pack_bytes_per_net(prec);
+    out->packed = fused_scratch_offset(prec) + fused_scratch_bytes();      // the six nets' blocks + the fp32 [A | B] scratch of the fused form
     out->saved = saved_bytes(n_pad, prec);
     out->operands = operand_bytes(n_pad, prec);
     out->k_splits = choose_plan(n_pad, prec).most;
@@ -2311,15 +2355,45 @@ int dpn_sizes(int64_t n, int prec, DpnSizes* out) {
     return 0;
 }
 
-int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, void* stream) {
-    if (!nets || !packed || (prec != 1 && prec != 2)) return -1;
+static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream);
+
+// form 0: the seven-GEMM stream of the ring kernels; form 1: the fused five-GEMM stream of dpn_fwd_tiles_kernel (dpn_layout.h) -- a GEMM launch
+// forms A = W1 w2 and B = W1 Wd (exact fp32 matrix cores, 12 problems) in the scratch tail of `packed`, the pack kernel splits them into fragments
+int dpn_pack_weights_form(const DpnNetPtrs nets[DPN_NETS], int prec, int form, void* packed, void* stream) {
+    if (!nets || !packed || (prec != 1 && prec != 2) || (form != 0 && form != 1)) return -1;
     PackArgs a;
     for (int k = 0; k < kNets; ++k) a.net[k] = nets[k];
     a.packed = reinterpret_cast<char*>(packed);
     a.ns = prec;
+    a.form = form;
+    a.fused = nullptr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(40 + 1, kNets), dim3(256), 0, s, a);
+    if (form == 1) {
+        float* F = reinterpret_cast<float*>(a.packed + fused_scratch_offset(prec));
+        a.fused = F;
+        DpnGemmProblem q[4 * kNets] = {};
+        for (int k = 0; k < kNets; ++k) {
+            // rows o of [A | W1 b2 | B | W1 bd | W1 e] (dpn_layout.h):  W1 . [w2 | b2] (N = 257: the hyper-network's row is [w2 | b2]),  W1 . Wd,  W1 . bd,  W1 . e
+            const float* Bm[4] = {nets[k].w2b2, nets[k].Wd, nets[k].bd, nets[k].evec};
+            const int ldb[4] = {(int)nets[k].ld_w2b2, kPe, 1, 1}, nn[4] = {kHidden + 1, kPe, 1, 1}, col[4] = {0, kFusedColB, kFusedColBd, kFusedColE};
+            for (int j = 0; j < 4; ++j) {
+                DpnGemmProblem& p = q[4 * k + j];
+                p.A[0] = nets[k].W1; p.lda[0] = kHidden;
+                p.B[0] = Bm[j]; p.ldb[0] = ldb[j];
+                p.C = F + (int64_t)k * kHidden * kFusedCols + col[j];
+                p.M = kHidden; p.N = nn[j]; p.K = kHidden; p.ldc = kFusedCols; p.ta = 0; p.tb = 0; p.nterms = 1;
+            }
+        }
+        const int rc = sgemm_batch_launch(4 * kNets, q, 0, nullptr, stream);
+        if (rc) return rc;
+    }
+    const int cols = form == 1 ? 28 : 40;                                // block columns of matrix fragments (+ 1 for the vectors): 544 / 800 KB per net
+    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(cols + 1, kNets), dim3(256), 0, s, a);
     return ck(hipGetLastError());
+}
+
+int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, void* stream) {
+    return dpn_pack_weights_form(nets, prec, dpn_fwd_form(prec, 0), packed, stream);
 }
 
 #endif  // DPN_HAS_REST
@@ -2347,9 +2421,9 @@ static int fwd_launch(const float* x, const float* y, const float* t, const floa
     if (!coord_data || !freqs || !geo || !packed || !out_n || n <= 0 || (prec != 1 && prec != 2)) return -1;
     if (!pe_in && (!x || !y || !t)) return -1;
 #ifdef DPN_TIMELINE
-    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, 0, ref_data, g_timeline};
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, ref_data, g_timeline};
 #else
-    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, nullptr, 0, ref_data};
+    FwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), out_n, jac_n, saved, ref_data};
 #endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), n_nets);
@@ -2363,17 +2437,8 @@ static int fwd_launch(const float* x, const float* y, const float* t, const floa
     // hi+lo mode: the tile-split kernel (dpn_fwd_tiles.h; 64 points per workgroup, two workgroups per CU).  Caller-encoded coordinates
     // and the single-bf16 mode stay on the ring kernel (one bf16 product per fragment pair cannot pay for the doubled weight stream).
     // DPN_FWD_KERNEL=ring|tiles overrides (A/B measurements, bitwise comparison of the two kernels in the tests).
-    const char* force = getenv("DPN_FWD_KERNEL");          // read per call: the tests switch kernels inside one process
-    const bool tiles = force ? (force[0] == 't') : (prec == 2);
-    if (tiles && !pe_in) {
+    if (use_tiles("DPN_FWD_KERNEL", prec, pe_in != nullptr)) {    // (expects the FUSED packed form: dpn_fwd_form)
         const dim3 grid64((unsigned)(a.n_pad / 64), n_nets);
-        if (saved && features_prepass()) {             // positional features once per point (read by the six nets' workgroups)
-            char* feat = reinterpret_cast<char*>(saved) + saved_state_bytes(a.n_pad, prec);
-            a.feat = feat;
-            a.feat_table_only = features_prepass() == 2;
-            if (prec == 1) hipLaunchKernelGGL(dpn_features_kernel<1>, dim3(grid64.x), dim3(256), 0, s, a, feat);
-            else hipLaunchKernelGGL(dpn_features_kernel<2>, dim3(grid64.x), dim3(256), 0, s, a, feat);
-        }
         if (prec == 1) hipLaunchKernelGGL(dpn_fwd_tiles_kernel<1>, grid64, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(dpn_fwd_tiles_kernel<2>, grid64, dim3(256), 0, s, a);
         return ck(hipGetLastError());
@@ -2434,9 +2499,7 @@ int dpn_bwd_points(const float* x, const float* y, const float* t, const float* 
 #endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
-    const char* force = getenv("DPN_BWD_KERNEL");          // ring | tiles (A/B measurements, bitwise comparison in the tests)
-    const bool tiles = force ? (force[0] == 't') : (prec == 2);
-    if (tiles && !pe_in) {
+    if (use_tiles("DPN_BWD_KERNEL", prec, pe_in != nullptr)) {    // ring | tiles: bit-identical operands (tests); both read w1 at S0 of either packed form
         const dim3 grid64((unsigned)(a.n_pad / 64), kNets);
         if (prec == 1) hipLaunchKernelGGL(dpn_bwd_tiles_kernel<1>, grid64, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(dpn_bwd_tiles_kernel<2>, grid64, dim3(256), 0, s, a);

@@ -742,7 +742,7 @@ class _EncoderStackFn(torch.autograd.Function):
         # four launches before the chain ends; only the token convolution's product (it needs d x0) stays behind the last launch.  Only for a
         # single field's row count (batches cut the reductions into slices: their own second launch) and only while every gradient so far is a
         # fresh slot of the optimiser's flat buffer (autograd keeps such a view as param.grad without touching it on the main stream).
-        may_fork = branch.enabled() and n <= 2048
+        may_fork = branch.enabled('wgrad16') and n <= 2048
 
         def flush(on_side):
             nonlocal batch, jobs, keep
@@ -790,7 +790,8 @@ class _EncoderStackFn(torch.autograd.Function):
             wgrad(base + 2, base + 3, D, dk, x)
             wgrad(base + 4, base + 5, D, dv, x)
             res = gs1
-            flush(True)
+            if l == 1:
+                flush(True)                                          # ONE fork: everything above the first layer (a fork / join pair costs 10-16 us)
         dx0 = new(n, D)
         emb = getattr(ctx.share, 'embed', None) if ctx.share is not None else None
         if emb is not None and B == 1 and n < 1024 and emb.get('token') is not None:

@@ -132,7 +132,10 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     lib = L.load()
     n = coord_data.shape[0]
     dev = coord_data.device
-    L.check(lib.dpn_pack_weights(nets, cfg.prec, _ptr(ws.packed), _stream()), 'dpn_pack_weights')
+    # the packed form the forward launch reads: fused (A = W1 w2, B = W1 Wd: five GEMMs per point and net) for the hi+lo mode's tile-split kernel,
+    # the plain matrices for the ring kernels (plain bf16, caller-encoded coordinates)
+    form = lib.dpn_fwd_form(cfg.prec, 0 if pe_in is None else 1)
+    L.check(lib.dpn_pack_weights_form(nets, cfg.prec, form, _ptr(ws.packed), _stream()), 'dpn_pack_weights')
     out_n = torch.empty((n, 6), dtype=torch.float32, device=dev)
     # with caller-encoded coordinates the kernel hands back d out / d pe_in [n, 6, 192] in place of the (x, y, t) Jacobian
     jac_n = torch.empty((n, 6, 3 if pe_in is None else 192), dtype=torch.float32, device=dev) if want_jac else None
@@ -186,7 +189,7 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
     L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
     # (only when every static gradient is a freshly leased slot of the optimiser's flat buffer: autograd then keeps the view as param.grad without
     # touching it; a gradient it would have to ADD to an existing one on the main stream must be complete when the node returns)
-    if fork and arena and branch.enabled():
+    if fork and arena and branch.enabled('finish'):
         L.check(lib.dpn_wgrad_finish_parts(nets, _ptr(ws.packed), n, cfg.prec, _ptr(partials), garr, 1, _stream()), 'dpn_wgrad_finish')
         # keep: what the branch READS (not the 48 gradient slots: they are persistent, and a second reference to a returned gradient makes
         # autograd copy it instead of keeping the view as param.grad)

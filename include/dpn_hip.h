@@ -81,7 +81,15 @@ int dpn_sizes(int64_t n_points, int prec, DpnSizes* out);
 /* fp32 tables: freq32 = 2**linspace(0,4,32), freq16 = 2**linspace(0,4,16) formed in fp32 exactly as
  * utils/position_encoding.py:27 does.  Copied to the device by the caller (8 + 4 = 48 floats: [32 | 16]). */
 
-/* Weight preparation: fp32 tensors -> MFMA-fragment-ordered bf16 (hi/lo) + permuted fp32 vectors + u = W2^T wo. */
+/* Weight preparation: fp32 tensors -> MFMA-fragment-ordered bf16 (hi/lo) + permuted fp32 vectors + u = W2^T wo.
+ * Two forms of the packed block (csrc/dpn_layout.h): form 0 = the matrices of variable_net.py:49-87 as they stand (w1, w2, Wd, W1 and their
+ * transposes: seven GEMMs per point and net); form 1 = FUSED: A = cat_fc1.fc.0.weight . w2 and B = cat_fc1.fc.0.weight . data_input_fc.weight
+ * are formed once per net in exact fp32 (variable_net.py:81-84 applies fc.0 to c = w2 h1 + Wd pe6 + ..., so pre2 = A h1 + B pe6 + const, and the
+ * reverse sweep needs only A^T): five GEMMs per point and net, c and d out / d c never formed.  dpn_fwd_form says which form the forward launch of
+ * a precision mode reads (1: hi+lo mode with raw coordinates; 0: plain bf16, or caller-encoded coordinates); dpn_pack_weights packs that form
+ * for raw coordinates.  The backward entry points read w1 and the vectors, which sit at the same offsets in both forms. */
+int dpn_fwd_form(int prec, int has_pe_in);
+int dpn_pack_weights_form(const DpnNetPtrs nets[DPN_NETS], int prec, int form, void* packed, void* stream);
 int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, void* stream);
 
 /* Forward + coordinate Jacobian (replaces PhysicsNet.forward's six VariableNet calls, physics_net.py:49-54,

@@ -68,22 +68,36 @@ def hyper_weights(state, net, meta_out, fore_h):
     return w1b1, w2b2, e
 
 
-def phase_a(W, pe, dpe, pe6, ref, prec):
-    """fwd value + reverse sweep.  Returns normalised out [N], J_xi [N,3] and the saved per-point state."""
+def phase_a(W, pe, dpe, pe6, ref, prec, fused=False):
+    """fwd value + reverse sweep.  Returns normalised out [N], J_xi [N,3] and the saved per-point state.
+
+    fused (round 5, csrc/dpn_fwd_tiles.h + dpn_layout.h): W1 = cat_fc1.fc.0.weight only ever multiplies c = w2 h1 + Wd pe6 + cvec and W1^T only
+    ever meets w2^T on the way back, so with A = W1 w2 and B = W1 Wd formed once per net (exact)
+        pre2 = A h1 + B pe6 + (W1 cvec + bf1),   wo . c = (w2^T wo) . h1 + (Wd^T wo) . pe6 + wo . cvec,   y = A^T (m2 (.) u) + 2 w2^T wo:
+    five GEMMs per point and net instead of seven; c and v = d out / d c are never formed (the backward pass needs neither: phase_b)."""
     w1, b1, w2, b2 = W['w1b1'][:, :192], W['w1b1'][:, 192], W['w2b2'][:, :256], W['w2b2'][:, 256]
     pre1 = mm(pe, w1.T, prec) + b1
     m1 = (pre1 > 0).to(pe.dtype)
     h1 = pre1 * m1
     cvec = b2 + W['bd'] + W['e']
-    c = mm(h1, w2.T, prec) + mm(pe6, W['Wd'].T, prec) + cvec
-    pre2 = mm(c, W['W1'].T, prec) + W['bf1']
-    m2 = (pre2 > 0).to(pe.dtype)
-    a = pre2 * m2
     u = W['W2'].T @ W['wo']                                            # [256]
-    out = a @ u + 2.0 * (c @ W['wo']) + (W['wo'] @ W['bf2'] + W['bo']) + ref
-    t2 = m2 * u
-    v = mm(t2, W['W1'], prec) + 2.0 * W['wo']
-    y = mm(v, w2, prec)
+    if fused:
+        A, B = W['W1'] @ w2, W['W1'] @ W['Wd']
+        a2 = w2.T @ W['wo']
+        pre2 = mm(h1, A.T, prec) + mm(pe6, B.T, prec) + (W['W1'] @ cvec + W['bf1'])
+        m2 = (pre2 > 0).to(pe.dtype)
+        out = (pre2 * m2) @ u + 2.0 * (h1 @ a2 + pe6 @ (W['Wd'].T @ W['wo']) + W['wo'] @ cvec) + (W['wo'] @ W['bf2'] + W['bo']) + ref
+        y = mm(m2 * u, A, prec) + 2.0 * a2
+        v = None
+    else:
+        c = mm(h1, w2.T, prec) + mm(pe6, W['Wd'].T, prec) + cvec
+        pre2 = mm(c, W['W1'].T, prec) + W['bf1']
+        m2 = (pre2 > 0).to(pe.dtype)
+        a = pre2 * m2
+        out = a @ u + 2.0 * (c @ W['wo']) + (W['wo'] @ W['bf2'] + W['bo']) + ref
+        t2 = m2 * u
+        v = mm(t2, W['W1'], prec) + 2.0 * W['wo']
+        y = mm(v, w2, prec)
     t1 = m1 * y
     gpe = mm(t1, w1, prec)                                             # [N,192]
     jxi = (gpe.reshape(pe.shape[0], 32, 2, 3) * dpe).sum(dim=(1, 2))   # [N,3]
@@ -197,7 +211,7 @@ def net_weights(state, net, meta_out, fore_h):
                 bf2=p('cat_fc1.fc.2.bias'), wo=p('out_fc.weight')[0], bo=p('out_fc.bias')[0])
 
 
-def pde_step(state, x, y, t, f, field, coord_data, forecast_h, geo, with_clip=True, prec='fp32', meta_out=None):
+def pde_step(state, x, y, t, f, field, coord_data, forecast_h, geo, with_clip=True, prec='fp32', meta_out=None, fused=True):
     """The whole restructured place_one_batch + backward to the per-net kernel-level gradients."""
     dt = x.dtype
     with torch.no_grad():
@@ -210,7 +224,7 @@ def pde_step(state, x, y, t, f, field, coord_data, forecast_h, geo, with_clip=Tr
         Ws, Ss, outs, jxis = [], [], [], []
         for k, net in enumerate(O.NETS):
             W = net_weights(state, net, meta_out, forecast_h)
-            out, jxi, S = phase_a(W, pe, dpe, pe6, coord_data[:, k], prec)
+            out, jxi, S = phase_a(W, pe, dpe, pe6, coord_data[:, k], prec, fused=fused)
             Ws.append(W), Ss.append(S), outs.append(out), jxis.append(jxi)
         out_n = torch.stack(outs, 1)
         jn = torch.stack(jxis, 1) * scale

@@ -36,14 +36,16 @@ def test_sizes_host_function():
     sz = _lib.DpnSizes()
     assert lib.dpn_sizes(37265, 1, ctypes.byref(sz)) == 0
     assert sz.n_pad == 37376 and sz.n_pad % 128 == 0
-    assert sz.packed == 6 * (800 * 1024 + 6 * 1024 + 16)
+    blocks = 6 * (800 * 1024 + 6 * 1024 + 16)                   # six nets' fragment blocks + vectors, then (256-byte aligned) the fp32 [A | B] scratch
+    assert sz.packed == (blocks + 255) // 256 * 256 + 6 * 256 * 456 * 4              # of the fused form (dpn_pack_weights_form, csrc/dpn_layout.h)
+    assert lib.dpn_fwd_form(2, 0) == 1 and lib.dpn_fwd_form(2, 1) == 0 and lib.dpn_fwd_form(1, 0) == 0
     sz2 = _lib.DpnSizes()
     assert lib.dpn_sizes(37265, 2, ctypes.byref(sz2)) == 0
     assert sz2.saved > sz.saved and sz2.operands > sz.operands
     # point ranges of the weight-gradient kernel: a per-product plan that fills one round of the chip at full size (42 workgroups per
-    # net over the three products M2^T Z1, M2^T G6, T1^T Z0: 14,13,15 ranges in single bf16, 13,12,17 in the hi+lo mode), one range per 16
+    # net over the three products M2^T Z1, M2^T G6, T1^T Z0: 14,13,15 ranges in single bf16, 14,12,16 in the hi+lo mode), one range per 16
     # tiles below that; k_splits (the most ranges one product is cut into) dimensions the partial-sum buffer
-    assert sz.k_splits == 15 and sz2.k_splits == 17
+    assert sz.k_splits == 15 and sz2.k_splits == 16
     small = _lib.DpnSizes()
     assert lib.dpn_sizes(1037, 2, ctypes.byref(small)) == 0 and small.k_splits == 2
     assert lib.dpn_sizes(256, 1, ctypes.byref(small)) == 0 and small.k_splits == 1

@@ -1117,13 +1117,15 @@ def test_config4_fp8_encoder_workload():
 
 @pytest.mark.parametrize('prec', ['bf16x2', 'bf16'])
 @pytest.mark.parametrize('n', [1037, 70])
-def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n, prec):
-    """The hi+lo mode's forward + Jacobian and backward stage-1 kernels exist in two decompositions: the ring form (one 512-register wave
-    per SIMD owns 32 points and all output tiles, weights shared through an LDS-DMA ring) and the tile-split form (the default: output
-    tiles split over the waves, activations shared through LDS, weights L2 -> VGPR, two workgroups per CU; csrc/dpn_fwd_tiles.h).  Both run
-    the same products in the same order per output tile, so everything they hand to the later kernels -- the saved state T1, M2, m1,
-    the Jacobian, the operands Z1, Z0, G6, gnet -- must agree BIT FOR BIT (the fields differ in the order the four waves' partial sums
-    are added: 1e-6).  Ragged sizes: 1037 = 16 full 64-point workgroups + 13 points, 70 = one full + 6 points."""
+def test_tile_split_kernels_against_the_ring_kernels(n, prec):
+    """The point kernels exist in two decompositions: the ring form (one 512-register wave per SIMD owns 32 points and all output tiles, weights
+    shared through an LDS-DMA ring; plain bf16 and caller-encoded coordinates) and the tile-split form (the hi+lo mode's default: output tiles
+    split over the waves, activations shared through LDS, weights L2 -> VGPR, two workgroups per CU; csrc/dpn_fwd_tiles.h).
+    BACKWARD stage 1: same products in the same order per output tile -- the operands Z1, Z0, G6, gnet agree BIT FOR BIT.
+    FORWARD: since round 5 the tile-split kernel runs the FUSED algebra (A = W1 w2, B = W1 Wd formed once per net: five GEMMs per point and net,
+    csrc/dpn_layout.h) and the ring kernel the seven GEMMs of variable_net.py:49-87 as they stand -- the same function in two arithmetics, so
+    fields, Jacobian and saved state agree to operand rounding, and the ReLU bits except at pre-activations within rounding distance of zero.
+    Ragged sizes: 1037 = 16 full 64-point workgroups + 13 points, 70 = one full + 6 points."""
     import ctypes
     from deepphysinet_amd import _lib as L, point_path as PP
     inp = synthetic_inputs(n, tag='inter')
@@ -1142,11 +1144,13 @@ def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n, prec):
             ws = PP._Workspace(n, cfg.prec, dev)
             nets = PP._net_ptrs(PP._f32c(heads), PP._f32c(evec), st)
             s = PP._stream()
-            L.check(lib.dpn_pack_weights(nets, cfg.prec, PP._ptr(ws.packed), s), 'pack')
             geo, ph, fr = cfg.geometry(), cfg.physics(), PP._freqs(dev)
             res = {}
             for kind in ('ring', 'tiles'):
                 os.environ['DPN_FWD_KERNEL'] = os.environ['DPN_BWD_KERNEL'] = kind
+                form = lib.dpn_fwd_form(cfg.prec, 0)
+                assert form == (1 if kind == 'tiles' else 0)
+                L.check(lib.dpn_pack_weights_form(nets, cfg.prec, form, PP._ptr(ws.packed), s), 'pack')
                 out_n = torch.zeros((n, 6), device=dev); jac_n = torch.zeros((n, 6, 3), device=dev)
                 saved = torch.zeros(ws.sizes.saved, dtype=torch.uint8, device=dev)
                 L.check(lib.dpn_fwd(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed),
@@ -1155,7 +1159,8 @@ def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n, prec):
                 L.check(lib.dpn_residual(PP._ptr(out_n), PP._ptr(jac_n), PP._ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, None, None,
                                          PP._ptr(g_out), PP._ptr(g_jxi), s), 'res')
                 operands = torch.zeros(ws.sizes.operands, dtype=torch.uint8, device=dev)
-                # the backward kernels of BOTH forms read the ring forward's cotangents, so that only the kernel under test differs
+                # the backward kernels of BOTH forms read the ring forward's cotangents and saved state, so that only the kernel under test differs
+                # (they read w1 and the b1 vector: at the same place in either packed form)
                 if kind == 'ring':
                     go, gj, sv = g_out.clone(), g_jxi.clone(), saved.clone()
                 L.check(lib.dpn_bwd_points(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed),
@@ -1169,8 +1174,24 @@ def test_tile_split_kernels_are_bit_identical_to_the_ring_kernels(n, prec):
             else:
                 os.environ[k] = v
     (o0, j0, s0, p0), (o1, j1, s1, p1) = res['ring'], res['tiles']
-    n_state = 6 * cfg.prec * ws.sizes.n_pad * 512 + 6 * ws.sizes.n_pad * 512 + 6 * ws.sizes.n_pad * 32       # T1 | M2 | m1 (the features behind them are the tile-split form's own)
-    assert torch.equal(j0, j1)
-    assert torch.equal(s0[:n_state], s1[:n_state])
-    assert torch.equal(p0, p1)
-    assert float((o0 - o1).abs().max()) <= 2e-6 * float(o0.abs().max())
+    assert torch.equal(p0, p1)                                                  # backward stage 1: bit for bit
+    n_pad, ns = int(ws.sizes.n_pad), int(cfg.prec)
+    # forward: two arithmetics of one function
+    tol_f, tol_j = (2e-5, 5e-4) if prec == 'bf16x2' else (3e-2, 0.35)
+    assert float((o0 - o1).abs().max()) <= tol_f * float(o0.abs().max())
+    dj = (j0 - j1).abs() / j0.abs().amax(dim=(0, 2), keepdim=True)
+    off = int((dj.amax(dim=(1, 2)) > tol_j).sum())                              # points whose Jacobian differs: those with a flipped ReLU bit
+    if prec == 'bf16x2':
+        t1_bytes, m2_bytes = 6 * ns * n_pad * 512, 6 * n_pad * 512
+        m2a, m2b = s0[t1_bytes:t1_bytes + m2_bytes], s1[t1_bytes:t1_bytes + m2_bytes]
+        m1a, m1b = s0[t1_bytes + m2_bytes:t1_bytes + m2_bytes + 6 * n_pad * 32], s1[t1_bytes + m2_bytes:t1_bytes + m2_bytes + 6 * n_pad * 32]
+        flipped2 = int((m2a.view(torch.int16) != m2b.view(torch.int16)).sum())
+        flipped1 = int(((m1a.view(torch.int32) ^ m1b.view(torch.int32)) != 0).sum())
+        print('ring vs tile-split forward (n = %d): %d differing relu-2 mask entries of %d, %d differing relu-1 words, %d points with a Jacobian row off by > %g'
+              % (n, flipped2, 6 * n * 256, flipped1, off, tol_j))
+        assert flipped2 <= max(4, 6 * n * 256 // 20000) and flipped1 <= max(4, n // 100)
+        assert off <= max(3, n // 100)
+    else:
+        assert off <= n // 4
+
+

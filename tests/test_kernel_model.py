@@ -37,8 +37,9 @@ def full_param_grads_from_kernel_grads(state, meta_out, fore_h, kgrads):
     return full
 
 
+@pytest.mark.parametrize('fused', [True, False])          # the five-GEMM algebra of the tile-split kernels / the seven GEMMs of the ring kernels
 @pytest.mark.parametrize('with_clip,gain', [(True, 1.0), (False, 1.0), (True, 5.0)])
-def test_restructured_equals_autograd_fp64(with_clip, gain):
+def test_restructured_equals_autograd_fp64(with_clip, gain, fused):
     dt = torch.float64
     st = O.make_state(dtype=dt, requires_grad=True, gain=gain)
     inp = {k: v.to(dt) for k, v in synthetic_inputs(96, tag='inter').items()}
@@ -47,7 +48,7 @@ def test_restructured_equals_autograd_fp64(with_clip, gain):
                                              GEO, with_clip=with_clip, return_parts=True)
     jac = O.jacobian_fields(x, y, t, ph)
     res = KM.pde_step(st, inp['x'], inp['y'], inp['t'], inp['f'], inp['field_data'], inp['coord_data'], inp['forecast_h'],
-                      GEO, with_clip=with_clip, prec='fp64')
+                      GEO, with_clip=with_clip, prec='fp64', fused=fused)
     assert torch.allclose(res['out_n'], torch.cat(fn, 1).detach(), rtol=1e-10, atol=1e-10)
     assert torch.allclose(res['jac_phys'], jac.detach(), rtol=1e-8, atol=1e-18)
     mine = res['losses'].numpy()
