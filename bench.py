@@ -173,10 +173,11 @@ def main():
     ap.add_argument('--no-prewarm', action='store_true', help='skip the untimed replays that bring the clock to a steady state (their number depends on timing: '
                                                               'a run that must do a fixed number of optimiser steps -- tests comparing two runs -- switches them off)')
     ap.add_argument('--no-lead-probe', action='store_true', help='skip the 8-lead probe of the configs[2] code path (about 1 s of GPU work)')
-    ap.add_argument('--encoder-fp8', nargs='?', const='1', default=None, choices=['1', 'mx'],
+    ap.add_argument('--encoder-fp8', nargs='?', const='mx', default=None, choices=['mx', '1'],
                     help='BASELINE configs[4]: the encoder layers\' forward GEMMs on fp8 (OCP e4m3) MFMA, bf16x2 Jacobian path; OFF by default -- it moves '
                          'the PDE losses by 1e-2 ... 2e-1 (tests/test_gpu_parity.py::test_config4_fp8_encoder_workload) and buys no time.  '
-                         '"mx": the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 form (one E8M0 scale per 32 k)')
+                         'mx (the default form): block-scaled v_mfma_scale_f32_32x32x64_f8f6f4, one E8M0 scale per 32 k; "1": the shelved non-scaled form with '
+                         'per-row scales (needs the experiment library: python -m deepphysinet_amd.build --experiments)')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -647,17 +648,17 @@ def main():
             # the kernel alone, back to back: the clock the socket's power cap leaves it, and the dense peak AT that clock (peak above = 2.4 GHz)
             sustained['peak_at_this_clock_tflops'] = MFMA_PEAK_BF16 / 1e12 * sustained['sclk_mhz'] / 2400.0
             roof['kernel_back_to_back'] = sustained
-        # operands of the three products per point per net: M2 (0/1 bf16, one plane: 512 B) + Z1, M2 + G6, T1 + Z0
-        # = 2 x 512 + 1792 B of bf16 (the 1792 x2 in the hi+lo mode); neither v (affine in m2: csrc SavedView) nor Z (linear in Z1, G6, g:
-        # dpn_finish_gside_kernel) is an operand any more
-        w_bytes = ws.sizes.n_pad * 6 * (2 * 512 + 1792 * ns)
+        # operands of the three products per point per net: M2 (0/1 bf16, one plane: 512 B) + Z1 (512 B x ns), M2 + [pe6 table], T1 (512 B x ns) + Z0
+        # (384 B x ns); the pe6 table is per POINT (384 B x ns, shared by the six nets: read from HBM once, then from the memory-side cache).  Neither v
+        # (affine in m2), nor Z (linear in Z1, G6, g), nor G6 = g pe6 (formed in registers from the table) is an operand
+        w_bytes = ws.sizes.n_pad * 6 * (2 * 512 + (512 + 512 + 384) * ns) + ws.sizes.n_pad * 384 * ns
         roof_hbm = {'bound': 'hbm', 'kernel': 'dpn_wgrad_kernel<%d>' % ns,
                     'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': w_bytes / (w_ms * 1e-3) / HBM_PEAK, 'kernel_ms': w_ms, 'algorithmic_bytes': w_bytes,
                     'traffic': pmc_traffic('dpn_wgrad_kernel', prec, args.points)[0], 'bwd_points_kernel_ms': b_ms}
-        # backward stage 1 (dpn_bwd_tiles_kernel / dpn_bwd_kernel): per point and net it writes the K-layout operands of the three weight-gradient
-        # products -- Z1 (256 columns) and Z0, G6 (192 columns), each hi (+ lo) bf16 -- and reads 40 B of cotangents: bound by its HBM writes
-        b_bytes = ws.sizes.n_pad * 6 * (512 + 2 * 384) * ns
+        # backward stage 1 (dpn_bwd_tiles_kernel / dpn_bwd_kernel): per point and net it writes the K-layout rows of Z1 (256 columns) and Z0 (192 columns),
+        # hi (+ lo) bf16, per point the pe6 table (192 columns), and reads 40 B of cotangents
+        b_bytes = ws.sizes.n_pad * 6 * (512 + 384) * ns + ws.sizes.n_pad * 384 * ns
         b_traffic = pmc_traffic('dpn_bwd_tiles_kernel' if ns == 2 else 'dpn_bwd_kernel', prec, args.points)[0]
         roof_hbm['bwd_stage1_kernel'] = {'bound': 'hbm', 'kernel': 'dpn_bwd_tiles_kernel<2>' if ns == 2 else 'dpn_bwd_kernel<1>',
                                          'achieved': b_bytes / (b_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
@@ -728,6 +729,8 @@ def main():
                                    'host_cpu': cpu_model, 'host_logical_cores': os.cpu_count(),
                                    'shared_jacobian_variant': {'value': v2, 'seconds_per_pass': secs2,
                                                                'note': 'same oracle, the 18 distinct derivatives taken once (SURVEY 8d variant ii)'}}
+        from deepphysinet_amd.encoder_ops import check_enc_status
+        check_enc_status()                         # raises if an encoder weight left the range of the f16 hi+lo operand split during the run
         print(json.dumps(out))
     if world > 1 or one_rank_rccl:
         torch.distributed.barrier()

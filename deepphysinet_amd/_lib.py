@@ -132,12 +132,7 @@ EXPORTS = {
     'dpn_enc_pack': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_wgrad16_partial_floats': (c_int64, [c_int, c_void_p, c_int]),
     'dpn_wgrad16': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    'dpn_gemm16_partial_floats': (c_int64, [c_int, c_void_p, c_int]),
-    'dpn_gemm16': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'dpn_enc_prep': (c_int, [POINTER(DpnEncPrep), c_void_p]),
-    'dpn_conv16_kp': (c_int64, [c_int]),
-    'dpn_conv16_split': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'dpn_conv16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dpn_enc_fwd': (c_int, [POINTER(DpnEncFwd), c_void_p]),
     'dpn_enc_bwd': (c_int, [POINTER(DpnEncBwd), c_void_p]),
     'dpn_add_ln_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -158,12 +153,24 @@ EXPORTS = {
     'dpn_clip_adam_flat': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                    c_float, c_float, c_void_p, c_void_p]),
     'dpn_clip_adam_flat_dev': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'dpn_gemm_fp8': (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dpn_gemm_fp8_mx': (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dpn_selftest': (c_int, [c_void_p, c_void_p]),
 }
 
+# Shelved experiments (include/dpn_hip_experiments.h): compiled only into libdpn_hip_exp.so (`python -m deepphysinet_amd.build --experiments`), which also
+# holds every product symbol; reached through load_experiments() by the code paths behind the matching frozen switches (config.py)
+EXPERIMENT_EXPORTS = {
+    'dpn_gemm16_partial_floats': (c_int64, [c_int, c_void_p, c_int]),
+    'dpn_gemm16': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'dpn_conv16_kp': (c_int64, [c_int]),
+    'dpn_conv16_split': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_conv16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dpn_gemm_fp8': (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+}
+EXP_LIB_PATH = os.path.join(_HERE, 'libdpn_hip_exp.so')
+
 _lib = None
+_exp = None
 
 # The per-FIELD math (encoder GEMMs, attention, LayerNorm, hyper-network heads, SmoothL1) has plain-torch expressions for host tensors.
 # They exist for the CPU-side tests of the module tree / state_dict contract / encoder math against the reference's golden vectors
@@ -182,6 +189,23 @@ def host_math_or_raise(t, what):
     if not t.is_cuda and not _cpu_reference_math[0]:
         raise RuntimeError('deepphysinet_amd: %s got a tensor on %s; the HIP kernels are the only product path (no CPU fallback). '
                            'deepphysinet_amd._lib.enable_cpu_reference_math() switches the torch expressions on for CPU-side tests.' % (what, t.device))
+
+
+def load_experiments():
+    """dlopen the experiment library (product symbols + the shelved kernels' entry points); raises if it has not been built."""
+    global _exp
+    if _exp is not None:
+        return _exp
+    if not os.path.exists(EXP_LIB_PATH):
+        raise RuntimeError('deepphysinet_amd: a shelved experiment was switched on (deepphysinet_amd/config.py) but %s is missing; build it with '
+                           '`python -m deepphysinet_amd.build --experiments`' % EXP_LIB_PATH)
+    lib = ctypes.CDLL(EXP_LIB_PATH)
+    for name, (res, args) in list(EXPORTS.items()) + list(EXPERIMENT_EXPORTS.items()):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _exp = lib
+    return lib
 
 
 def load():

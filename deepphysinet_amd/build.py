@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, 'csrc', 'dpn_kernels.hip'), os.path.join(HERE, 'csrc', 'dpn_encoder.hip'),
         os.path.join(HERE, 'csrc', 'dpn_sampler.hip'), os.path.join(HERE, 'csrc', 'dpn_fp8.hip'),
         os.path.join(HERE, 'csrc', 'dpn_encoder_chain.hip')]
-DEPS = SRCS + [os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(HERE, 'csrc', 'dpn_fwd_tiles.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h')]
+DEPS = SRCS + [os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(HERE, 'csrc', 'dpn_fwd_tiles.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h'),
+               os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip_experiments.h')]
 LIB = os.path.join(HERE, 'libdpn_hip.so')
 
 
@@ -65,5 +66,37 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+EXP_LIB = os.path.join(HERE, 'libdpn_hip_exp.so')
+EXP_UNITS = (4, 5)            # dpn_fp8.hip (the non-scaled fp8 GEMM), dpn_encoder_chain.hip (dpn_conv16*, dpn_gemm16): include/dpn_hip_experiments.h
+
+
+def build_experiments(force: bool = False) -> str:
+    """libdpn_hip_exp.so: the product objects with the units that hold shelved kernels recompiled -DDPN_EXPERIMENTS (their entry points are
+    compiled out of the product library).  Tests of those kernels and the tools under tools/ that measure them load it."""
+    build_library()
+    deps = DEPS + [os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip_experiments.h')]
+    if not force and os.path.exists(EXP_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(EXP_LIB) for d in deps):
+        return EXP_LIB
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    obj_dir = os.path.join(HERE, 'csrc', '_obj')
+    objs, procs = [], []
+    for i, (src, flags, obj) in enumerate(UNITS):
+        if i in EXP_UNITS:
+            o = os.path.join(obj_dir, 'exp_' + obj)
+            procs.append(subprocess.Popen([hipcc, *COMMON, *flags, '-DDPN_EXPERIMENTS', '-I' + os.path.join(os.path.dirname(HERE), 'include'), '-c', src, '-o', o]))
+            objs.append(o)
+        else:
+            objs.append(os.path.join(obj_dir, obj))
+    for pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, 'hipcc -DDPN_EXPERIMENTS')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', EXP_LIB + '.tmp'], check=True)
+    os.replace(EXP_LIB + '.tmp', EXP_LIB)
+    return EXP_LIB
+
+
 if __name__ == '__main__':
+    import sys
     print(build_library(force=True, verbose=True))
+    if '--experiments' in sys.argv:
+        print(build_experiments(force=True))

@@ -447,6 +447,16 @@ static_assert(kAttnLds <= 160 * 1024, "one workgroup per CU");
 
 }  // namespace
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: the "already set" mark is a bit per device (atomic: two host threads may launch
+// first at the same time; setting the attribute twice is harmless, skipping it on a second GPU is a launch failure)
+#include <atomic>
+static inline bool dpn_first_use_on_device(std::atomic<unsigned long long>& done, unsigned long long& bit) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    bit = 1ull << (d & 63);
+    return (done.load(std::memory_order_acquire) & bit) == 0;
+}
+
 extern "C" {
 
 int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, int batch, float* out, float* P, void* stream) {
@@ -454,8 +464,9 @@ int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, int batc
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.out = out; a.P = P; a.L = L; a.scale = 1.0f / sqrtf((float)kE);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); once = true; }
+    static std::atomic<unsigned long long> done{0};
+    unsigned long long bit;
+    if (dpn_first_use_on_device(done, bit)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); done.fetch_or(bit, std::memory_order_release); }
     hipLaunchKernelGGL(dpn_attn_fwd_kernel, dim3((L + 31) / 32, kH, batch), dim3(kAT), kAttnLds, s, a);
     return (int)hipGetLastError();
 }
@@ -467,8 +478,9 @@ int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o,
     a.q = q; a.k = k; a.v = v; a.o = o; a.go = go; a.P = const_cast<float*>(P); a.dq = dq; a.dk = dk; a.dv = dv; a.L = L;
     a.scale = 1.0f / sqrtf((float)kE);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); once = true; }
+    static std::atomic<unsigned long long> done{0};
+    unsigned long long bit;
+    if (dpn_first_use_on_device(done, bit)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); done.fetch_or(bit, std::memory_order_release); }
     hipLaunchKernelGGL(dpn_attn_bwd_kernel, dim3((L + 31) / 32, kH, 2 * batch), dim3(kAT), kAttnLds, s, a);
     return (int)hipGetLastError();
 }

@@ -27,11 +27,22 @@
 // (1.5 MB) from L2 straight into registers (buffer_load_dwordx4 with a scalar running offset), kPF k-steps ahead and ACROSS the row passes
 // and barriers between the GEMMs (LDS-only barriers: vmcnt stays in flight).  That stream at the CU's ~55 B/clk L2 path is the kernel's
 // bound (~12 us per launch); the MFMAs (2 304 per workgroup) take a third of it.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 
 #include "../../include/dpn_hip.h"
+#ifdef DPN_EXPERIMENTS                       // shelved kernels' entry points (dpn_conv16*, dpn_gemm16): the experiment library only
+#include "../../include/dpn_hip_experiments.h"
+#else
+// (internal in the product build: the strided-GEMM description dpn_wgrad16's problems are expressed in; public only with the experiments header)
+typedef struct DpnGemm16Problem {
+    const float* A; const float* B; float* C; float* asum; const float* bias;
+    int32_t M, N, K, ldc;
+    int64_t a_sm, a_sk, b_sn, b_sk;
+} DpnGemm16Problem;
+#endif
 
 #define DEV __device__ __forceinline__
 
@@ -888,6 +899,7 @@ __global__ __launch_bounds__(256) void dpn_enc_prep_kernel(PrepArgs a) {
     else { const int jj = j - a.na; const float s_ = hv * a.fb[jj]; a.ob[(int64_t)b * 2 * a.nb + 2 * jj] = sinf(s_); a.ob[(int64_t)b * 2 * a.nb + 2 * jj + 1] = cosf(s_); }
 }
 
+#ifdef DPN_EXPERIMENTS
 // Experiment (DPN_CONV16=1): the token convolution's operands split once per step for dpn_conv16.  Its own launch: inside dpn_enc_prep the
 // 29 KB of LDS and the registers of split_row_planes slowed every other block range of that launch (encoder forward 183 -> 189 us).
 __global__ __launch_bounds__(256) void dpn_conv16_split_kernel(ConvSplitArgs a) {
@@ -1033,6 +1045,7 @@ __global__ __launch_bounds__(256) void dpn_conv16_kernel(Conv16Args a) {
         }
     }
 }
+#endif  // DPN_EXPERIMENTS (dpn_conv16_split_kernel, dpn_conv16_kernel)
 
 // ------------------------------------------------------------------------------------------------ weight gradients
 // d W[M][N] = G^T X over the token rows (G: the cotangent [rows][M] of a linear's output, X: its input [rows][N]); d b = column sums of G.
@@ -1459,6 +1472,14 @@ int set_lds(K kernel, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 int img_off(int mat, int nn) { return (mat * 2 + nn) * kImgBytes; }
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: the "already set" mark is a bit per device (atomic: two host threads may launch
+// first at the same time; setting the attribute twice is harmless, skipping it on a second GPU is a launch failure)
+bool first_use_on_device(std::atomic<unsigned long long>& done, unsigned long long& bit) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    bit = 1ull << (d & 63);
+    return (done.load(std::memory_order_acquire) & bit) == 0;
+}
 
 }  // namespace
 
@@ -1513,16 +1534,18 @@ static int gemm16_launch(int n, const DpnGemm16Problem* problems, int n_jobs, co
     return (int)hipGetLastError();
 }
 
-int64_t dpn_gemm16_partial_floats(int n, const DpnGemm16Problem* problems, int slices) {
+static int64_t gemm16_partial_floats(int n, const DpnGemm16Problem* problems, int slices) {
     if (n <= 0 || !problems || slices <= 1) return 0;
     int64_t tot = 0;
     for (int i = 0; i < n; ++i) tot += (int64_t)slices * ((int64_t)problems[i].M * problems[i].N + (problems[i].asum ? problems[i].M : 0));
     return tot;
 }
-
+#ifdef DPN_EXPERIMENTS
+int64_t dpn_gemm16_partial_floats(int n, const DpnGemm16Problem* problems, int slices) { return gemm16_partial_floats(n, problems, slices); }
 int dpn_gemm16(int n, const DpnGemm16Problem* problems, int slices, float* partials, int reduce, void* stream) {
     return gemm16_launch(n, problems, 0, nullptr, slices, partials, reduce, stream);
 }
+#endif
 
 static int wgrad_as_gemm16(int n, const DpnWgradProblem* problems, DpnGemm16Problem* out) {
     for (int i = 0; i < n; ++i) {
@@ -1537,7 +1560,7 @@ int64_t dpn_wgrad16_partial_floats(int n, const DpnWgradProblem* problems, int s
     if (n <= 0 || n > kWgMaxProblems || !problems || slices <= 1) return 0;
     DpnGemm16Problem g[kWgMaxProblems];
     if (wgrad_as_gemm16(n, problems, g)) return 0;
-    return dpn_gemm16_partial_floats(n, g, slices);
+    return gemm16_partial_floats(n, g, slices);
 }
 
 int dpn_wgrad16(int n, const DpnWgradProblem* problems, int n_jobs, const DpnColsumJob* jobs, int slices, float* partials, void* stream) {
@@ -1576,6 +1599,7 @@ int dpn_enc_prep(const DpnEncPrep* p, void* stream) {
     return (int)hipGetLastError();
 }
 
+#ifdef DPN_EXPERIMENTS
 int64_t dpn_conv16_kp(int K) { return K <= 0 ? 0 : ((int64_t)K + 31) / 32 * 32; }
 
 int dpn_conv16_split(const float* x, int T, int C, int batch, const float* conv_w, int conv_n, void* xs, int32_t* xe, void* ws, int32_t* we, void* stream) {
@@ -1603,6 +1627,7 @@ int dpn_conv16(const void* xs, const int32_t* xe, const void* ws, const int32_t*
     hipLaunchKernelGGL(dpn_conv16_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
+#endif  // DPN_EXPERIMENTS
 
 int dpn_enc_fwd(const DpnEncFwd* p, void* stream) {
     if (!p || !p->wpack || p->rows <= 0 || p->n_mats <= 0 || p->n_mats > DPN_ENC_MAX_MATS || p->next < 0 || p->next > 2) return -1;
@@ -1637,13 +1662,14 @@ int dpn_enc_fwd(const DpnEncFwd* p, void* stream) {
     a.n_main = (p->rows + rpw - 1) / rpw; a.n_img = ni;
     // the warm-up helpers pay while the working workgroups are few (one or a few field samples); a batch of fields warms the L2s by itself
     const dim3 grid(a.n_main + (a.n_main <= 64 && !getenv("DPN_ENC_NO_HELPERS") ? kHelpers : 0)), block(kThreads);
-    static bool once = false;
+    static std::atomic<unsigned long long> done{0};
+    unsigned long long dev_bit;
 #define DPN_ENC_FWD_CASES(X) X(true, 0) X(true, 1) X(true, 2) X(false, 1)
-    if (!once) {
+    if (first_use_on_device(done, dev_bit)) {
 #define X(T, N) if (set_lds(dpn_enc_fwd_kernel<T, N, 1>, Lds<1>::kBytes) || set_lds(dpn_enc_fwd_kernel<T, N, 2>, Lds<2>::kBytes)) return -2;
         DPN_ENC_FWD_CASES(X)
 #undef X
-        once = true;
+        done.fetch_or(dev_bit, std::memory_order_release);
     }
 #define X(T, N) if ((p->tail != 0) == T && p->next == N) { \
         if (wide) hipLaunchKernelGGL((dpn_enc_fwd_kernel<T, N, 2>), grid, block, Lds<2>::kBytes, s, a); \
@@ -1686,13 +1712,14 @@ int dpn_enc_bwd(const DpnEncBwd* p, void* stream) {
     const int rpw = wide ? 32 : 16;
     a.n_main = (p->rows + rpw - 1) / rpw; a.n_img = ni;
     const dim3 grid(a.n_main + (a.n_main <= 64 && ni > 0 && !getenv("DPN_ENC_NO_HELPERS") ? kHelpers : 0)), block(kThreads);
-    static bool once = false;
+    static std::atomic<unsigned long long> done{0};
+    unsigned long long dev_bit;
 #define DPN_ENC_BWD_CASES(X) X(0, true) X(1, true) X(2, true) X(1, false)
-    if (!once) {
+    if (first_use_on_device(done, dev_bit)) {
 #define X(H, B) if (set_lds(dpn_enc_bwd_kernel<H, B, 1>, Lds<1>::kBytes) || set_lds(dpn_enc_bwd_kernel<H, B, 2>, Lds<2>::kBytes)) return -2;
         DPN_ENC_BWD_CASES(X)
 #undef X
-        once = true;
+        done.fetch_or(dev_bit, std::memory_order_release);
     }
 #define X(H, B) if (p->head == H && (p->body != 0) == B) { \
         if (wide) hipLaunchKernelGGL((dpn_enc_bwd_kernel<H, B, 2>), grid, block, Lds<2>::kBytes, s, a); \

@@ -15,6 +15,9 @@
 #include <stdint.h>
 
 #include "../../include/dpn_hip.h"
+#ifdef DPN_EXPERIMENTS
+#include "../../include/dpn_hip_experiments.h"
+#endif
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define DEV __device__ __forceinline__
@@ -52,6 +55,7 @@ DEV long quant8(const float* p, float inv_scale, bool valid) {      // eight con
     return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
 }
 
+#ifdef DPN_EXPERIMENTS
 __global__ __launch_bounds__(256) void dpn_gemm_fp8_kernel(Fp8Args a) {
     __shared__ float s_row[32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(256) void dpn_gemm_fp8_kernel(Fp8Args a) {
         }
     }
 }
+#endif  // DPN_EXPERIMENTS (the non-scaled form)
 
 
 // ---- the block-scaled (MX) form: v_mfma_scale_f32_32x32x64_f8f6f4, the only large-K fp8 MFMA of gfx950 (twice the rate of the instruction
@@ -167,6 +172,7 @@ extern "C" int dpn_gemm_fp8_mx(int M, int N, int K, const float* A, int lda, con
     return (int)hipGetLastError();
 }
 
+#ifdef DPN_EXPERIMENTS                       // the non-scaled fp8 form (per-row scales): shelved, experiment library only
 extern "C" int dpn_gemm_fp8(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int epi,
                             float* aux_out, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || (K & 15) || (lda & 3) || (ldw & 3) || (epi != DPN_EPI_NONE && epi != DPN_EPI_GELU)) return -1;
@@ -174,3 +180,4 @@ extern "C" int dpn_gemm_fp8(int M, int N, int K, const float* A, int lda, const 
     hipLaunchKernelGGL(dpn_gemm_fp8_kernel, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
+#endif

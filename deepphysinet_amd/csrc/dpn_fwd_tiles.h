@@ -623,20 +623,21 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// Backward, stage 1 (per-point cotangent streams -> operands of the weight-gradient reductions), tile-split form.  Same arithmetic and same
-// operand layout as dpn_bwd_kernel (bit-identical Z0, Z1, G6, gnet); decomposition as dpn_fwd_tiles_kernel: 64 points per workgroup, wave
-// w owns tiles 2w, 2w+1 of both column tiles, the cotangent fragments are shared through LDS, the weights come L2 -> VGPR.
+// Backward, stage 1 (per-point cotangent streams -> operands of the weight-gradient reductions), tile-split form.  Same arithmetic and same operand
+// layout as dpn_bwd_kernel (bit-identical Z0, Z1, pe6 table, gnet); decomposition as dpn_fwd_tiles_kernel: 64 points per workgroup, wave w owns tiles
+// 2w, 2w+1 of both column tiles, the cotangent fragments are shared through LDS, the weights come L2 -> VGPR.
 //   Z0 = g pe + sum_c gJ_c d pe / d xi_c                      -> X, K-layout rows (operand of dw1 = T1^T Z0)
 //   Z1 = m1 (.) (w1 Z0 + g b1)                                -> K-layout rows (operand of S1 = M2^T Z1)
-//   G6 = g pe6                                                -> K-layout rows (operand of S2 = M2^T G6)
+//   net 0 only: the per-point table pe6                       -> K-layout rows (from which dpn_wgrad_kernel forms G6 = g pe6 of every net: OperandView)
 // Round 5: Z = w2 Z1 + Wd G6 + g (b2 + bd + e) is no longer formed.  It existed only as the Y operand of G = M2^T Z, and being linear in
-// (Z1, G6, g) that product is S1 w2^T + S2 Wd^T + (M2^T g) (x) cvec: one exact-fp32 GEMM per net behind the reduction
-// (dpn_finish_gside_kernel) instead of 114 688 of this kernel's 163 840 MACs per point and net, a 1-KB row written per point and net, and a
-// fourth points-reduction product reading it back.
+// (Z1, G6, g) that product is S1 w2^T + S2 Wd^T + (M2^T g) (x) cvec: one exact-fp32 GEMM per net behind the reduction (dpn_finish_gside_kernel)
+// instead of 114 688 of this kernel's 163 840 MACs per point and net, a 1-KB row written per point and net, and a fourth points-reduction product.
+// LDS: the X image of 12 k-steps (48 KB in the hi+lo mode) + the b1 vector: 49 KB, <= 168 registers => THREE workgroups per CU (the kernel is a chain of
+// feature evaluation, one short multiply loop and streaming stores: more waves in flight is what hides them).
 template <int NS>
-__global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
-    using C = ts::Cfg<NS>;
-    __shared__ __attribute__((aligned(16))) char lds[C::kLdsBytes];
+__global__ __launch_bounds__(256, 3) void dpn_bwd_tiles_kernel(BwdArgs a) {
+    constexpr int kXBytes = 12 * 2 * NS * 1024;
+    __shared__ __attribute__((aligned(16))) char lds[kXBytes + 1024];
     const int net = blockIdx.y;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -645,15 +646,11 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
 #if TS_PRIO == 2
     __builtin_amdgcn_s_setprio(1);
 #endif
-    float* vec = reinterpret_cast<float*>(lds + C::kVecOff);
+    float* vec = reinterpret_cast<float*>(lds + kXBytes) - kVecB1 * 256;     // only b1 is read (acc_init indexes vec + which * 256)
     char* xl = lds + lane * 16;
     {
-        const u32x4* gv = reinterpret_cast<const u32x4*>(pk + (long)kPackKB * 1024 * NS);
-        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
-        const u32x4 v0 = gv[i0];
-        const u32x4 v1 = gv[i1 < ts::kVecFloats / 4 ? i1 : i0];
-        reinterpret_cast<u32x4*>(vec)[i0] = v0;
-        if (i1 < ts::kVecFloats / 4) reinterpret_cast<u32x4*>(vec)[i1] = v1;
+        const float* gv = reinterpret_cast<const float*>(pk + (long)kPackKB * 1024 * NS) + kVecB1 * 256;
+        reinterpret_cast<float*>(lds + kXBytes)[threadIdx.x] = gv[threadIdx.x];
     }
     auto chunk = [&](const int kb) __attribute__((always_inline)) { return pk + (long)kb * 1024 * NS; };
     ts::Head<NS, 2> H;
@@ -679,16 +676,9 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
         const int64_t pt = (tile0 + h) * 32 + j;
         ov.gnet[(int64_t)net * a.n_pad + pt] = (pt < a.n) ? a.g_out[pt * 6 + net] : 0.f;
     }
-    // ---------------- Z0 -> X (k-steps 0..11) and K-layout rows: wave w builds the (column tile of Z0, point tile) units 3w .. 3w+2
-    Frag<NS> Z0f[3][2];
-    // the K-layout hand-over of a unit set {f[uu][0], f[uu][1]} (three units x NS planes) spread over a 12-k-step multiply loop
-    auto side_units = [&](const KMat& m, const Frag<NS> (&f)[3][2], const int ks) __attribute__((always_inline)) {
-#pragma unroll
-        for (int v = 0; v < 3 * NS; ++v) {
-            const int uu = v / NS, s_ = v % NS, u = 3 * w + uu;
-            if (ks == (12 / (3 * NS)) * v + 1) ts::save_plane_k(m, net, NS, s_, tile0 + (u & 1), u >> 1, lane, I, false, f[uu][0].w[s_], f[uu][1].w[s_]);
-        }
-    };
+    // ---------------- Z0 -> X (k-steps 0..11) and K-layout rows: wave w builds the (column tile of Z0, point tile) units 3w .. 3w+2.  The rows go
+    // out at once (not deferred into the multiply loop as in the forward kernel): nothing of them stays live, the kernel fits 168 registers and
+    // three workgroups share a CU -- with one short multiply loop per workgroup, other workgroups are what hides the stores
 #pragma unroll
     for (int uu = 0; uu < 3; ++uu) {
         const int u = 3 * w + uu, ct = u >> 1, p = u & 1;     // wave-uniform
@@ -696,15 +686,12 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
         const int64_t pcp = p ? pc[1] : pc[0];
         float gjc = 0.f;
         if (a.g_jxi && ((tile0 + p) * 32 + j) < a.n) gjc = a.g_jxi[(pcp * 6 + net) * 3 + (ct >> 1)];
-        Frag<NS>& f0 = Z0f[uu][0];
-        Frag<NS>& f1 = Z0f[uu][1];
+        Frag<NS> f0, f1;
         ts::z0_frag<NS>(f0, a, 2 * ct, h, pcp, gp, gjc);
         ts::z0_frag<NS>(f1, a, 2 * ct + 1, h, pcp, gp, gjc);
         ts::x_store<NS>(xl, 2 * ct, p, f0);
         ts::x_store<NS>(xl, 2 * ct + 1, p, f1);
-#if !TS_DEFER_SAVES
         ts::save_tile_k<NS, NS>(ov.Z0, net, tile0 + p, ct, lane, I, false, f0, f1);
-#endif
     }
     TS_STAMP(1);
     ts::barrier_lds();
@@ -715,14 +702,7 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) ts::acc_init(acc[t][p], vec, kVecB1, h, 2 * w + t, g[p]);
-#if TS_DEFER_SAVES
-    {
-        auto side = [&](const int ks) __attribute__((always_inline)) { side_units(ov.Z0, Z0f, ks); };
-        ts::gemm<NS, 12, 2, false, decltype(side), false>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc, side);
-    }
-#else
     ts::gemm<NS, 12, 2, false, ts::NoSide, false>(chunk(kS0 + 2 * w * 12), xl, lane, H, acc);
-#endif
     TS_STAMP(3);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -737,16 +717,16 @@ __global__ __launch_bounds__(256, 2) void dpn_bwd_tiles_kernel(BwdArgs a) {
             ts::save_tile_k<NS, NS>(ov.Z1, net, tile0 + p, 2 * w + t, lane, I, false, F0, F1);
         }
     TS_STAMP(4);
-    // ---------------- G6 = g pe6 -> K-layout rows: units as for Z0
+    if (net != 0) return;
+    // ---------------- net 0: the per-point pe6 table (OperandView) -> K-layout rows, units as for Z0
 #pragma unroll
     for (int uu = 0; uu < 3; ++uu) {
         const int u = 3 * w + uu, ct = u >> 1, p = u & 1;
-        const float gp = p ? g[1] : g[0];
         const int64_t pcp = p ? pc[1] : pc[0];
         Frag<NS> f0, f1;
-        ts::pe6_frag<NS>(f0, a, 2 * ct, h, pcp, gp);
-        ts::pe6_frag<NS>(f1, a, 2 * ct + 1, h, pcp, gp);
-        ts::save_tile_k<NS, NS>(ov.G6, net, tile0 + p, ct, lane, I, false, f0, f1);
+        ts::pe6_frag<NS>(f0, a, 2 * ct, h, pcp);
+        ts::pe6_frag<NS>(f1, a, 2 * ct + 1, h, pcp);
+        ts::save_tile_k<NS, NS>(ov.PE6, 0, tile0 + p, ct, lane, I, false, f0, f1);
     }
     TS_STAMP(5);
 }

@@ -171,74 +171,78 @@ DEV float pack_src(const PackArgs& a, const int net, int kb, int lane, int e) {
 
 // vectors in [h][T][r] order (channel 32T + drow32(r,h)); u = W2^T wo; const0 = wo.bf2 + bo
 // form 1 (dpn_layout.h): C2 = W1 cvec + bf1, A2 = w2^T wo, Bv = Wd^T wo (PE6 slot order), const0 += 2 wo.cvec
-DEV void pack_vectors(const PackArgs& a, const int net) {
+// EIGHT blocks per net (part = 0..7): block `part` owns the 32 vector entries idx = 32 part .. 32 part + 31; its 256 threads are 8 groups of 32, group og
+// sums the reduction index o over [32 og, 32 og + 32) and the eight partial sums are joined in a fixed order through LDS.  (One block per net walking
+// 256-long chains of dependent loads -- three of them in the fused form -- was the long pole of the launch: 31-40 us.)
+constexpr int kVecParts = 8;
+DEV void pack_vectors(const PackArgs& a, const int net, const int part) {
     const DpnNetPtrs& P = a.net[net];
     float* vec = reinterpret_cast<float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
-    const int idx = threadIdx.x;
+    const int tid = threadIdx.x, og = tid >> 5;
+    const int idx = 32 * part + (tid & 31);
     const int h = idx >> 7, T = (idx >> 4) & 7, r = idx & 15;
     const int ch = 32 * T + drow32(r, h);
-    __shared__ float red[256];
-    // u = W2^T wo (and, fused form, A2 = w2^T wo, Bv = Wd^T wo): 256 independent row reads per thread and vector -- all vectors in ONE loop, twelve to
-    // sixteen loads in flight at a time (the loop is latency-bound: a loop per vector would put three such chains in a row on this one block per
-    // net), partial sums joined in a fixed order
-    float up[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
     const int c6 = idx < kPe ? pe6_ch(idx >> 4, (idx >> 3) & 1, idx & 7) : 0;                // Bv: idx = PE6 slot 16 ks + 8 h + e (idx < 192)
+    __shared__ float red[3][8][32];
+    float up = 0.f, a2 = 0.f, bv = 0.f;
     if (a.form == 1) {
-#pragma unroll 4
-        for (int o = 0; o < kHidden; o += 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float w = P.wo[o + j];
-                up[j] = fmaf(w, P.W2[(o + j) * kHidden + ch], up[j]);
-                a2[j] = fmaf(w, P.w2b2[(o + j) * P.ld_w2b2 + ch], a2[j]);                   // (w2^T wo)[ch]
-                bv[j] = fmaf(w, P.Wd[(o + j) * kPe + c6], bv[j]);                           // (Wd^T wo)[pe6 channel of this slot]
-            }
+#pragma unroll 8
+        for (int o = 32 * og; o < 32 * og + 32; ++o) {
+            const float w = P.wo[o];
+            up = fmaf(w, P.W2[o * kHidden + ch], up);
+            a2 = fmaf(w, P.w2b2[o * P.ld_w2b2 + ch], a2);                                    // (w2^T wo)[ch]
+            bv = fmaf(w, P.Wd[o * kPe + c6], bv);                                            // (Wd^T wo)[pe6 channel of this slot]
         }
     } else {
-#pragma unroll 4
-        for (int o = 0; o < kHidden; o += 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) up[j] = fmaf(P.wo[o + j], P.W2[(o + j) * kHidden + ch], up[j]);
-        }
+#pragma unroll 8
+        for (int o = 32 * og; o < 32 * og + 32; ++o) up = fmaf(P.wo[o], P.W2[o * kHidden + ch], up);
     }
-    const float u = (up[0] + up[1]) + (up[2] + up[3]);
-    const float cv_nat = P.w2b2[idx * P.ld_w2b2 + kHidden] + P.bd[idx] + P.evec[idx];      // cvec[idx], natural order
-    vec[kVecB1 * 256 + idx] = P.w1b1[ch * P.ld_w1b1 + kPe];
-    vec[kVecU * 256 + idx] = u;
-    vec[kVecWo * 256 + idx] = P.wo[ch];
-    red[idx] = P.wo[idx] * (P.bf2[idx] + (a.form == 1 ? 2.0f * cv_nat : 0.f));
+    red[0][og][tid & 31] = up; red[1][og][tid & 31] = a2; red[2][og][tid & 31] = bv;
     __syncthreads();
-    if (a.form == 1) {
-        // (W1 cvec)[ch] = W1 b2 + W1 bd + W1 e: three columns of the GEMM launch's scratch (a pass over W1's rows here, one row per thread, is
-        // 256 uncoalesced loads in a row: it made this block the long pole of the launch, 31 us)
-        const float* Fr = a.fused + ((long)net * kHidden + ch) * kFusedCols;
-        vec[kVecC2 * 256 + idx] = ((Fr[kFusedColB2] + Fr[kFusedColBd]) + Fr[kFusedColE]) + P.bf1[ch];
-        vec[kVecA2 * 256 + idx] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
-        vec[kVecBv * 256 + idx] = idx < kPe ? (bv[0] + bv[1]) + (bv[2] + bv[3]) : 0.f;
-    } else {
-        vec[kVecCvec * 256 + idx] = P.w2b2[ch * P.ld_w2b2 + kHidden] + P.bd[ch] + P.evec[ch];
-        vec[kVecBf1 * 256 + idx] = P.bf1[ch];
-        vec[kVecB2BdE_unused * 256 + idx] = 0.f;
+    if (og == 0) {
+        const int c = tid;
+        auto sum8 = [&](const int q) { return ((red[q][0][c] + red[q][1][c]) + (red[q][2][c] + red[q][3][c])) + ((red[q][4][c] + red[q][5][c]) + (red[q][6][c] + red[q][7][c])); };
+        vec[kVecB1 * 256 + idx] = P.w1b1[ch * P.ld_w1b1 + kPe];
+        vec[kVecU * 256 + idx] = sum8(0);
+        vec[kVecWo * 256 + idx] = P.wo[ch];
+        if (a.form == 1) {
+            // (W1 cvec)[ch] = W1 b2 + W1 bd + W1 e: three columns of the GEMM launch's scratch (dpn_layout.h)
+            const float* Fr = a.fused + ((long)net * kHidden + ch) * kFusedCols;
+            vec[kVecC2 * 256 + idx] = ((Fr[kFusedColB2] + Fr[kFusedColBd]) + Fr[kFusedColE]) + P.bf1[ch];
+            vec[kVecA2 * 256 + idx] = sum8(1);
+            vec[kVecBv * 256 + idx] = idx < kPe ? sum8(2) : 0.f;
+        } else {
+            vec[kVecCvec * 256 + idx] = P.w2b2[ch * P.ld_w2b2 + kHidden] + P.bd[ch] + P.evec[ch];
+            vec[kVecBf1 * 256 + idx] = P.bf1[ch];
+            vec[kVecB2BdE_unused * 256 + idx] = 0.f;
+        }
     }
+    if (part != 0) return;
+    // const0 = wo . (bf2 [+ 2 cvec]) + bo: block 0 of the net, all 256 threads
+    __shared__ float red1[256];
+    const float cv_nat = P.w2b2[tid * P.ld_w2b2 + kHidden] + P.bd[tid] + P.evec[tid];        // cvec[tid], natural order
+    red1[tid] = P.wo[tid] * (P.bf2[tid] + (a.form == 1 ? 2.0f * cv_nat : 0.f));
+    __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (idx < s) red[idx] += red[idx + s];
+        if (tid < s) red1[tid] += red1[tid + s];
         __syncthreads();
     }
-    if (idx == 0) {
-        vec[kNumVecs * 256 + 0] = red[0] + P.bo[0];
+    if (tid == 0) {
+        vec[kNumVecs * 256 + 0] = red1[0] + P.bo[0];
         vec[kNumVecs * 256 + 1] = (float)a.form; vec[kNumVecs * 256 + 2] = 0.f; vec[kNumVecs * 256 + 3] = 0.f;
     }
 }
 
 #if DPN_HAS_REST
 __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
-    if (blockIdx.x == gridDim.x - 1) { pack_vectors(a, blockIdx.y); return; }      // last block column: the fp32 vectors of this net
+    const int mcols = gridDim.x - kVecParts;                                          // block columns of matrix fragments, then kVecParts of vector blocks
+    if ((int)blockIdx.x >= mcols) { pack_vectors(a, blockIdx.y, blockIdx.x - mcols); return; }
     const int net = blockIdx.y;
     const int ns = a.ns;
     uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
     const int skip = a.form == 1 ? kS5 - kS3 : 0;     // the fused form leaves [kS3, kS5) unwritten
     const int total = (kPackKB - skip) * 64;          // (kb, lane) pairs
-    for (int u = blockIdx.x * 256 + threadIdx.x; u < total; u += (gridDim.x - 1) * 256) {     // the last block column packs the vectors
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < total; u += mcols * 256) {
         int kb = u >> 6;
         const int lane = u & 63;
         if (kb >= kS3) kb += skip;
@@ -632,21 +636,28 @@ static int64_t saved_bytes(int64_t n_pad, int ns) { return saved_state_bytes(n_p
 
 struct OperandView {     // written by dpn_bwd_points
     KMat Z1;             // [6][NS] x 256   (round 5: Z is not an operand any more, dpn_finish_gside_kernel)
-    KMat Z0, G6;         // [6][NS] x 192   (G6 = gout * pe6)
-    float* gnet;         // [6][n_pad]  per-net cotangent of the normalised field, zero for padding points
+    KMat Z0;             // [6][NS] x 192
+    KMat PE6;            // [1][NS] x 192   per-POINT table of the data features (sin / cos of coord_data), written once by the net-0 workgroups
+    float* gnet;         // [6][n_pad]      per-net cotangent of the normalised field, zero for padding points
 };
+// Round 5: G6 = g pe6 (the Y operand of S2 = M2^T G6) is no longer written per point AND NET: it is a per-point table times a per-net scalar, so
+// dpn_wgrad_kernel forms it in registers from the table fragment it has just read (seven VALU instructions per element beside the MFMAs) and the table
+// -- 768 B per point in the hi+lo mode, shared by the six nets -- stays in the memory-side cache.  Stage 1 writes 2 560 -> 1 792 B per point and net.
+// (The same was built for Z0 = g pe3 + gJ_c d pe3 / d xi_c -- the partner column of one pe3 table through a DPP move -- and measured: stage 1 91 us
+// instead of 130, but product 3's tile loop no longer fits 256 registers beside its 128 accumulators and two X planes, each reload of a spilled value
+// waits for the LDS-DMA ring as well, and dpn_wgrad_kernel went 198 -> 337 us; profiles/round5_operand_tables.txt.  Z0 stays a per-net operand.)
 DEV OperandView operand_view(void* base, int64_t n_pad, int ns) {
     OperandView o;
     char* b = reinterpret_cast<char*>(base);
-    const int64_t m256 = (int64_t)kNets * ns * n_pad * 512, m192 = (int64_t)kNets * ns * n_pad * 384;
+    const int64_t m256 = (int64_t)kNets * ns * n_pad * 512, m192 = (int64_t)kNets * ns * n_pad * 384, t192 = (int64_t)ns * n_pad * 384;
     const int64_t tiles32 = n_pad / 32;
     o.Z1 = KMat{b, tiles32, 8};
     o.Z0 = KMat{b + m256, tiles32, 6};
-    o.G6 = KMat{b + m256 + m192, tiles32, 6};
-    o.gnet = reinterpret_cast<float*>(b + m256 + 2 * m192);
+    o.PE6 = KMat{b + m256 + m192, tiles32, 6};
+    o.gnet = reinterpret_cast<float*>(b + m256 + m192 + t192);
     return o;
 }
-static int64_t operand_bytes(int64_t n_pad, int ns) { return (int64_t)kNets * ns * n_pad * 512 + 2 * (int64_t)kNets * ns * n_pad * 384 + (int64_t)kNets * n_pad * 4 + 1024; }
+static int64_t operand_bytes(int64_t n_pad, int ns) { return (int64_t)kNets * ns * n_pad * 512 + (int64_t)(kNets + 1) * ns * n_pad * 384 + (int64_t)kNets * n_pad * 4 + 1024; }
 
 // ------------------------------------------------------------------------------------------------ forward + Jacobian
 struct FwdArgs {
@@ -1156,6 +1167,11 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
     };
     {
         Frag<NS> z0[12];
+        if (net == 0) {                           // the per-point table of the data features (OperandView): written once for the six nets
+            build_pe6<NS>(L, cd6, z0, 1.0f);
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) store_tile_k<NS, NS>(ov.PE6, 0, tile32, ct, L, z0[2 * ct], z0[2 * ct + 1], false);
+        }
         if (a.pe_in) load_pe3<NS>(a.pe_in + pc * kPe, h, z0, g);
         else build_pe3<NS, true>(L, z0, g, gj);
 #pragma unroll
@@ -1167,14 +1183,6 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
             else DPN_STEP(T, 12, false, z0, acc[T], epi1(T - 1));
         }
         epi1(7);
-    }
-    // ---------------- G6 = g pe6 (operand of S2 = M2^T G6).  Z = w2 Z1 + Wd G6 + g cvec is NOT formed any more (round 5): it is linear in
-    // (Z1, G6, g), so M2^T Z = S1 w2^T + S2 Wd^T + mvec (x) cvec is one exact-fp32 GEMM per net behind the reduction (dpn_finish_gside_kernel)
-    {
-        Frag<NS> g6[12];
-        build_pe6<NS>(L, cd6, g6, g);
-#pragma unroll
-        for (int ct = 0; ct < 6; ++ct) store_tile_k<NS, NS>(ov.G6, net, tile32, ct, L, g6[2 * ct], g6[2 * ct + 1], false);
         pipe.drain();
     }
 }
@@ -1235,7 +1243,9 @@ struct WgradShape {
     static constexpr int kPieces = (kX + kY) / 1024;
     static constexpr int kIssue = (kPieces + 7) / 8;                    // 1-KB pieces per wave per tile; if they do not divide (single bf16, 192 columns:
     static constexpr int kPad = kIssue * 8 - kPieces;                   // 28 pieces), the last waves re-read one fixed kilobyte into a dummy area
-    static constexpr int kSlot = kX + kY + 8 * 256 + (kPad ? 1024 : 0); // + 8 per-wave copies of g[64]
+    static constexpr int kGOff = kX + kY;                               // 8 per-wave copies of g[64]
+    static constexpr int kPadOff = kGOff + 8 * 256;
+    static constexpr int kSlot = kPadOff + (kPad ? 1024 : 0);
     static constexpr int PER_TILE = kIssue + 1;                         // DMA instructions per wave per tile
     static constexpr int RING = (160 * 1024) / kSlot < 5 ? (160 * 1024) / kSlot : 5;
 };
@@ -1267,7 +1277,8 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
     const char* xb = (PROD == 3) ? sv.T1.base : sv.M2.base;                                      // 8 column tiles
     static_assert(PROD >= 1 && PROD <= 3, "products: 1 = M2^T Z1, 2 = M2^T G6, 3 = T1^T Z0");
-    const char* yb = (PROD == 1) ? ov.Z1.base : (PROD == 2) ? ov.G6.base : ov.Z0.base;   // nct column tiles
+    const char* yb = (PROD == 1) ? ov.Z1.base : (PROD == 2) ? ov.PE6.base : ov.Z0.base;   // nct column tiles; product 2: the per-point TABLE (no net index)
+    const int64_t ynet = (PROD == 2) ? 0 : net;
     const float* gnet = ov.gnet + (int64_t)net * a.n_pad;
 
     // every wave issues PER_TILE DMA instructions per tile: piece q = wave + 8*j of the (X planes, Y planes) image, + its own g copy.
@@ -1282,19 +1293,19 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
     for (int j = 0; j < S::kIssue; ++j) {
         const int q = wave + 8 * j;
         if (S::kPad && q >= S::kPieces) {                               // a cache hit after the first time
-            pbase[j] = xb + ((int64_t)net * nsx * tiles + (t0 < tiles ? t0 : 0)) * 16384; pstride[j] = 0; pdst[j] = S::kX + S::kY + 8 * 256;
+            pbase[j] = xb + ((int64_t)net * nsx * tiles + (t0 < tiles ? t0 : 0)) * 16384; pstride[j] = 0; pdst[j] = S::kPadOff;
         } else if (q < nsx * 16) {
             pbase[j] = xb + ((int64_t)net * nsx + q / 16) * tiles * 16384 + (q % 16) * 1024; pstride[j] = 16384; pdst[j] = q * 1024;
         } else {
             const int qy = q - nsx * 16;
-            pbase[j] = yb + ((int64_t)net * NS + qy / (2 * nct)) * tiles * S::kYPlane + (qy % (2 * nct)) * 1024; pstride[j] = S::kYPlane; pdst[j] = q * 1024;
+            pbase[j] = yb + (ynet * NS + qy / (2 * nct)) * tiles * S::kYPlane + (qy % (2 * nct)) * 1024; pstride[j] = S::kYPlane; pdst[j] = q * 1024;
         }
     }
     auto issue = [&](int64_t tile, int slot) __attribute__((always_inline)) {
         char* sl = lds + slot * kSlot;
 #pragma unroll
         for (int j = 0; j < S::kIssue; ++j) dma16_nt(pbase[j] + tile * pstride[j] + lane * 16, sl + pdst[j]);
-        dma4(reinterpret_cast<const char*>(gnet + tile * 32) + lane * 4, sl + S::kX + S::kY + wave * 256);
+        dma4(reinterpret_cast<const char*>(gnet + tile * 32) + lane * 4, sl + S::kGOff + wave * 256);
     };
 
     f32x16 acc[4][2];
@@ -1311,20 +1322,27 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
     };
     auto compute = [&](const int slot_) __attribute__((always_inline)) {
         const unsigned buf = lds_base + slot_ * kSlot;
-        const unsigned gl = buf + S::kX + S::kY + wave * 256;
+        const unsigned gl = buf + S::kGOff + wave * 256;
         constexpr int KB = (NS == 1) ? 2 : 1;                       // single-bf16 fragments: both k-steps of the tile are read up front
         u32x4 gqa[KB][2], faa[KB][nsx][4], fba[KB][NS][2];
+        // one base register per stream, the fragment index as the instruction's immediate offset (a full address per read costs a VGPR each for its
+        // slot-independent part -- ~30 of them, hoisted out of the tile loop -- and spilled once the in-register operand forming of products 2 / 3 came in)
+        const unsigned baseG = gl + h * 16;
+        const unsigned baseA = buf + wm * 4096 + lane * 16, baseB = buf + S::kX + wn * 2048 + lane * 16;
+        auto rd128o = [&](u32x4& v, const unsigned base, const int off) __attribute__((always_inline)) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "i"(off) : "memory");
+        };
         auto issue_reads = [&](const int kk, const int b) __attribute__((always_inline)) {
-            rd128(gqa[b][0], gl + (16 * kk + 4 * h) * 4);
-            rd128(gqa[b][1], gl + (16 * kk + 4 * h + 8) * 4);
+            rd128o(gqa[b][0], baseG, 64 * kk);
+            rd128o(gqa[b][1], baseG, 64 * kk + 32);
 #pragma unroll
             for (int s2 = 0; s2 < nsx; ++s2)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) rd128(faa[b][s2][m], buf + s2 * 16384 + ((kk * 8 + wm * 4 + m) * 64 + lane) * 16);
+                for (int m = 0; m < 4; ++m) rd128o(faa[b][s2][m], baseA, s2 * 16384 + (kk * 8 + m) * 1024);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) rd128(fba[b][s2][n2], buf + S::kX + s2 * S::kYPlane + ((kk * nct + wn * 2 + n2) * 64 + lane) * 16);
+                for (int n2 = 0; n2 < 2; ++n2) rd128o(fba[b][s2][n2], baseB, s2 * S::kYPlane + (kk * nct + n2) * 1024);
         };
         constexpr int kReads = 2 + 4 * nsx + 2 * NS;                // LDS reads per k-step
         if constexpr (NS == 1) { issue_reads(0, 0); issue_reads(1, 1); }
@@ -1345,6 +1363,21 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
             if constexpr (nsx == 2) asm volatile("" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]));
             const float gp[8] = {__uint_as_float(gq0[0]), __uint_as_float(gq0[1]), __uint_as_float(gq0[2]), __uint_as_float(gq0[3]),
                                  __uint_as_float(gq1[0]), __uint_as_float(gq1[1]), __uint_as_float(gq1[2]), __uint_as_float(gq1[3])};
+            if constexpr (PROD == 2) {
+                // the Y fragments just read are the per-point TABLE pe6 (hi [+ lo]); this net's operand G6 = g pe6 is formed here: element e of a register
+                // pair <-> point e of the lane's eight (gp[e])
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        float v0 = bf_lo(fb[0][n2][p]), v1 = bf_hi(fb[0][n2][p]);
+                        if constexpr (NS == 2) { v0 += bf_lo(fb[1][n2][p]); v1 += bf_hi(fb[1][n2][p]); }
+                        const float z0 = gp[2 * p] * v0, z1 = gp[2 * p + 1] * v1;
+                        const u32 hi = pack2(z0, z1);
+                        fb[0][n2][p] = hi;
+                        if constexpr (NS == 2) fb[1][n2][p] = pack2(z0 - bf_lo(hi), z1 - bf_hi(hi));
+                    }
+            }
             if (PROD == 1 && wave == 0 && i == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gsum += gp[e];
@@ -2311,14 +2344,15 @@ static inline bool use_tiles(const char* knob, int prec, bool has_pe_in) {
 // profiles/round3_wgrad_plans.txt): 10,11,10,11 327 us, 11,11,9,11 303 us, 10,10,9,13 277 us, 10,10,8,14 277 us, 9,9,8,16 280 us --
 // a plateau at 5.0 TB/s.  Single bf16 (rings of four and five): 10,11,10,11 156 us, 10,10,9,13 160-163 us.
 struct SplitPlan { int s[4]; int most; };
-// Round 5: three products (s[0] = 0: M2^T Z is gone, dpn_finish_gside_kernel).  The 42 ranges per net go to them in the proportions the
-// four-product plans had found (single bf16 10,11,10,11 -> 14,13,15) or a sweep did (hi+lo, tools/wgrad_overlap_probe.py, profiles/round5_wgrad_plans.txt:
-// 13,12,17 250 us, 12,12,18 226, 14,12,16 214, 13,11,18 215, 14,11,17 214, 12,11,19 219, 15,12,15 219, 13,13,16 215).
+// Round 5: three products (s[0] = 0: M2^T Z is gone, dpn_finish_gside_kernel); product 2 forms its Y operand G6 = g pe6 in registers from the
+// per-point table (OperandView), which makes ITS tiles the slowest: it gets the most ranges per byte.  Sweeps of the 42 ranges per net
+// (tools/wgrad_overlap_probe.py, profiles/round5_wgrad_plans.txt; eager launches back to back): hi+lo 14,12,16 277 us, 15,12,15 244, 14,13,15 234,
+// 13,13,16 228, 15,13,14 233, 13,14,15 224; single bf16 14,13,15 163 us, 15,13,14 136, 14,12,16 137, 13,13,16 129, 15,12,15 133, 16,13,13 132.
 static inline SplitPlan choose_plan(int64_t n_pad, int ns) {
     int64_t c = n_pad / 32 / 16;
     if (c < 1) c = 1;
     SplitPlan p;
-    if (c >= 10) p = (ns == 2) ? SplitPlan{{0, 14, 12, 16}, 16} : SplitPlan{{0, 14, 13, 15}, 15};
+    if (c >= 10) p = (ns == 2) ? SplitPlan{{0, 13, 14, 15}, 15} : SplitPlan{{0, 13, 13, 16}, 16};
     else p = SplitPlan{{0, (int)c, (int)c, (int)c}, (int)c};
 #ifdef DPN_EXPERIMENT_SPLITS                     // timing experiments only: DPN_WGRAD_PLAN="9,12,10,11"
     if (const char* e = getenv("DPN_WGRAD_PLAN")) {
@@ -2387,8 +2421,8 @@ int dpn_pack_weights_form(const DpnNetPtrs nets[DPN_NETS], int prec, int form, v
         const int rc = sgemm_batch_launch(4 * kNets, q, 0, nullptr, stream);
         if (rc) return rc;
     }
-    const int cols = form == 1 ? 28 : 40;                                // block columns of matrix fragments (+ 1 for the vectors): 544 / 800 KB per net
-    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(cols + 1, kNets), dim3(256), 0, s, a);
+    const int cols = form == 1 ? 28 : 40;                                // block columns of matrix fragments (+ kVecParts for the vectors): 544 / 800 KB per net
+    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(cols + kVecParts, kNets), dim3(256), 0, s, a);
     return ck(hipGetLastError());
 }
 

@@ -160,7 +160,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         fp8 = fp8_mode in ('1', 'mx')
 
         def gemm8(M, N, K, A, W, bias, C, epi=0, aux_out=None):
-            fn = lib.dpn_gemm_fp8_mx if fp8_mode == 'mx' else lib.dpn_gemm_fp8
+            fn = lib.dpn_gemm_fp8_mx if fp8_mode == 'mx' else L.load_experiments().dpn_gemm_fp8     # (the non-scaled form: shelved, experiment library)
             L.check(fn(M, N, K, _p(A), K, _p(W), K, _p(bias), _p(C), N, epi, _p(aux_out), _s()), 'dpn_gemm_fp8')
         q, k, v = new(n, D), new(n, D), new(n, D)
         if fp8:
@@ -288,7 +288,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
             xs, xe, ws, we, Kp, _ = c16
             n_parts = 16
             emb_parts = torch.empty((n_parts, B * T, D), dtype=torch.float32, device=dev)
-            L.check(lib.dpn_conv16(_p(xs), _p(xe), _p(ws), _p(we), B * T, D, Kp, n_parts, _p(emb_parts), _s()), 'dpn_conv16')
+            L.check(L.load_experiments().dpn_conv16(_p(xs), _p(xe), _p(ws), _p(we), B * T, D, Kp, n_parts, _p(emb_parts), _s()), 'dpn_conv16')
         elif not config.FROZEN.embed_gemm16:
             # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one exact-fp32 MFMA launch (24 us)
             parts = 16
@@ -315,7 +315,7 @@ class _DataEmbeddingFn(torch.autograd.Function):
             emb_parts = torch.empty((n_parts, B * T, D), dtype=torch.float32, device=dev)
             q.A, q.B, q.C, q.M, q.N, q.K, q.ldc = _p(xu), _p(w2), _p(emb_parts), B * T, D, K3, D
             q.a_sm, q.a_sk, q.b_sn, q.b_sk = K3, 1, K3, 1
-            L.check(lib.dpn_gemm16(1, ctypes.byref(q), n_parts, _p(emb_parts), 0, _s()), 'dpn_gemm16')
+            L.check(L.load_experiments().dpn_gemm16(1, ctypes.byref(q), n_parts, _p(emb_parts), 0, _s()), 'dpn_gemm16')
         if te is None:
             te = lead_time_pe(h, freq_bands)
         n_tok = token.shape[-2]
@@ -340,6 +340,11 @@ class _DataEmbeddingFn(torch.autograd.Function):
         g3 = g.reshape(B, -1, D)
         g_emb = _c(g3[:, ctx.n_tok:]).reshape(n, D)              # one field: a contiguous row range (no copy)
         done = getattr(ctx.share, 'embed', None) if ctx.share is not None else None
+        # The stack node's weight-gradient launch has computed dW, db (and the learnable tokens' gradient) from ITS d x0 -- valid only when that is
+        # the cotangent arriving here, i.e. x0 had exactly one consumer and no hook rewrote its gradient: otherwise (a second use of
+        # `last_embedding`, a tensor hook) the incoming g differs and the gradients are computed from it below.
+        if done is not None and done.get('grads') is not None and done.get('dx0_ptr') != g.data_ptr():
+            done['grads'] = done['g_tok'] = None
         if done is not None and done.get('grads') is not None:       # computed by the stack node's weight-gradient launch
             dw, db = done['grads']
             done['grads'] = None
@@ -361,10 +366,17 @@ class _DataEmbeddingFn(torch.autograd.Function):
         return None, dw.view(ctx.w_shape), db, g_tok, None, None, None, None, None, None
 
 
+def _params_ok(params, device):
+    """Every parameter the fused kernels read through a raw pointer: fp32, on `device`, contiguous (a .half() / .double() model, or one on another
+    GPU, would be read as fp32 words of the wrong size -- silently wrong, or out of bounds): otherwise the per-op path handles or rejects it."""
+    return all(p is not None and p.is_cuda and p.device == device and p.dtype == torch.float32 and p.is_contiguous() for p in params)
+
+
 def _embedding_fits(field, emb_module, token, h):
     conv = emb_module.value_embedding.tokenConv
     return (field.is_cuda and field.dim() == 3 and conv.weight.shape[0] == 256 and conv.kernel_size == (3,)
-            and conv.bias is not None and token.shape[-1] == 256 and h.numel() == field.shape[0])
+            and conv.bias is not None and token.shape[-1] == 256 and h.numel() == field.shape[0]
+            and _params_ok((conv.weight, conv.bias, token, emb_module.position_embedding.pe), field.device))
 
 
 def data_embedding_fused(field, emb_module, token, h, prep=None):
@@ -809,6 +821,7 @@ class _EncoderStackFn(torch.autograd.Function):
             batch.append((g_emb, emb['xu'], dwt, dbt))
             keep.append(g_emb)
             emb['grads'] = (dwt, dbt)
+            emb['dx0_ptr'] = dx0.data_ptr()
         # every weight gradient of the stack and the LayerNorm parameter sums: ONE launch (dpn_wgrad16; plus its slice reduction for batches
         # of fields)
         flush(False)
@@ -842,7 +855,7 @@ def _layer_fits(layer):
                                                  layer.conv1, layer.conv2)))
 
 
-def _stack_fits(layers, norm, projection):
+def _stack_fits(layers, norm, projection, device=None):
     if config.FROZEN.encoder_fp8 or config.FROZEN.encoder_unfused or len(layers) < 1:
         return False
     if not all(_layer_fits(l_) and not getattr(l_.attention.inner_attention, 'output_attention', False) for l_ in layers):
@@ -852,6 +865,10 @@ def _stack_fits(layers, norm, projection):
     final = norm is not None
     if final and not (norm.elementwise_affine and norm.eps == 1e-5 and tuple(projection.weight.shape) == (256, 256) and projection.bias is not None):
         return False
+    if device is not None:
+        every = [p for l_ in layers for p in l_.parameters()] + ([norm.weight, norm.bias, projection.weight, projection.bias] if final else [])
+        if not _params_ok(every, device):
+            return False
     return 6 * len(layers) + (1 if final else 0) <= L.ENC_MAX_MATS
 
 
@@ -894,6 +911,7 @@ def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
     if config.FROZEN.conv16 and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and tuple(conv.weight.shape[1:]) == (C, 3):
         # EXPERIMENT: the token convolution's operands split into f16 hi / lo fragment images with one power-of-two scale per row (dpn_conv16).
         # Measured: the GEMM 23.7 -> 11.2 us, the split 12-16 us -- no gain; not the product path.
+        lib = L.load_experiments()
         Kp, n_out = int(lib.dpn_conv16_kp(3 * C)), conv.weight.shape[0]
         if (B * T + 16) * Kp * 4 < 2 ** 31 - 8192 and Kp <= 29 * 256:
             xs = torch.empty(((B * T + 15) // 16 * 16, 2 * Kp), dtype=torch.float16, device=dev)      # fragment images: 16-row strips x (Kp / 32) blocks x 2 KB
@@ -915,7 +933,7 @@ def encoder_forward_fused(net, x_enc, forecast_h):
         return None
     layers = list(enc.attn_layers)
     n_tok = net.learnable_token.shape[-2]
-    if not (_stack_fits(layers, enc.norm, net.projection) and _embedding_fits(x_enc, emb, net.learnable_token, forecast_h)
+    if not (_stack_fits(layers, enc.norm, net.projection, x_enc.device) and _embedding_fits(x_enc, emb, net.learnable_token, forecast_h)
             and n_tok + x_enc.shape[1] <= 288):
         return None
     prep = encoder_prep(x_enc, forecast_h, emb, getattr(net, 'extra_lead_freqs', None), layers, enc.norm, net.projection)
@@ -948,6 +966,8 @@ def encoder_stack_fused(x, layers, norm=None, projection=None, wpack=None, share
         if not (norm.elementwise_affine and norm.eps == 1e-5 and tuple(projection.weight.shape) == (256, 256) and projection.bias is not None):
             return None
         params += [norm.weight, norm.bias, projection.weight, projection.bias]
+    if not _params_ok([p.detach() for p in params], x.device):
+        return None
     B, Lt = x.shape[0], x.shape[1]
     out = _EncoderStackFn.apply(x.reshape(B * Lt, 256), B, Lt, len(layers), final, wpack, share, *params)
     return out.view(B, Lt, 256)

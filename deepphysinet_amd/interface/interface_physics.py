@@ -455,12 +455,17 @@ class InterfacePhysics(nn.Module):
                 if rank == 0 and global_step % log_step == 1:
                     print('epoch %d step %d loss %.6g %s' % (epoch, global_step, float(loss),
                                                               ' '.join('%s %.4g' % (k, float(v)) for k, v in parts.items())))
+                if global_step % log_step == 1:                       # (the loop synchronises here anyway: float(loss))
+                    from ..encoder_ops import check_enc_status
+                    check_enc_status()                                # an encoder weight outside the f16 hi+lo split's range raises HERE, named
                 if max_steps is not None and global_step >= max_steps:
                     break
             if epoch % save_step == 0:
                 if lr_schedule is not None:
                     lr_schedule.step()
                     optimizer.sync_hyper()
+                from ..encoder_ops import check_enc_status
+                check_enc_status()
                 if checkpoint_path and rank == 0:
                     self.save_model(checkpoint_path, epoch, global_step, prefix='physics', dx=self.dx, dy=self.dy, dt=self.dt,
                                     pred_x_span=self.dx * self.lon_size, pred_y_span=self.dy * self.lat_size, pred_t_span=self.pred_t_span,

@@ -244,19 +244,6 @@ typedef struct DpnEncPrep {
 } DpnEncPrep;
 int dpn_enc_prep(const DpnEncPrep* p, void* stream);
 
-/* EXPERIMENT (DPN_CONV16=1): the token convolution (model/embed.py:45-47) on f16 hi+lo MFMA with operands split once per step.
- * dpn_conv16_split: each im2col row (of x [batch*T][C], circular, as dpn_im2col_circ3) and each weight row [conv_n][3C] scaled by a power of two
- * (row maximum into [8, 16): biased exponents in xe / we) and written as f16 hi and lo MFMA-fragment images: per (16-row strip, 32-k block)
- * 2 KB = [hi | lo][lane = (k % 32) / 8 * 16 + row % 16][8 f16]; xs holds ceil(batch*T / 16) strips, ws ceil(conv_n / 16), each of Kp / 32 blocks,
- * Kp = dpn_conv16_kp(3C) (zero-filled behind 3C). */
-int dpn_conv16_split(const float* x, int T, int C, int batch, const float* conv_w, int conv_n, void* xs, int32_t* xe, void* ws, int32_t* we, void* stream);
-/* dpn_conv16, the GEMM on those images: parts[s][m][n] = sum over the s-th K-slice of x(m, k) w(n, k), fp32,
- * scales undone (M = batch*T rows, N = conv_n, `slices` K-slices of whole 32-k blocks, at most 16 blocks each; dpn_embed_assemble adds the
- * slices in order).  f16 hi+lo,
- * three products, fp32 accumulate (fp32-class); a row's scale depends on that row only, so a field's result does not depend on its batch. */
-int64_t dpn_conv16_kp(int K);
-int dpn_conv16(const void* xs, const int32_t* xe, const void* ws, const int32_t* we, int M, int N, int Kp, int slices, float* parts, void* stream);
-
 /* Forward.  tail = 1:  x1 = norm1(x + o Wo^T + bo);  pre = x1 Wc1^T + bc1;  act = gelu(pre);  x2 = norm2(x1 + act Wc2^T + bc2)
  *                      (o = the attention output, x = the layer input; x1, xhat1, rstd1, pre, act, x2, xhat2, rstd2 are written);
  *           next = 1:  y0, y1, y2 = t Wn0^T + bn0, ...   the NEXT layer's q / k / v projections of t = x2 (tail = 1) or t = xin (tail = 0);
@@ -306,19 +293,6 @@ typedef struct DpnWgradProblem { const float* G; const float* X; float* dW; floa
 int64_t dpn_wgrad16_partial_floats(int n, const DpnWgradProblem* problems, int slices);
 int dpn_wgrad16(int n, const DpnWgradProblem* problems /* host array */, int n_jobs, const DpnColsumJob* jobs, int slices, float* partials,
                 void* stream);
-
-/* The same kernel for any small GEMM, one launch for up to DPN_WGRAD_MAX_PROBLEMS of them:  C[m][n] = sum_k A(m, k) B(n, k) (+ bias[n]),
- * A(m, k) = A[m * a_sm + k * a_sk], B(n, k) = B[n * b_sn + k * b_sk] (element strides: "k runs over rows" is a_sm = 1, a_sk = ld; "k is
- * contiguous" is a_sm = ld, a_sk = 1); asum[m] = sum_k A(m, k) (optional).  slices > 1 cuts K; with reduce = 0 the caller adds the partial
- * results partials[problem][slice][M * N (+ M)] itself (the data embedding's assemble kernel does).  Used for the token convolution
- * (embed.py:45-47: x_unfolded W^T with K = 3 * 2405) instead of the exact-fp32 dpn_sgemm_batch. */
-typedef struct DpnGemm16Problem {
-    const float* A; const float* B; float* C; float* asum; const float* bias;
-    int32_t M, N, K, ldc;
-    int64_t a_sm, a_sk, b_sn, b_sk;
-} DpnGemm16Problem;
-int64_t dpn_gemm16_partial_floats(int n, const DpnGemm16Problem* problems, int slices);
-int dpn_gemm16(int n, const DpnGemm16Problem* problems /* host array */, int slices, float* partials, int reduce, void* stream);
 
 /* out = LayerNorm_256(x + r) * gamma + beta (eps 1e-5), r may be NULL (transformer_net.py:37,44,68); saves xhat [rows][256] and rstd [rows].
  * Backward: gx = d/d(x + r) (the same tensor is the gradient of x and of r), dgamma, dbeta [256].  With dgamma = dbeta = NULL only gx and the
@@ -409,15 +383,11 @@ int dpn_clip_adam_flat_dev(int n_tensors, float* const* params, const float* con
                            float* exp_avg_sq_flat, double* scratch_dev, int* step_dev, const float* hyper_dev, float* out_norm_dev,
                            void* stream);
 
-/* BASELINE configs[4] experiment (OFF in the product; DPN_ENCODER_FP8=1 routes the encoder layers' forward GEMMs here): C[M][N] =
- * epilogue(A[M][K] . W[N][K]^T + bias[N]) on the fp8 matrix cores (OCP e4m3 operands quantised in the kernel with one scale per row of A
- * and per row of W, fp32 accumulate); K a multiple of 16, lda / ldw multiples of 4; epi = DPN_EPI_NONE or DPN_EPI_GELU (aux_out
- * receives the pre-activation).  Replaces nothing of the reference by default: its measured parity error is why. */
-int dpn_gemm_fp8(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int epi,
-                 float* aux_out, void* stream);
-/* The same GEMM on the block-scaled (MX) fp8 instruction v_mfma_scale_f32_32x32x64_f8f6f4: one E8M0 power-of-two scale per 32 consecutive k of
- * a row (OCP MX), applied by the hardware; K % 64 == 0.  DPN_ENCODER_FP8=mx routes the encoder's forward GEMMs here (measurement:
- * profiles/round3_fp8_mx_encoder.json). */
+/* BASELINE configs[4] (OFF by default; `bench.py --encoder-fp8` / DPN_ENCODER_FP8=mx routes the encoder layers' forward GEMMs here): C[M][N] =
+ * epilogue(A[M][K] . W[N][K]^T + bias[N]) on the block-scaled (MX) fp8 instruction v_mfma_scale_f32_32x32x64_f8f6f4: OCP e4m3 operands quantised in
+ * the kernel, one E8M0 power-of-two scale per 32 consecutive k of a row (OCP MX) applied by the hardware, fp32 accumulate; K % 64 == 0; epi =
+ * DPN_EPI_NONE or DPN_EPI_GELU (aux_out receives the pre-activation).  Replaces nothing of the reference by default: its measured parity error is why
+ * (profiles/round3_fp8_mx_encoder.json).  (The non-scaled fp8 form with per-row scales is a shelved experiment: dpn_hip_experiments.h.) */
 int dpn_gemm_fp8_mx(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int epi,
                  float* aux_out, void* stream);
 

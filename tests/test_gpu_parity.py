@@ -1017,12 +1017,15 @@ def test_variable_net_standalone_forward_matches_oracle():
 
 
 def test_fp8_gemm_experiment_kernel_matches_its_definition():
-    """configs[4] experiment kernel (csrc/dpn_fp8.hip, off in the product): C = s_a s_w q(A / s_a) q(W / s_w)^T + bias with one scale per
-    row and OCP e4m3 operands -- against the same definition written with torch's float8_e4m3fn casts; and its distance from the exact
-    product, which is why the product does not use it (a few percent)."""
+    """A SHELVED experiment kernel (csrc/dpn_fp8.hip, compiled only into the experiment library, include/dpn_hip_experiments.h): the non-scaled
+    fp8 GEMM, C = s_a s_w q(A / s_a) q(W / s_w)^T + bias with one scale per row and OCP e4m3 operands -- against the same definition written
+    with torch's float8_e4m3fn casts; and its distance from the exact product (a few percent).  The product library does not export it."""
     import ctypes
     from deepphysinet_amd import _lib as L
-    lib = L.load()
+    assert not hasattr(L.load(), 'dpn_gemm_fp8')
+    from deepphysinet_amd.build import build_experiments
+    build_experiments()
+    lib = L.load_experiments()
     dev = _dev()
     torch.manual_seed(0)
     for M, N, K, epi in ((287, 256, 256, 0), (1000, 256, 256, 1), (64, 96, 32, 0)):
@@ -1102,7 +1105,7 @@ def test_config4_fp8_encoder_workload():
     got = {}
     from deepphysinet_amd import config
     for fp8 in ('0', '1'):
-        with config.override(encoder_fp8='1' if fp8 == '1' else ''), torch.no_grad():
+        with config.override(encoder_fp8='mx' if fp8 == '1' else ''), torch.no_grad():      # configs[4] = the block-scaled (MX) fp8 form
             got[fp8] = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).double().cpu().numpy()
     err_prod = np.abs(got['0'] - ref['parts']) / np.abs(ref['parts'])
     err_fp8 = np.abs(got['1'] - ref['parts']) / np.abs(ref['parts'])
@@ -1195,3 +1198,65 @@ def test_tile_split_kernels_against_the_ring_kernels(n, prec):
         assert off <= n // 4
 
 
+
+
+def test_encoder_guards_of_the_fused_path():
+    """(1) a weight outside the f16 hi+lo split's range (|w| >= 32768) raises at the next check_enc_status() -- which the training loop
+    and bench.py call where they synchronise anyway -- instead of surfacing later as inf / NaN; (2) a model whose parameters are not fp32 on the
+    input's device never reaches the fused kernels (they read raw pointers as fp32): the fit checks send it to the per-op path, which rejects it;
+    (3) a second consumer of the data embedding's output (the cut of the staged backward) gets correct gradients: the weight gradients the stack
+    node computed from ITS d x0 are used only when that is the cotangent that arrives."""
+    from deepphysinet_amd import encoder_ops as EO
+    dev = _dev()
+    m = _model('bf16x2')
+    g = _gpu(synthetic_inputs(64, GEO.lon, GEO.lat, GEO.dx, GEO.dy))
+    net = m.physics_net
+    # (1)
+    EO.check_enc_status()
+    w = net.meta_net.model.encoder.attn_layers[0].conv1.weight
+    keep = w.detach().clone()
+    with torch.no_grad():
+        w[3, 5, 0] = 1.0e5
+    with torch.no_grad():
+        net.encode_field(g['field_data'], g['forecast_h'])
+    with pytest.raises(RuntimeError, match='32768'):
+        EO.check_enc_status()
+    with torch.no_grad():
+        w.copy_(keep)
+        EO.enc_status(dev).zero_()
+    EO.check_enc_status()
+    # (2)
+    tn = net.meta_net.model
+    layers = list(tn.encoder.attn_layers)
+    assert EO._stack_fits(layers, tn.encoder.norm, tn.projection, dev)
+    p = layers[1].conv2.bias
+    old = p.data
+    p.data = old.double()
+    try:
+        assert not EO._stack_fits(layers, tn.encoder.norm, tn.projection, dev)
+        assert EO.encoder_forward_fused(tn, g['field_data'], g['forecast_h']) is None
+    finally:
+        p.data = old
+    # (3) loss = sum(meta_out * c) + sum(x0 * d): x0 has two consumers, so the embedding node receives d x0 (stack) + d
+    net.zero_grad(set_to_none=True)
+    torch.manual_seed(5)
+    meta = net.encode_field(g['field_data'], g['forecast_h'], keep_embedding=True)
+    x0 = tn.last_embedding
+    object.__setattr__(tn, 'last_embedding', None)
+    c, d = torch.randn_like(meta), torch.randn_like(x0)
+    ((meta * c).sum() + (x0 * d).sum()).backward()
+    got = {k: v.grad.detach().clone() for k, v in (('w', tn.enc_embedding.value_embedding.tokenConv.weight), ('b', tn.enc_embedding.value_embedding.tokenConv.bias),
+                                                      ('tok', tn.learnable_token))}
+    # the same by linearity: two backward passes with a single consumer each
+    want = {}
+    for only_meta in (True, False):
+        net.zero_grad(set_to_none=True)
+        meta = net.encode_field(g['field_data'], g['forecast_h'], keep_embedding=True)
+        x0 = tn.last_embedding
+        object.__setattr__(tn, 'last_embedding', None)
+        ((meta * c).sum() if only_meta else (x0 * d).sum()).backward()
+        for k, v in (('w', tn.enc_embedding.value_embedding.tokenConv.weight), ('b', tn.enc_embedding.value_embedding.tokenConv.bias), ('tok', tn.learnable_token)):
+            want[k] = want.get(k, 0) + (v.grad.detach().clone() if v.grad is not None else 0)
+    for k in got:
+        err = float((got[k] - want[k]).abs().max() / want[k].abs().max())
+        assert err < 2e-5, (k, err)

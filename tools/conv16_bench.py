@@ -17,7 +17,7 @@ b = synth_batch(1024, dev, seed=1)
 field = b['field_data'].repeat(B, 1, 1) * (1.0 + 0.1 * torch.arange(B, device=dev).view(B, 1, 1))
 h = b['forecast_h'].repeat(B, 1, 1)
 layers = list(net.encoder.attn_layers)
-lib = L.load()
+lib = L.load_experiments()
 with torch.no_grad():
     __import__('deepphysinet_amd.config').config.set_switches(conv16=True)
     prep = E.encoder_prep(field, h, net.enc_embedding, None, layers, net.encoder.norm, net.projection)
