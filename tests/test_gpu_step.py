@@ -309,6 +309,27 @@ def test_bench_two_ranks_with_a_lead_batch_run_the_staged_captured_step():
     assert out['value'] > 0 and np.isfinite(out['ms_per_step']) and out['parameters_finite'] is True
 
 
+def test_bench_eight_ranks_on_one_device_run_the_scaling_benchmarks_code_path():
+    """the driver's 8-GPU run must not be the first time `bench.py --gpus 8` executes.  Eight processes on the one GPU of the test
+    box (DPN_BENCH_ONE_DEVICE=1, gloo through the host -- RCCL refuses several ranks on one device), a tiny workload: every rank builds the same bucket
+    layout (the fingerprint all-gather would raise), runs the same number of steps and all-reduces, the per-rank record covers all eight, and the
+    launcher exits cleanly."""
+    env = dict(os.environ, DPN_BENCH_ONE_DEVICE='1', DPN_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--points', '512', '--blocks', '2',
+                        '--no-prewarm', '--no-cpu-baseline', '--no-alt', '--no-power', '--no-lead-probe'], env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['n_gpus'] == 8 and out['config']['parallelism'] == 'dp8' and out['config']['step_segments'] == 4 and out['config']['hip_graph'] is True
+    coll = out['collective']
+    assert coll['world'] == 8 and len(coll['devices']) == 8 and sorted(d['rank'] for d in coll['devices']) == list(range(8))
+    assert len({d['pid'] for d in coll['devices']}) == 8                       # eight processes
+    pr = coll['per_rank']
+    assert len(pr['ms_per_step']) == 8 and pr['min'] <= pr['max'] and 0 <= pr['slowest_rank'] < 8
+    assert out['value'] > 0 and np.isfinite(out['ms_per_step']) and out['timed_blocks'] == 2
+
+
 def test_bench_step_with_rccl_collectives_on_one_rank():
     """The N > 1 step shape (three segment graphs, an in-place bucket all-reduce behind each, the optimiser graph) with the REAL backend
     ('nccl' = RCCL) in a one-rank group: the collective calls, ReduceOp.AVG, and their interplay with hipGraph capture / replay and the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Phase timeline of dpn_bwd_tiles_kernel (experiment build: python tools/variant_build.py tl -DDPN_TIMELINE -DTS_TIMELINE [ablation flags
--DTS_ABL_NOSTORE | -DTS_ABL_NOMFMA | -DTS_ABL_NOALOAD]).  Every wave stamps the shader clock at 15 phase boundaries; this runs the bench
+-DTS_ABL_NOSTORE | -DTS_ABL_NOMFMA | -DTS_ABL_NOALOAD]).  Every wave stamps the shader clock at 5 phase boundaries (round 5: one GEMM is left in this kernel); this runs the bench
 workload's forward + stage-1 backward and prints the mean cycles of every phase over all waves, plus the kernel's time from HIP events.
 usage: bwd_tiles_timeline.py [n] [variant name, default tl]"""
 import ctypes, os, sys
@@ -22,9 +22,7 @@ cfg = m.point_config()
 lib = L.load()
 lib.dpn_debug_set_timeline.argtypes = [ctypes.c_void_p]
 b = synth_batch(n, dev, seed=1)
-NAMES = ['prologue: vectors, cotangents, Z0 features -> X', 'barrier', 'GEMM Z1 = w1 Z0 (+ Z0 hand-over)', 'Z1 epilogue (mask, pack)', 'barrier', 'X store',
-         'barrier', 'GEMM Z += w2 Z1 (+ Z1 hand-over)', 'pe6 features (G6)', 'barrier', 'X store', 'barrier', 'GEMM Z += Wd G6 (+ G6 hand-over)',
-         'Z epilogue (split, pack, stores)']
+NAMES = ['prologue: b1, cotangents, Z0 features -> X and K-layout rows', 'barrier', 'GEMM Z1 = w1 Z0', 'Z1 epilogue (mask, pack, K-layout rows)']
 with torch.no_grad():
     heads, evec, statics = m.physics_net.field_weights(b['field_data'], b['forecast_h'])
     x_, y_, t_ = (PP._f32c(b[k]).reshape(-1) for k in ('x', 'y', 't'))
@@ -58,9 +56,9 @@ with torch.no_grad():
     torch.cuda.synchronize()
     us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev)
     t = tl.cpu().numpy().astype('int64') & 0xFFFFFFFF
-    t = t[:, :, :, :15]
-    d = ((t[..., 1:] - t[..., :-1]) & 0xFFFFFFFF).reshape(-1, 14)
-    total = ((t[..., 14] - t[..., 0]) & 0xFFFFFFFF).reshape(-1)
+    t = t[1:, :, :, :5]                                      # nets 1..5 (the net-0 workgroups also write the pe6 table)
+    d = ((t[..., 1:] - t[..., :-1]) & 0xFFFFFFFF).reshape(-1, 4)
+    total = ((t[..., 4] - t[..., 0]) & 0xFFFFFFFF).reshape(-1)
     print('dpn_bwd_tiles_kernel<2>, %d points, library %s: kernel median %.1f us (min %.1f); %d waves sampled, wave lifetime mean %.0f / median %.0f cycles'
           % (n, os.path.basename(os.environ['DPN_LIB']), us[len(us) // 2], us[0], d.shape[0], total.mean(), np.median(total)))
     groups = {'multiply loops (with the saved-operand hand-over inside)': 0.0, 'features / epilogues / stores': 0.0, 'barrier waits': 0.0}
@@ -72,5 +70,4 @@ with torch.no_grad():
         print('  %2d %-52s mean %8.0f  median %8.0f  (%4.1f %%)' % (i, nm, mean, med, 100.0 * mean / total.mean()))
     for gname, v in groups.items():
         print('  %-58s %8.0f cycles  %4.1f %%' % (gname, v, 100.0 * v / total.mean()))
-    n_mfma = (12 + 16 + 12) * 12 + 12 * 2 * 2 + 0
-    print('  MFMA issue alone (multiply loops): %d instructions x 32 cycles = %d cycles per wave (+ 2 transposing MFMAs per saved plane)' % ((12 + 16 + 12) * 12, (12 + 16 + 12) * 12 * 32))
+    print('  MFMA issue alone (multiply loop): %d instructions x 32 cycles = %d cycles per wave (+ 2 transposing MFMAs per saved plane)' % (12 * 12, 12 * 12 * 32))

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Phase timeline of dpn_fwd_tiles_kernel (experiment build: python tools/variant_build.py tl -DDPN_TIMELINE -DTS_TIMELINE).
 
-Every wave stamps the shader clock at 29 phase boundaries; this prints, per phase, the mean / median cycles over all waves of the launch,
-split into multiply phases (the seven GEMM loops), epilogue / feature phases and barrier waits.  usage: tiles_timeline.py [n] [variant name, default tl]
+Every wave stamps the shader clock at 21 phase boundaries; this prints, per phase, the mean / median cycles over all waves of the launch,
+split into multiply phases (the five GEMM loops of the fused form), epilogue / feature phases and barrier waits.  usage: tiles_timeline.py [n] [variant name, default tl]
 """
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,10 +23,10 @@ cfg = m.point_config()
 lib = L.load()
 lib.dpn_debug_set_timeline.argtypes = [ctypes.c_void_p]
 b = synth_batch(n, dev, seed=1)
-NAMES = ['prologue: vectors, pe3 features', 'barrier', 'L1 multiply', 'L1 epilogue (relu, mask, pack)', 'barrier A', 'store + barrier B',
-         'L2 multiply (w2.h1)', 'pe6 features', 'barrier A', 'store + barrier B', 'L2 multiply (Wd.pe6)', 'L2 epilogue (wo.c, pack)', 'barrier A', 'store + barrier B',
-         'fc1 multiply', 'fc1 epilogue (mask, t2, M2 save)', 'barrier A', 'store + barrier B + field', 'v multiply', 'v epilogue (pack)', 'barrier A', 'store + barrier B',
-         'y multiply', 'y epilogue (mask, T1 save)', 'barrier A', 'store + barrier B', 'gpe multiply', 'Jacobian contraction']
+NAMES = ['prologue: vectors, pe3 features', 'barrier', 'L1 multiply (w1.pe3)', 'L1 epilogue ((w2^T wo).h1, relu, mask, pack)', 'barrier A + store', 'barrier B',
+         'A multiply (A.h1)', 'pe6 features (+ (Wd^T wo).pe6)', 'barrier A + store', 'barrier B', 'B multiply (B.pe6)', 'pre2 epilogue (mask, t2, field share)',
+         'barrier A + store', 'barrier B + field', 'y multiply (A^T.t2, M2 save inside)', 'y epilogue (mask, T1 save)', 'barrier A + store', 'barrier B',
+         'gpe multiply (w1^T.t1, T1 save inside)', 'Jacobian contraction']
 with torch.no_grad():
     heads, evec, statics = m.physics_net.field_weights(b['field_data'], b['forecast_h'])
     x_, y_, t_ = (PP._f32c(b[k]).reshape(-1) for k in ('x', 'y', 't'))
@@ -49,10 +49,10 @@ with torch.no_grad():
     torch.cuda.synchronize()
     t = tl.cpu().numpy().astype('int64') & 0xFFFFFFFF
     import numpy as np
-    t = t[:, :, :3, :29]                                    # waves 0..2 run every phase
+    t = t[:, :, :3, :21]                                    # waves 0..2 run every phase
     d = (t[..., 1:] - t[..., :-1]) & 0xFFFFFFFF
-    d = d.reshape(-1, 28)
-    total = ((t[..., 28] - t[..., 0]) & 0xFFFFFFFF).reshape(-1)
+    d = d.reshape(-1, 20)
+    total = ((t[..., 20] - t[..., 0]) & 0xFFFFFFFF).reshape(-1)
     print('dpn_fwd_tiles_kernel<2>, %d points: %d waves sampled, wave lifetime mean %.0f / median %.0f cycles' % (n, d.shape[0], total.mean(), np.median(total)))
     groups = {'multiply': 0.0, 'epilogue / features': 0.0, 'barrier + store': 0.0}
     for i, nm in enumerate(NAMES):
@@ -62,4 +62,4 @@ with torch.no_grad():
         print('  %2d %-36s mean %8.0f  median %8.0f  (%4.1f %%)' % (i, nm, mean, med, 100.0 * mean / total.mean()))
     for g, v in groups.items():
         print('  %-22s %8.0f cycles  %4.1f %%' % (g, v, 100.0 * v / total.mean()))
-    print('  MFMA issue alone: %d instructions x 32 cycles = %d cycles per wave' % (1288, 1288 * 32))
+    print('  MFMA issue alone: %d instructions x 32 cycles = %d cycles per wave' % (72 * 12, 72 * 12 * 32))
