@@ -116,6 +116,8 @@ EXPORTS = {
     'dpn_residual_finish': (c_int, [c_void_p, c_int64, POINTER(DpnPhysics), c_void_p, c_void_p]),
     'dpn_bwd_points': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dpn_bwd_points_scaled': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_wgrad': (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_wgrad_finish': (c_int, [POINTER(DpnNetPtrs), c_void_p, c_int64, c_int, c_void_p, POINTER(DpnNetGradPtrs), c_void_p]),
     'dpn_wgrad_finish_parts': (c_int, [POINTER(DpnNetPtrs), c_void_p, c_int64, c_int, c_void_p, POINTER(DpnNetGradPtrs), c_int, c_void_p]),

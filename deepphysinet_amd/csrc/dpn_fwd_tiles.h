@@ -659,12 +659,13 @@ __global__ __launch_bounds__(256, 3) void dpn_bwd_tiles_kernel(BwdArgs a) {
     const int64_t tiles32 = a.n_pad / 32;
     int64_t pc[2];
     float g[2];                                               // cotangent of the lane's point in column tile p (zero for padding points)
+    const float gsc = a.g_scale ? a.g_scale[0] : 1.0f;        // an upstream cotangent on unit-cotangent streams (dpn_bwd_points_scaled)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int64_t pt = (tile0 + p) * 32 + j;
         const bool valid = pt < a.n;
         pc[p] = valid ? pt : (a.n - 1);
-        g[p] = valid ? a.g_out[pc[p] * 6 + net] : 0.f;
+        g[p] = valid ? gsc * a.g_out[pc[p] * 6 + net] : 0.f;
     }
     const ts::Ident I = ts::make_ident(j, h);
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256, 3) void dpn_bwd_tiles_kernel(BwdArgs a) {
     for (int p = 0; p < 2; ++p) m1w[p] = reinterpret_cast<const u32*>(sv.m1 + ((int64_t)net * tiles32 + tile0 + p) * 64 + lane)[w];
     if (w == 0) {                                             // lane (j, h): point j of column tile h
         const int64_t pt = (tile0 + h) * 32 + j;
-        ov.gnet[(int64_t)net * a.n_pad + pt] = (pt < a.n) ? a.g_out[pt * 6 + net] : 0.f;
+        ov.gnet[(int64_t)net * a.n_pad + pt] = (pt < a.n) ? gsc * a.g_out[pt * 6 + net] : 0.f;
     }
     // ---------------- Z0 -> X (k-steps 0..11) and K-layout rows: wave w builds the (column tile of Z0, point tile) units 3w .. 3w+2.  The rows go
     // out at once (not deferred into the multiply loop as in the forward kernel): nothing of them stays live, the kernel fits 168 registers and
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(256, 3) void dpn_bwd_tiles_kernel(BwdArgs a) {
         const float gp = p ? g[1] : g[0];
         const int64_t pcp = p ? pc[1] : pc[0];
         float gjc = 0.f;
-        if (a.g_jxi && ((tile0 + p) * 32 + j) < a.n) gjc = a.g_jxi[(pcp * 6 + net) * 3 + (ct >> 1)];
+        if (a.g_jxi && ((tile0 + p) * 32 + j) < a.n) gjc = gsc * a.g_jxi[(pcp * 6 + net) * 3 + (ct >> 1)];
         Frag<NS> f0, f1;
         ts::z0_frag<NS>(f0, a, 2 * ct, h, pcp, gp, gjc);
         ts::z0_frag<NS>(f1, a, 2 * ct + 1, h, pcp, gp, gjc);

@@ -126,7 +126,6 @@ struct PackArgs {
     char* packed;
     int ns;
     int form;              // 0: the seven-GEMM stream (ring kernels), 1: the fused five-GEMM stream (dpn_fwd_tiles_kernel; dpn_layout.h)
-    const float* fused;    // form 1: fp32 [6][256][448] rows o of [A = W1 w2 | B = W1 Wd] (made by the GEMM launch in front of this kernel)
 };
 
 DEV float pack_src(const PackArgs& a, const int net, int kb, int lane, int e) {
@@ -138,19 +137,6 @@ DEV float pack_src(const PackArgs& a, const int net, int kb, int lane, int e) {
     } else if (kb >= kS5) {                           // S5: w1^T rows rho (PE slots), K over o
         const int rel = kb - kS5, T = rel / 16, ks = rel % 16;
         return P.w1b1[chain_ch(ks, h, e) * P.ld_w1b1 + gpe_row_to_pe3_ch(32 * T + i)];
-    }
-    if (a.form == 1) {
-        const float* F = a.fused + (long)net * kHidden * kFusedCols;
-        if (kb < kFB) {                               // FA: A rows o, K = chain(h1)
-            const int rel = kb - kFA, T = rel / 16, ks = rel % 16;
-            return F[(32 * T + i) * kFusedCols + chain_ch(ks, h, e)];
-        } else if (kb < kFAT) {                       // FB: B rows o, K = PE6 slots
-            const int rel = kb - kFB, T = rel / 12, ks = rel % 12;
-            return F[(32 * T + i) * kFusedCols + kFusedColB + pe6_ch(ks, h, e)];
-        } else {                                      // FAT: A^T rows j, K over o = chain(t2)
-            const int rel = kb - kFAT, T = rel / 16, ks = rel % 16;
-            return F[chain_ch(ks, h, e) * kFusedCols + (32 * T + i)];
-        }
     }
     if (kb < kS2) {                                   // S1: w2 (8 tiles x 16 k-steps), then Wd (8 tiles x 12 k-steps)
         const int rel = kb - kS1;
@@ -206,9 +192,7 @@ DEV void pack_vectors(const PackArgs& a, const int net, const int part) {
         vec[kVecU * 256 + idx] = sum8(0);
         vec[kVecWo * 256 + idx] = P.wo[ch];
         if (a.form == 1) {
-            // (W1 cvec)[ch] = W1 b2 + W1 bd + W1 e: three columns of the GEMM launch's scratch (dpn_layout.h)
-            const float* Fr = a.fused + ((long)net * kHidden + ch) * kFusedCols;
-            vec[kVecC2 * 256 + idx] = ((Fr[kFusedColB2] + Fr[kFusedColBd]) + Fr[kFusedColE]) + P.bf1[ch];
+            // (C2 = W1 cvec + bf1 is written by the fused kernel's own tile role: it needs a pass over W1, i.e. the matrix cores)
             vec[kVecA2 * 256 + idx] = sum8(1);
             vec[kVecBv * 256 + idx] = idx < kPe ? sum8(2) : 0.f;
         } else {
@@ -240,12 +224,10 @@ __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
     const int net = blockIdx.y;
     const int ns = a.ns;
     uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
-    const int skip = a.form == 1 ? kS5 - kS3 : 0;     // the fused form leaves [kS3, kS5) unwritten
-    const int total = (kPackKB - skip) * 64;          // (kb, lane) pairs
+    const int total = kPackKB * 64;                   // (kb, lane) pairs (form 0; the fused form has its own kernel, dpn_pack_fused_kernel)
     for (int u = blockIdx.x * 256 + threadIdx.x; u < total; u += mcols * 256) {
-        int kb = u >> 6;
+        const int kb = u >> 6;
         const int lane = u & 63;
-        if (kb >= kS3) kb += skip;
         u16 hi[8], lo[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -260,6 +242,107 @@ __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
             w.x = lo[0] | (lo[1] << 16); w.y = lo[2] | (lo[3] << 16); w.z = lo[4] | (lo[5] << 16); w.w = lo[6] | (lo[7] << 16);
             dst[(kb * ns + 1) * 64 + lane] = w;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused form: products + packing in ONE launch
+// A = W1 w2, B = W1 Wd (and C2 = W1 cvec + bf1) on the exact-fp32 matrix instruction, each 32 x 32 result tile split hi / lo and written straight into
+// the fragment stream (A: rows o AND, transposed, rows j; B: rows o over PE6 slots) -- no fp32 scratch, no second launch (rounds before: a 24-problem
+// dpn_sgemm_batch launch + dpn_pack_matrices_kernel, 17 + 10 us on the chain between the hyper-network heads and the forward kernel).
+// Block roles per net (blockIdx.x): [0, 64) tiles of A | [64, 112) tiles of B (columns in PE6 SLOT order) | [112, 120) C2 | [120, 132) the w1 / w1^T
+// fragments | [132, 140) the vector blocks (pack_vectors).
+constexpr int kFusedBlocks = 64 + 48 + 8 + 12 + kVecParts;
+DEV f32x16 pk_mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__global__ __launch_bounds__(256) void dpn_pack_fused_kernel(PackArgs a) {
+    const int net = blockIdx.y, bx = blockIdx.x, ns = a.ns;
+    if (bx >= 132) { pack_vectors(a, net, bx - 132); return; }
+    const DpnNetPtrs& P = a.net[net];
+    uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
+    auto put = [&](const int kb, const int lane, const float (&x)[8]) __attribute__((always_inline)) {
+        u16 hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hi[e] = f2bf(x[e]); lo[e] = f2bf(x[e] - bf2f(hi[e])); }
+        uint4 w;
+        w.x = hi[0] | (hi[1] << 16); w.y = hi[2] | (hi[3] << 16); w.z = hi[4] | (hi[5] << 16); w.w = hi[6] | (hi[7] << 16);
+        dst[(kb * ns) * 64 + lane] = w;
+        if (ns == 2) {
+            w.x = lo[0] | (lo[1] << 16); w.y = lo[2] | (lo[3] << 16); w.z = lo[4] | (lo[5] << 16); w.w = lo[6] | (lo[7] << 16);
+            dst[(kb * ns + 1) * 64 + lane] = w;
+        }
+    };
+    if (bx >= 120) {                                          // w1 (kS0 .. kS1) and w1^T (kS5 .. kPackKB): 192 (kb) x 64 lanes over 12 blocks
+        for (int u = (bx - 120) * 256 + threadIdx.x; u < 192 * 64; u += 12 * 256) {
+            int kb = u >> 6;
+            const int lane = u & 63;
+            if (kb >= kS1) kb += kS5 - kS1;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = pack_src(a, net, kb, lane, e);
+            put(kb, lane, x);
+        }
+        return;
+    }
+    // ---- a 32 x 32 tile of W1 . R, R = w2 (role 0), Wd with its columns in PE6 slot order (role 1), cvec as a single column (role 2)
+    const int role = bx < 64 ? 0 : bx < 112 ? 1 : 2;
+    const int rb = role == 0 ? bx : role == 1 ? bx - 64 : bx - 112;
+    const int To = rb & 7, Tc = role == 2 ? 0 : rb >> 3;      // row tile (o), column tile (j / slot)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, kh = lane >> 5;
+    __shared__ float red[4][16][64];
+    __shared__ float tile[32][33];
+    const float* W1r = P.W1 + (32 * To + col) * kHidden;
+    int ccol = 0;                                             // this lane's column of R
+    if (role == 0) ccol = 32 * Tc + col;
+    else if (role == 1) { const int sl = 32 * Tc + col; ccol = pe6_ch(sl >> 4, (sl >> 3) & 1, sl & 7); }
+    f32x16 acc = (f32x16)0.f;
+    float av[32], bv[32];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int k0 = 64 * wv + 8 * m + 4 * kh;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(W1r + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            av[4 * m + e] = q[e];
+            if (role == 0) bv[4 * m + e] = P.w2b2[(long)k * P.ld_w2b2 + ccol];
+            else if (role == 1) bv[4 * m + e] = P.Wd[k * kPe + ccol];
+            else bv[4 * m + e] = col == 0 ? (P.w2b2[(long)k * P.ld_w2b2 + kHidden] + P.bd[k] + P.evec[k]) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) acc = pk_mfma_f32(av[kk], bv[kk], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv][r][lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wv + 4 * q;                                         // element (r, lane) of the tile: row drow32(r, kh), column col
+        tile[drow32(r, kh)][col] = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+    }
+    __syncthreads();
+    if (role == 2) {                                                      // C2[o] = (W1 cvec)[o] + bf1[o], in the vectors' [h][T][r] order
+        if (threadIdx.x < 32) {
+            const int o = 32 * To + threadIdx.x, w_ = o & 31;
+            float* vec = reinterpret_cast<float*>(a.packed + (long)net * pack_bytes_per_net(ns) + (long)kPackKB * 1024 * ns);
+            vec[kVecC2 * 256 + ((w_ >> 2) & 1) * 128 + (o >> 5) * 16 + (w_ & 3) + 4 * (w_ >> 3)] = tile[threadIdx.x][0] + P.bf1[o];
+        }
+        return;
+    }
+    // ---- the tile as fragments: thread = (form, k-step of the tile's pair, lane)
+    const int form = threadIdx.x >> 7, ksl = (threadIdx.x >> 6) & 1, i = lane & 31, h = lane >> 5;
+    float x[8];
+    if (role == 1) {
+        if (form == 1) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = tile[i][16 * ksl + 8 * h + e];                       // PE6 slot (h, e) of k-step 2 Tc + ksl
+        put(kFB + To * 12 + 2 * Tc + ksl, lane, x);
+    } else if (form == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = tile[i][16 * ksl + 8 * (e >> 2) + 4 * h + (e & 3)];  // A rows o, K = chain(h1): column j = chain_ch(ks, h, e)
+        put(kFA + To * 16 + 2 * Tc + ksl, lane, x);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = tile[16 * ksl + 8 * (e >> 2) + 4 * h + (e & 3)][i];  // A^T rows j, K = chain(t2): row o = chain_ch(ks, h, e)
+        put(kFAT + Tc * 16 + 2 * To + ksl, lane, x);
     }
 }
 
@@ -1106,6 +1189,7 @@ struct BwdArgs {
     DpnGeometry geo;
     const char* packed;
     const float *g_out, *g_jxi;
+    const float* g_scale;    // device scalar multiplied into both cotangent streams as they are read (an upstream cotangent on unit-cotangent streams), or null
     void* saved;
     void* operands;
 #ifdef DPN_TIMELINE
@@ -1133,11 +1217,12 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
     float cd6[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) cd6[c] = a.coord_data[pc * 6 + c];
-    const float g = L.valid ? a.g_out[pc * 6 + net] : 0.f;         // padding points carry a zero cotangent: every operand row is zero
+    const float gsc = a.g_scale ? a.g_scale[0] : 1.0f;
+    const float g = L.valid ? gsc * a.g_out[pc * 6 + net] : 0.f;   // padding points carry a zero cotangent: every operand row is zero
     float gj[3] = {0.f, 0.f, 0.f};
     if (a.g_jxi && L.valid) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gj[c] = a.g_jxi[(pc * 6 + net) * 3 + c];
+        for (int c = 0; c < 3; ++c) gj[c] = gsc * a.g_jxi[(pc * 6 + net) * 3 + c];
     }
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
@@ -1304,7 +1389,12 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
     auto issue = [&](int64_t tile, int slot) __attribute__((always_inline)) {
         char* sl = lds + slot * kSlot;
 #pragma unroll
-        for (int j = 0; j < S::kIssue; ++j) dma16_nt(pbase[j] + tile * pstride[j] + lane * 16, sl + pdst[j]);
+        for (int j = 0; j < S::kIssue; ++j) {
+            // read-once operand streams carry the non-temporal hint; the per-point pe6 table of product 2 is read by six nets' workgroups and should
+            // stay in the memory-side cache (PMC, round 5: with the hint on it the table came from HBM six times: 1 052 MB against 890 algorithmic)
+            if (PROD == 2 && wave + 8 * j >= nsx * 16) dma16(pbase[j] + tile * pstride[j] + lane * 16, sl + pdst[j]);
+            else dma16_nt(pbase[j] + tile * pstride[j] + lane * 16, sl + pdst[j]);
+        }
         dma4(reinterpret_cast<const char*>(gnet + tile * 32) + lane * 4, sl + S::kGOff + wave * 256);
     };
 
@@ -1622,10 +1712,7 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
 // are contiguous along the lane index) and their partial tiles are added in a fixed order through LDS.
 DEV f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 constexpr int kVsideBlocks = 8 * 15;
-__global__ __launch_bounds__(256) void dpn_finish_vside_kernel(FinishArgs a) {
-    __shared__ float red[4][16][64];
-    __shared__ float qs[32];
-    const int bx = blockIdx.x;
+DEV void finish_vside_body(const FinishArgs& a, const int bx, float (&red)[4][16][64], float (&qs)[32]) {
     const int rt = bx & 7, ctile = bx >> 3, net = blockIdx.y;
     const int kind = ctile < 8 ? 0 : ctile == 8 ? 1 : 2;                  // d w2 | vector column | dWd
     const DpnNetPtrs& P = a.net[net];
@@ -1672,9 +1759,8 @@ __global__ __launch_bounds__(256) void dpn_finish_vside_kernel(FinishArgs a) {
 // per-tile parts of r[o] = sum_i W1[o][i] G[o][i] (+ bf1 mvec, added by dpn_finish_fc2_kernel).  One workgroup per 32 x 32 tile of G; wave wv
 // takes j in [64 wv, 64 wv + 64) and k in [48 wv, 48 wv + 48); lane (col, kh) holds four consecutive reduction indices per load of its row.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-__global__ __launch_bounds__(256) void dpn_finish_gside_kernel(FinishArgs a) {
-    __shared__ float red[4][16][64];
-    const int bx = blockIdx.x, net = blockIdx.y;
+DEV void finish_gside_body(const FinishArgs& a, const int bx, float (&red)[4][16][64]) {
+    const int net = blockIdx.y;
     const int rt = bx & 7, ct = bx >> 3;
     const DpnNetPtrs& P = a.net[net];
     const DpnNetGradPtrs& Gd = a.grad[net];
@@ -1722,6 +1808,17 @@ __global__ __launch_bounds__(256) void dpn_finish_gside_kernel(FinishArgs a) {
         for (int sft = 16; sft > 0; sft >>= 1) rp += __shfl_xor(rp, sft);
         if (col == 0) a.scratch_rp[((int64_t)net * 8 + ct) * 256 + o] = rp;
     }
+}
+
+// ONE launch for the two independent consumers of dpn_finish_rows_kernel's sums: blocks [0, n_v) = the W1^T diag(u) factor (what the hyper-network's
+// backward waits for), the rest = G = S1 w2^T + S2 Wd^T + ... (static tensors only) -- side by side instead of one behind the other.  n_v = 0 or
+// kVsideBlocks, the grid decides which halves run (dpn_wgrad_finish_parts).
+constexpr int kGsideBlocks = 64;
+__global__ __launch_bounds__(256) void dpn_finish_sides_kernel(FinishArgs a, int n_v) {
+    __shared__ float red[4][16][64];
+    __shared__ float qs[32];
+    if ((int)blockIdx.x < n_v) finish_vside_body(a, blockIdx.x, red, qs);
+    else finish_gside_body(a, blockIdx.x - n_v, red);
 }
 
 // one block per (row o', net): r, then dW2 = wo (x) r, dbf2, dwo (with colsum(Z) = w2 q1 + Wd q6 + sum g cvec), dbo, dbf1
@@ -2331,7 +2428,6 @@ static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 // hi+lo mode: the tile-split kernels (dpn_fwd_tiles.h; 64 points per workgroup, two workgroups per CU).  Caller-encoded coordinates and the
 // single-bf16 mode stay on the ring kernels.  DPN_FWD_KERNEL / DPN_BWD_KERNEL = ring | tiles override (read per call: the tests compare the two
 // decompositions inside one process).
-static inline int64_t fused_scratch_offset(int prec) { return (((int64_t)kNets * pack_bytes_per_net(prec) + 255) / 256) * 256; }
 static inline bool use_tiles(const char* knob, int prec, bool has_pe_in) {
     const char* force = getenv(knob);
     return (force ? (force[0] == 't') : (prec == 2)) && !has_pe_in;
@@ -2381,7 +2477,7 @@ int dpn_sizes(int64_t n, int prec, DpnSizes* out) {
     if (!out || n <= 0 || (prec != 1 && prec != 2)) return -1;
     const int64_t n_pad = pad_points(n);
     out->n_pad = n_pad;
-    out->packed = fused_scratch_offset(prec) + fused_scratch_bytes();      // the six nets' blocks + the fp32 [A | B] scratch of the fused form
+    out->packed = (((int64_t)kNets * pack_bytes_per_net(prec) + 255) / 256) * 256;
     out->saved = saved_bytes(n_pad, prec);
     out->operands = operand_bytes(n_pad, prec);
     out->k_splits = choose_plan(n_pad, prec).most;
@@ -2391,8 +2487,8 @@ int dpn_sizes(int64_t n, int prec, DpnSizes* out) {
 
 static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, int n_jobs, const DpnColsumJob* jobs, void* stream);
 
-// form 0: the seven-GEMM stream of the ring kernels; form 1: the fused five-GEMM stream of dpn_fwd_tiles_kernel (dpn_layout.h) -- a GEMM launch
-// forms A = W1 w2 and B = W1 Wd (exact fp32 matrix cores, 12 problems) in the scratch tail of `packed`, the pack kernel splits them into fragments
+// form 0: the seven-GEMM stream of the ring kernels; form 1: the fused five-GEMM stream of dpn_fwd_tiles_kernel (dpn_layout.h) -- ONE launch forms
+// A = W1 w2, B = W1 Wd and C2 = W1 cvec + bf1 on the exact-fp32 matrix instruction and writes them as fragments (dpn_pack_fused_kernel)
 int dpn_pack_weights_form(const DpnNetPtrs nets[DPN_NETS], int prec, int form, void* packed, void* stream) {
     if (!nets || !packed || (prec != 1 && prec != 2) || (form != 0 && form != 1)) return -1;
     PackArgs a;
@@ -2400,29 +2496,12 @@ int dpn_pack_weights_form(const DpnNetPtrs nets[DPN_NETS], int prec, int form, v
     a.packed = reinterpret_cast<char*>(packed);
     a.ns = prec;
     a.form = form;
-    a.fused = nullptr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (form == 1) {
-        float* F = reinterpret_cast<float*>(a.packed + fused_scratch_offset(prec));
-        a.fused = F;
-        DpnGemmProblem q[4 * kNets] = {};
-        for (int k = 0; k < kNets; ++k) {
-            // rows o of [A | W1 b2 | B | W1 bd | W1 e] (dpn_layout.h):  W1 . [w2 | b2] (N = 257: the hyper-network's row is [w2 | b2]),  W1 . Wd,  W1 . bd,  W1 . e
-            const float* Bm[4] = {nets[k].w2b2, nets[k].Wd, nets[k].bd, nets[k].evec};
-            const int ldb[4] = {(int)nets[k].ld_w2b2, kPe, 1, 1}, nn[4] = {kHidden + 1, kPe, 1, 1}, col[4] = {0, kFusedColB, kFusedColBd, kFusedColE};
-            for (int j = 0; j < 4; ++j) {
-                DpnGemmProblem& p = q[4 * k + j];
-                p.A[0] = nets[k].W1; p.lda[0] = kHidden;
-                p.B[0] = Bm[j]; p.ldb[0] = ldb[j];
-                p.C = F + (int64_t)k * kHidden * kFusedCols + col[j];
-                p.M = kHidden; p.N = nn[j]; p.K = kHidden; p.ldc = kFusedCols; p.ta = 0; p.tb = 0; p.nterms = 1;
-            }
-        }
-        const int rc = sgemm_batch_launch(4 * kNets, q, 0, nullptr, stream);
-        if (rc) return rc;
+    if (form == 1) {                                                      // products + packing in one launch (no fp32 scratch)
+        hipLaunchKernelGGL(dpn_pack_fused_kernel, dim3(kFusedBlocks, kNets), dim3(256), 0, s, a);
+        return ck(hipGetLastError());
     }
-    const int cols = form == 1 ? 28 : 40;                                // block columns of matrix fragments (+ kVecParts for the vectors): 544 / 800 KB per net
-    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(cols + kVecParts, kNets), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(40 + kVecParts, kNets), dim3(256), 0, s, a);
     return ck(hipGetLastError());
 }
 
@@ -2519,16 +2598,29 @@ int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n, float beta
 
 #endif  // DPN_HAS_REST
 #if DPN_HAS_POINT
+static int bwd_points_launch(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
+                             const DpnGeometry* geo, const void* packed, int prec, const float* g_out, const float* g_jxi, const float* g_scale,
+                             const void* saved, void* operands, void* stream);
 int dpn_bwd_points(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
                    const DpnGeometry* geo, const void* packed, int prec, const float* g_out, const float* g_jxi, const void* saved,
                    void* operands, void* stream) {
+    return bwd_points_launch(x, y, t, pe_in, coord_data, n, freqs, geo, packed, prec, g_out, g_jxi, nullptr, saved, operands, stream);
+}
+int dpn_bwd_points_scaled(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
+                          const DpnGeometry* geo, const void* packed, int prec, const float* g_out, const float* g_jxi, const float* g_scale,
+                          const void* saved, void* operands, void* stream) {
+    return bwd_points_launch(x, y, t, pe_in, coord_data, n, freqs, geo, packed, prec, g_out, g_jxi, g_scale, saved, operands, stream);
+}
+static int bwd_points_launch(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n, const float* freqs,
+                             const DpnGeometry* geo, const void* packed, int prec, const float* g_out, const float* g_jxi, const float* g_scale,
+                             const void* saved, void* operands, void* stream) {
     if (!coord_data || !freqs || !geo || !packed || !g_out || !saved || !operands || n <= 0 || (prec != 1 && prec != 2)) return -1;
     if (pe_in ? (g_jxi != nullptr) : (!x || !y || !t)) return -1;
 #ifdef DPN_TIMELINE
-    BwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), g_out, g_jxi,
+    BwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), g_out, g_jxi, g_scale,
               const_cast<void*>(saved), operands, g_timeline};
 #else
-    BwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), g_out, g_jxi,
+    BwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), g_out, g_jxi, g_scale,
               const_cast<void*>(saved), operands};
 #endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -2590,14 +2682,10 @@ int dpn_wgrad_finish_parts(const DpnNetPtrs nets[DPN_NETS], const void* packed, 
     a.scratch_sg = a.scratch_q6 + kNets * 256;
     a.scratch_rp = a.scratch_sg + 8;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (parts & 1) {
-        hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(dpn_finish_vside_kernel, dim3(kVsideBlocks, kNets), dim3(256), 0, s, a);
-    }
-    if (parts & 2) {
-        hipLaunchKernelGGL(dpn_finish_gside_kernel, dim3(64, kNets), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
-    }
+    if (parts & 1) hipLaunchKernelGGL(dpn_finish_rows_kernel, dim3(256, kNets), dim3(256), 0, s, a);
+    const int n_v = (parts & 1) ? kVsideBlocks : 0, n_g = (parts & 2) ? kGsideBlocks : 0;
+    hipLaunchKernelGGL(dpn_finish_sides_kernel, dim3(n_v + n_g, kNets), dim3(256), 0, s, a, n_v);
+    if (parts & 2) hipLaunchKernelGGL(dpn_finish_fc2_kernel, dim3(256, kNets), dim3(256), 0, s, a);
     return ck(hipGetLastError());
 }
 

@@ -68,7 +68,7 @@ DPN_HD long pack_bytes_per_net(int ns) { return (long)kPackKB * 1024 * ns + kNum
 
 // ------------------------------------------------------------------ FUSED form of the block (round 5; dpn_fwd_tiles_kernel)
 // With A = W1 w2 and B = W1 Wd formed once per net (exact fp32) the forward + Jacobian pass is five GEMMs instead of seven
-// (dpn_fwd_tiles.h).  Same block size and the same offsets for what the other kernels read (S0 = w1 for the backward stage-1 kernels, S5 = w1^T,
+// (dpn_fwd_tiles.h; dpn_pack_fused_kernel forms the products and writes their fragments in one launch).  Same block size and the same offsets for what the other kernels read (S0 = w1 for the backward stage-1 kernels, S5 = w1^T,
 // the vector block), so that one buffer serves either form:
 //   F0  = S0  w1     8 x 12        FA  A      8 x 16  (A rows o, K = chain(h1))       FB  B    8 x 12  (A rows o, K = PE6 slots)
 //   FAT       A^T    8 x 16  (A rows j, K = chain(t2))                                  F5  = S5  w1^T  6 x 16;   [kS3, kS5) stays unwritten
@@ -77,9 +77,5 @@ DPN_HD long pack_bytes_per_net(int ns) { return (long)kPackKB * 1024 * ns + kNum
 constexpr int kF0 = kS0, kFA = kS1, kFB = kS1 + 8 * 16, kFAT = kS2, kF5 = kS5;
 static_assert(kFB + 8 * 12 == kS2 && kFAT + 8 * 16 == kS3, "fused form fits the block");
 enum { kVecC2 = kVecCvec, kVecA2 = kVecBf1, kVecBv = kVecB2BdE_unused };
-// fp32 scratch [6][256][kFusedCols]: rows o of [A = W1 w2 (256) | W1 b2 | pad 3 | B = W1 Wd (192) | W1 bd | W1 e | pad 2] -- the three vectors are what
-// C2 = W1 (b2 + bd + e) + bf1 is made of (one GEMM launch forms everything that needs a pass over W1)
-constexpr int kFusedCols = 456, kFusedColB2 = 256, kFusedColB = 260, kFusedColBd = 452, kFusedColE = 453;
-DPN_HD long fused_scratch_bytes() { return (long)kNets * kHidden * kFusedCols * 4; }
 
 }  // namespace dpn

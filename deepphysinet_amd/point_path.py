@@ -95,6 +95,17 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_ones = {}
+
+
+def _one(device):
+    """A persistent device scalar 1.0 (the unit cotangent of a total loss)."""
+    k = (device.type, device.index)
+    if k not in _ones:
+        _ones[k] = torch.ones(1, dtype=torch.float32, device=device)
+    return _ones[k]
+
+
 HEADS_COLS = 6 * 193 + 6 * 257          # one GEMM output row: [w1b1 of net 0..5 | w2b2 of net 0..5]
 HEADS_W2_OFF = 6 * 193
 
@@ -154,7 +165,7 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     return out_n, jac_n
 
 
-def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics, into=None, fork=False, keep=()):
+def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, g_out, g_jxi, statics, into=None, fork=False, keep=(), g_scale=None):
     """Weight gradients from per-point cotangents.  Returns (g_heads [256,2700], g_evec [6,256], [48 static grads]); `into` = the same
     triple preallocated by the caller (a batch of fields writes each field's gradients side by side).
 
@@ -169,8 +180,9 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
     operands = torch.empty(ws.sizes.operands, dtype=torch.uint8, device=dev)
     partials = torch.empty(ws.sizes.partials, dtype=torch.uint8, device=dev)
     geo = cfg.geometry()
-    L.check(lib.dpn_bwd_points(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), n, _ptr(_freqs(dev)), ctypes.byref(geo),
-                               _ptr(ws.packed), cfg.prec, _ptr(g_out), _ptr(g_jxi), _ptr(ws.saved), _ptr(operands), _stream()),
+    # g_scale: a device scalar multiplied into both cotangent streams as stage 1 reads them (they were formed for a unit cotangent of the total)
+    L.check(lib.dpn_bwd_points_scaled(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), n, _ptr(_freqs(dev)), ctypes.byref(geo),
+                                      _ptr(ws.packed), cfg.prec, _ptr(g_out), _ptr(g_jxi), _ptr(g_scale), _ptr(ws.saved), _ptr(operands), _stream()),
             'dpn_bwd_points')
     arena = False
     if into is None:
@@ -306,8 +318,17 @@ class _PdeLossFn(torch.autograd.Function):
         sums = torch.empty(((n + 255) // 256) * 6, dtype=torch.float64, device=dev)      # per-block rows, reduced by dpn_residual_finish
         losses7 = torch.empty(7, dtype=torch.float32, device=dev)
         geo, ph = cfg.geometry(), cfg.physics()
-        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, None, _ptr(sums),
-                                 None, None, _stream()), 'dpn_residual')
+        # With gradients wanted, the SAME pass over the points also writes d total / d (out, Jacobian) for a unit cotangent of the total (the usual
+        # backward: loss.backward(seed) on the sum of the six terms): the backward pass then has no residual launch of its own, stage 1 multiplies
+        # the cotangent that arrives into the streams as it reads them (dpn_bwd_points_scaled).  A cotangent on the individual terms takes the
+        # separate pass, as before.
+        ctx.unit = None
+        if need_grad:
+            g_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
+            g_jxi = torch.empty((n, 6, 3), dtype=torch.float32, device=dev)
+            ctx.unit = (g_out, g_jxi)
+        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, _ptr(_one(dev)) if need_grad else None,
+                                 _ptr(sums), _ptr(g_out) if need_grad else None, _ptr(g_jxi) if need_grad else None, _stream()), 'dpn_residual')
         L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses7), _stream()), 'dpn_residual_finish')
         ctx.cfg, ctx.ws = cfg, ws
         ctx.keep = (x_, y_, t_, f_, cd_, hd_, ev_, st, out_n, jac_n)
@@ -327,12 +348,16 @@ class _PdeLossFn(torch.autograd.Function):
         gt = None if g_total is None else _f32c(g_total).reshape(1)
         if gl is None and gt is None:
             return (None,) * (8 + len(st))
+        nets = _net_ptrs(hd_, ev_, st)
+        if gl is None and ctx.unit is not None:                  # cotangent on the total only: the unit-cotangent streams of the forward pass, scaled on load
+            g_out, g_jxi = ctx.unit
+            ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st, fork=True, keep=(hd_, ev_), g_scale=gt)
+            return (None, None, None, None, None, None, ghd, gev, *gst)
         g_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
         g_jxi = torch.empty((n, 6, 3), dtype=torch.float32, device=dev)
         geo, ph = cfg.geometry(), cfg.physics()
         L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), _ptr(gl), _ptr(gt), None,
                                  _ptr(g_out), _ptr(g_jxi), _stream()), 'dpn_residual(grad)')
-        nets = _net_ptrs(hd_, ev_, st)
         ghd, gev, gst = _backward_points(cfg, ctx.ws, nets, x_, y_, t_, None, cd_, g_out, g_jxi, st, fork=True, keep=(hd_, ev_))
         return (None, None, None, None, None, None, ghd, gev, *gst)
 

@@ -135,6 +135,12 @@ int dpn_residual_finish(const double* loss_sums, int64_t n_points, const DpnPhys
 int dpn_bwd_points(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n_points,
                    const float* freqs, const DpnGeometry* geo, const void* packed, int prec,
                    const float* g_out, const float* g_jxi, const void* saved, void* operands, void* stream);
+/* The same with a device scalar multiplied into both cotangent streams as they are read: the caller has g_out / g_jxi for a UNIT cotangent of the total
+ * loss (dpn_residual evaluated once, losses and cotangents in one pass) and the upstream cotangent arrives later, as a tensor (loss.backward(seed)). */
+int dpn_bwd_points_scaled(const float* x, const float* y, const float* t, const float* pe_in, const float* coord_data, int64_t n_points,
+                          const float* freqs, const DpnGeometry* geo, const void* packed, int prec,
+                          const float* g_out, const float* g_jxi, const float* g_scale /* [1] device, or NULL = 1 */, const void* saved, void* operands,
+                          void* stream);
 
 /* Backward, stage 2: weight-gradient reductions over points (split-K partial sums). */
 int dpn_wgrad(int64_t n_points, int prec, const float* g_out, const void* saved, const void* operands, void* partials, void* stream);

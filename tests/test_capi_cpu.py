@@ -47,8 +47,8 @@ def test_sizes_host_function():
     sz = _lib.DpnSizes()
     assert lib.dpn_sizes(37265, 1, ctypes.byref(sz)) == 0
     assert sz.n_pad == 37376 and sz.n_pad % 128 == 0
-    blocks = 6 * (800 * 1024 + 6 * 1024 + 16)                   # six nets' fragment blocks + vectors, then (256-byte aligned) the fp32 [A | B] scratch
-    assert sz.packed == (blocks + 255) // 256 * 256 + 6 * 256 * 456 * 4              # of the fused form (dpn_pack_weights_form, csrc/dpn_layout.h)
+    blocks = 6 * (800 * 1024 + 6 * 1024 + 16)                   # six nets' fragment blocks + vectors (either packed form, csrc/dpn_layout.h)
+    assert sz.packed == (blocks + 255) // 256 * 256
     assert lib.dpn_fwd_form(2, 0) == 1 and lib.dpn_fwd_form(2, 1) == 0 and lib.dpn_fwd_form(1, 0) == 0
     sz2 = _lib.DpnSizes()
     assert lib.dpn_sizes(37265, 2, ctypes.byref(sz2)) == 0
