@@ -444,8 +444,46 @@ def main():
         med = sorted(times)[len(times) // 2]
         rec.update({'model': m, 'optimizer': opt, 'dt': med, 'graphed': graphs is not None, 'fn': fn, 'first_block_s': first, 'block_s': times,
                     'prewarm_s': prewarm_s, 'prewarm_replays': prewarm_replays, 'per_rank': per_rank, 'staged': staged, 'graphs': graphs,
-                    'n_reduce': n_reduce, 'replayer': replayer})
+                    'n_reduce': n_reduce, 'replayer': replayer,
+                    'recapture': (lambda: capture_one_graph() if (split_step and len(graphs) == 1) else capture_segments()) if graphs is not None else None})
         return rec
+
+    def in_step_kernel_times(rec, reps=40):
+        """Durations of the three point kernels INSIDE the replayed step: a second capture of the same step with two device-clock stamps (one-thread
+        kernels writing wall_clock64, point_path.KernelClock) around each of dpn_fwd / dpn_bwd_points / dpn_wgrad, replayed 10 + `reps` times back to
+        back behind the timed region.  (HIP event records inside a capture are dependencies, not timers, and torch refuses external events on ROCm;
+        an event pair around an eager launch measures the kernel in another clock / cache state than the step's: it read 370-419 us where rocprofv3
+        shows 353 us for the launches of the step.)  The stamp pair's own cost is measured in the same replay and subtracted.  One GPU only."""
+        if rec.get('recapture') is None or world > 1 or args.leads != 1:
+            return None
+        from deepphysinet_amd import point_path as PP
+        try:
+            PP.clock = PP.KernelClock(dev)
+            try:
+                probe_graphs = rec['recapture']()
+            finally:
+                clk, PP.clock = PP.clock, None
+            pf = rec['replayer'](probe_graphs)
+            for _ in range(10):
+                pf()
+            torch.cuda.synchronize()
+            clk.reset()
+            for _ in range(reps):
+                pf()
+            torch.cuda.synchronize()
+            d = clk.durations()
+            del probe_graphs
+            if not all(k in d for k in ('fwd', 'bwd', 'wgrad')):
+                return {'error': 'stamps incomplete: %s' % sorted(d)}
+            med = lambda v: sorted(v)[len(v) // 2]
+            return {'replays': reps, 'clock_khz': clk.khz,
+                    'fwd_us': sum(d['fwd']) / reps, 'bwd_us': sum(d['bwd']) / reps, 'wgrad_us': sum(d['wgrad']) / reps,
+                    'fwd_us_median': med(d['fwd']), 'fwd_us_min': min(d['fwd']), 'fwd_us_max': max(d['fwd']),
+                    'stamp_pair_us': sum(d['pair']) / reps if 'pair' in d else None}
+        except Exception as e:                     # noqa
+            PP.clock = None
+            torch.cuda.synchronize()
+            return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
     def collective_info():
         """Who took part: backend, world size, every rank's device (index, PCI bus id, name) gathered over the process group itself, and the
@@ -550,9 +588,11 @@ def main():
         out['config']['encoder_fp8'] = 'mx (E8M0 scale per 32 k, v_mfma_scale_f32_32x32x64_f8f6f4)' if args.encoder_fp8 == 'mx' else 'per-row scales, v_mfma_f32_32x32x16_fp8_fp8'
         out['dtype'] += '; encoder forward GEMMs fp8 e4m3 MFMA (configs[4])'
 
-    def kernel_rooflines(m, prec):
+    def kernel_rooflines(m, prec, in_step=None):
         """`roofline` (dpn_fwd_kernel, MFMA-bound: the dominant kernel) and `roofline_hbm_kernel` (dpn_wgrad_kernel) of the workload in
-        precision mode `prec`, durations measured live with a HIP event pair around every launch inside a pre-queued replay of the point path."""
+        precision mode `prec`.  Durations: `in_step` (in_step_kernel_times: device-clock stamps around the launches inside the replayed step graph)
+        when it is there; beside it (`kernel_ms_eager_pair`), and alone when the step was not captured, a HIP event pair around every launch inside a
+        pre-queued eager replay of the point path."""
         import ctypes
         from deepphysinet_amd import _lib as L
         from deepphysinet_amd import point_path as PP
@@ -624,6 +664,9 @@ def main():
             k_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / reps
             b_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / reps
             w_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / reps
+            eager_ms = (k_ms, b_ms, w_ms)
+            if in_step and 'fwd_us' in in_step:
+                k_ms, b_ms, w_ms = in_step['fwd_us'] * 1e-3, in_step['bwd_us'] * 1e-3, in_step['wgrad_us'] * 1e-3
             sustained = None
             if not args.no_power:
                 def soak():
@@ -640,6 +683,9 @@ def main():
         roof = {'bound': 'mfma', 'kernel': fwd_name,
                 'achieved': ach / 1e12, 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_BF16,
                 'traffic': traffic, 'traffic_source': source, 'kernel_ms': k_ms,
+                'kernel_ms_source': ('device-clock stamps around the launch inside the replayed step graph, mean of %d replays' % in_step['replays'])
+                                    if in_step and 'fwd_us' in in_step else 'HIP event pair around each launch, pre-queued eager replay of the point path',
+                'kernel_ms_eager_pair': eager_ms[0], 'in_step': in_step,
                 'algorithmic_flop_per_point': ALG_FLOP_FWD_JAC,
                 'algorithmic_bytes': args.points * 136,          # 40 B in + 96 B out per point: the kernel is MFMA-bound
                 'executed_mfma_tflops': args.points * 6 * (EXEC_MAC_FWD if ns == 2 else EXEC_MAC_FWD_RING) * 2 * nsplit / (k_ms * 1e-3) / 1e12,
@@ -654,7 +700,7 @@ def main():
         w_bytes = ws.sizes.n_pad * 6 * (2 * 512 + (512 + 512 + 384) * ns) + ws.sizes.n_pad * 384 * ns
         roof_hbm = {'bound': 'hbm', 'kernel': 'dpn_wgrad_kernel<%d>' % ns,
                     'achieved': w_bytes / (w_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': w_bytes / (w_ms * 1e-3) / HBM_PEAK, 'kernel_ms': w_ms, 'algorithmic_bytes': w_bytes,
+                    'frac': w_bytes / (w_ms * 1e-3) / HBM_PEAK, 'kernel_ms': w_ms, 'kernel_ms_eager_pair': eager_ms[2], 'algorithmic_bytes': w_bytes,
                     'traffic': pmc_traffic('dpn_wgrad_kernel', prec, args.points)[0], 'bwd_points_kernel_ms': b_ms}
         # backward stage 1 (dpn_bwd_tiles_kernel / dpn_bwd_kernel): per point and net it writes the K-layout rows of Z1 (256 columns) and Z0 (192 columns),
         # hi (+ lo) bf16, per point the pe6 table (192 columns), and reads 40 B of cotangents
@@ -662,12 +708,13 @@ def main():
         b_traffic = pmc_traffic('dpn_bwd_tiles_kernel' if ns == 2 else 'dpn_bwd_kernel', prec, args.points)[0]
         roof_hbm['bwd_stage1_kernel'] = {'bound': 'hbm', 'kernel': 'dpn_bwd_tiles_kernel<2>' if ns == 2 else 'dpn_bwd_kernel<1>',
                                          'achieved': b_bytes / (b_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                                         'frac': b_bytes / (b_ms * 1e-3) / HBM_PEAK, 'kernel_ms': b_ms, 'algorithmic_bytes': b_bytes, 'traffic': b_traffic,
+                                         'frac': b_bytes / (b_ms * 1e-3) / HBM_PEAK, 'kernel_ms': b_ms, 'kernel_ms_eager_pair': eager_ms[1],
+                                         'algorithmic_bytes': b_bytes, 'traffic': b_traffic,
                                          'executed_mfma_frac_of_peak': args.points * 6 * EXEC_MAC_BWD1 * 2 * nsplit / (b_ms * 1e-3) / MFMA_PEAK_BF16}
         return roof, roof_hbm
 
     if rank == 0:
-        out['roofline'], out['roofline_hbm_kernel'] = kernel_rooflines(m, args.prec)
+        out['roofline'], out['roofline_hbm_kernel'] = kernel_rooflines(m, args.prec, in_step_kernel_times(rec))
         out['roofline']['step_frac_of_peak'] = pts_per_s / world * ALG_FLOP_STEP / MFMA_PEAK_BF16
         if not args.no_power and world == 1:
             def steps_():
@@ -686,7 +733,7 @@ def main():
                                            'parity': 'PDE losses within 1e-4 of the fp32 reference' if alt == 'bf16x2' else
                                                      'plain bf16 operands: PDE losses within 5e-2 (measured 1e-3 ... 2e-2), not the parity-grade mode'}
             if args.leads == 1:
-                r2, _ = kernel_rooflines(m2, alt)
+                r2, _ = kernel_rooflines(m2, alt, in_step_kernel_times(rec2))
                 out['other_precision_mode']['roofline'] = {k: r2[k] for k in ('kernel', 'frac', 'kernel_ms', 'achieved', 'executed_mfma_frac_of_peak')}
             del m2
             rec2.clear()

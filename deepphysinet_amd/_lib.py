@@ -2,7 +2,7 @@
 library is missing or no MI355X is visible, every point-path call raises."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DPN_LIB', os.path.join(_HERE, 'libdpn_hip.so'))    # DPN_LIB: experiment builds only
@@ -101,6 +101,8 @@ class DpnSizes(Structure):
 EXPORTS = {
     'dpn_version': (c_int, []),
     'dpn_sizes': (c_int, [c_int64, c_int, POINTER(DpnSizes)]),
+    'dpn_clock_stamp': (c_int, [c_void_p, c_void_p, c_uint32, c_void_p]),
+    'dpn_clock_rate_khz': (c_int, [POINTER(c_int)]),
     'dpn_pack_weights': (c_int, [POINTER(DpnNetPtrs), c_int, c_void_p, c_void_p]),
     'dpn_fwd_form': (c_int, [c_int, c_int]),
     'dpn_pack_weights_form': (c_int, [POINTER(DpnNetPtrs), c_int, c_int, c_void_p, c_void_p]),

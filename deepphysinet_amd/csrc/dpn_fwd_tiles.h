@@ -638,7 +638,10 @@ template <int NS>
 __global__ __launch_bounds__(256, 3) void dpn_bwd_tiles_kernel(BwdArgs a) {
     constexpr int kXBytes = 12 * 2 * NS * 1024;
     __shared__ __attribute__((aligned(16))) char lds[kXBytes + 1024];
-    const int net = blockIdx.y;
+    // a.reverse (DPN_BWD_ORDER=reverse, a probe of the memory-side cache: DESIGN.md section 4c): workgroups walk nets and tiles in the opposite order of the
+    // forward launch, so stage 1 begins on the saved state the forward wrote last.  Same values either way (no sum crosses a tile).
+    const int net = a.reverse ? kNets - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const unsigned bx = a.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     TS_STAMP(0);
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(256, 3) void dpn_bwd_tiles_kernel(BwdArgs a) {
     auto chunk = [&](const int kb) __attribute__((always_inline)) { return pk + (long)kb * 1024 * NS; };
     ts::Head<NS, 2> H;
     ts::gemm_head<NS, 12, 2>(chunk(kS0 + 2 * w * 12), lane, H);
-    const int64_t tile0 = (int64_t)blockIdx.x * 2;
+    const int64_t tile0 = (int64_t)bx * 2;
     const int64_t tiles32 = a.n_pad / 32;
     int64_t pc[2];
     float g[2];                                               // cotangent of the lane's point in column tile p (zero for padding points)

@@ -1192,6 +1192,7 @@ struct BwdArgs {
     const float* g_scale;    // device scalar multiplied into both cotangent streams as they are read (an upstream cotangent on unit-cotangent streams), or null
     void* saved;
     void* operands;
+    int reverse;             // tile-split kernel: walk nets / tiles in the opposite order (DPN_BWD_ORDER=reverse: a cache-residency probe)
 #ifdef DPN_TIMELINE
     unsigned* timeline;      // experiment build: [net][workgroup][4 waves][48] shader clocks at the phase boundaries of dpn_bwd_tiles_kernel
 #endif
@@ -1297,6 +1298,7 @@ struct WgradArgs {
     void* saved;
     void* operands;
     float* partials;
+    int reverse;            // every workgroup walks its point range from the end (DPN_WGRAD_ORDER=reverse: a cache-residency probe; the sums' order changes)
 #ifdef DPN_WGRAD_PHASES
     unsigned* phases;       // experiment build: [net][workgroup][8 waves][8]: cycles in wait / barrier / issue / compute, tiles
 #endif
@@ -1388,6 +1390,7 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
     }
     auto issue = [&](int64_t tile, int slot) __attribute__((always_inline)) {
         char* sl = lds + slot * kSlot;
+        if (a.reverse && t1 > t0) tile = t0 + (t1 - 1 - tile);
 #pragma unroll
         for (int j = 0; j < S::kIssue; ++j) {
             // read-once operand streams carry the non-temporal hint; the per-point pe6 table of product 2 is read by six nets' workgroups and should
@@ -2428,6 +2431,10 @@ static inline int64_t pad_points(int64_t n) { return ((n + 127) / 128) * 128; }
 // hi+lo mode: the tile-split kernels (dpn_fwd_tiles.h; 64 points per workgroup, two workgroups per CU).  Caller-encoded coordinates and the
 // single-bf16 mode stay on the ring kernels.  DPN_FWD_KERNEL / DPN_BWD_KERNEL = ring | tiles override (read per call: the tests compare the two
 // decompositions inside one process).
+static inline int order_reversed(const char* knob) {          // read on every launch: a measurement switch (tools set it between runs of one process)
+    const char* e = getenv(knob);
+    return e && e[0] == 'r' ? 1 : 0;                     // "reverse"
+}
 static inline bool use_tiles(const char* knob, int prec, bool has_pe_in) {
     const char* force = getenv(knob);
     return (force ? (force[0] == 't') : (prec == 2)) && !has_pe_in;
@@ -2462,6 +2469,15 @@ static inline SplitPlan choose_plan(int64_t n_pad, int ns) {
     return p;
 }
 #endif  // DPN_HAS_REST
+#if DPN_HAS_REST
+// A device-clock stamp as a graph node: HIP event records inside a stream capture are not timing events (and torch refuses external events on ROCm),
+// so a measurement INSIDE a replayed hipGraph puts this one-thread kernel in front of and behind the launch it brackets.  wall_clock64() is the
+// constant-rate counter HIP events read (hipDeviceAttributeWallClockRate, 100 MHz on gfx950).
+__global__ void dpn_clock_stamp_kernel(unsigned long long* ring, unsigned int* cursor, unsigned int cap) {
+    const unsigned long long t = wall_clock64();
+    ring[atomicAdd(cursor, 1u) % cap] = t;
+}
+#endif
 constexpr int64_t kFinishScratchFloats = (int64_t)kNets * 65536 + (int64_t)kNets * 256 * 192 + 4 * kNets * 256 + 8 + (int64_t)kNets * 8 * 256;   // S1 | S2 | mv | u | q1 | q6 | sum g | r parts (FinishArgs)
 static inline int ck(hipError_t e) { return (int)e; }
 
@@ -2469,6 +2485,20 @@ extern "C" {
 
 #if DPN_HAS_REST
 int dpn_version(void) { return 2; }
+
+int dpn_clock_stamp(unsigned long long* ring, unsigned int* cursor, unsigned int cap, void* stream) {
+    if (!ring || !cursor || cap == 0) return -1;
+    hipLaunchKernelGGL(dpn_clock_stamp_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), ring, cursor, cap);
+    return ck(hipGetLastError());
+}
+
+int dpn_clock_rate_khz(int* khz) {
+    if (!khz) return -1;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return ck(e);
+    return ck(hipDeviceGetAttribute(khz, hipDeviceAttributeWallClockRate, dev));
+}
 
 // which packed form (dpn_pack_weights_form) the forward launch of this precision mode expects: 1 = fused (tile-split kernel), 0 = ring stream
 int dpn_fwd_form(int prec, int has_pe_in) { return use_tiles("DPN_FWD_KERNEL", prec, has_pe_in != 0) ? 1 : 0; }
@@ -2618,10 +2648,10 @@ static int bwd_points_launch(const float* x, const float* y, const float* t, con
     if (pe_in ? (g_jxi != nullptr) : (!x || !y || !t)) return -1;
 #ifdef DPN_TIMELINE
     BwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), g_out, g_jxi, g_scale,
-              const_cast<void*>(saved), operands, g_timeline};
+              const_cast<void*>(saved), operands, order_reversed("DPN_BWD_ORDER"), g_timeline};
 #else
     BwdArgs a{x, y, t, coord_data, freqs, pe_in, n, pad_points(n), *geo, reinterpret_cast<const char*>(packed), g_out, g_jxi, g_scale,
-              const_cast<void*>(saved), operands};
+              const_cast<void*>(saved), operands, order_reversed("DPN_BWD_ORDER")};
 #endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(a.n_pad / 128), kNets);
@@ -2646,7 +2676,7 @@ int dpn_wgrad(int64_t n, int prec, const float* g_out, const void* saved, const 
     if (!g_out || !saved || !operands || !partials || n <= 0 || (prec != 1 && prec != 2)) return -1;
     const SplitPlan plan = choose_plan(pad_points(n), prec);
     WgradArgs a{n, pad_points(n), {plan.s[0], plan.s[1], plan.s[2], plan.s[3]}, const_cast<void*>(saved), const_cast<void*>(operands),
-                reinterpret_cast<float*>(partials)};
+                reinterpret_cast<float*>(partials), order_reversed("DPN_WGRAD_ORDER")};
 #ifdef DPN_WGRAD_PHASES
     a.phases = g_wgrad_phases;
 #endif

@@ -139,6 +139,54 @@ class _Workspace:
         self.saved = torch.empty(self.sizes.saved, dtype=torch.uint8, device=self.device)
 
 
+class KernelClock:
+    """Measurement aid (bench.py): device-clock stamps around the three point kernels INSIDE a captured step.  While `point_path.clock` holds one,
+    every launch of dpn_fwd / dpn_bwd_points / dpn_wgrad through this module is bracketed by two dpn_clock_stamp nodes (one-thread kernels appending
+    wall_clock64 to a ring); `durations()` turns the ring into per-kernel microseconds.  The product path runs with `clock = None`."""
+    NAMES = ('pair', 'fwd', 'bwd', 'wgrad')          # 'pair': two stamps back to back -- the stamp's own cost, subtracted from the others
+
+    def __init__(self, device, cap=4096):
+        self.cap = cap
+        self.ring = torch.zeros(cap, dtype=torch.int64, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+        khz = ctypes.c_int(0)
+        L.check(L.load().dpn_clock_rate_khz(ctypes.byref(khz)), 'dpn_clock_rate_khz')
+        self.khz = khz.value
+        self.order = []                               # names in stamp order within one replay (recorded while capturing)
+        self.recording = True
+
+    def stamp(self, name):
+        if self.recording:
+            self.order.append(name)
+        L.check(L.load().dpn_clock_stamp(_ptr(self.ring), _ptr(self.cursor), self.cap, _stream()), 'dpn_clock_stamp')
+
+    def reset(self):
+        self.cursor.zero_()
+        self.recording = False
+
+    def durations(self):
+        """{name: [us per replay]} from the stamps written since reset(); the 'pair' interval of the same replay is subtracted from the kernels'."""
+        n = int(self.cursor.item())
+        per = len(self.order)
+        if per == 0 or n == 0 or n > self.cap or n % per:
+            return {}
+        t = self.ring[:n].cpu().view(-1, per).double() * (1e3 / self.khz)          # us
+        out = {}
+        for name in self.NAMES:
+            idx = [i for i, nm in enumerate(self.order) if nm == name]
+            if len(idx) == 2:
+                out[name] = (t[:, idx[1]] - t[:, idx[0]]).tolist()
+        pair = out.get('pair')
+        if pair:
+            for name in ('fwd', 'bwd', 'wgrad'):
+                if name in out:
+                    out[name] = [v - p_ for v, p_ in zip(out[name], pair)]
+        return out
+
+
+clock = None            # a KernelClock while bench.py captures its instrumented copy of the step
+
+
 def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coord_data, want_jac, want_saved, ref6=None):
     lib = L.load()
     n = coord_data.shape[0]
@@ -160,8 +208,12 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
         L.check(lib.dpn_fwd_ref_nets(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), _ptr(ref6), n, _ptr(_freqs(dev)), ctypes.byref(geo),
                                      _ptr(ws.packed), cfg.prec, n_nets, _ptr(out_n), None, _stream()), 'dpn_fwd_ref_nets')
         return out_n, jac_n
+    if clock is not None:
+        clock.stamp('pair'), clock.stamp('pair'), clock.stamp('fwd')
     L.check(lib.dpn_fwd_ref(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), _ptr(ref6), n, _ptr(_freqs(dev)), ctypes.byref(geo),
                             _ptr(ws.packed), cfg.prec, _ptr(out_n), _ptr(jac_n), _ptr(ws.saved), _stream()), 'dpn_fwd')
+    if clock is not None:
+        clock.stamp('fwd')
     return out_n, jac_n
 
 
@@ -181,9 +233,13 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
     partials = torch.empty(ws.sizes.partials, dtype=torch.uint8, device=dev)
     geo = cfg.geometry()
     # g_scale: a device scalar multiplied into both cotangent streams as stage 1 reads them (they were formed for a unit cotangent of the total)
+    if clock is not None:
+        clock.stamp('bwd')
     L.check(lib.dpn_bwd_points_scaled(_ptr(x), _ptr(y), _ptr(t), _ptr(pe_in), _ptr(coord_data), n, _ptr(_freqs(dev)), ctypes.byref(geo),
                                       _ptr(ws.packed), cfg.prec, _ptr(g_out), _ptr(g_jxi), _ptr(g_scale), _ptr(ws.saved), _ptr(operands), _stream()),
             'dpn_bwd_points')
+    if clock is not None:
+        clock.stamp('bwd')
     arena = False
     if into is None:
         g_heads = torch.empty((256, HEADS_COLS), dtype=torch.float32, device=dev)
@@ -198,7 +254,11 @@ def _backward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coo
     else:
         g_heads, g_evec, g_stat = into
     garr = _net_ptrs(g_heads, g_evec, g_stat, cls=L.DpnNetGradPtrs)
+    if clock is not None:
+        clock.stamp('wgrad')
     L.check(lib.dpn_wgrad(n, cfg.prec, _ptr(g_out), _ptr(ws.saved), _ptr(operands), _ptr(partials), _stream()), 'dpn_wgrad')
+    if clock is not None:
+        clock.stamp('wgrad')
     # (only when every static gradient is a freshly leased slot of the optimiser's flat buffer: autograd then keeps the view as param.grad without
     # touching it; a gradient it would have to ADD to an existing one on the main stream must be complete when the node returns)
     if fork and arena and branch.enabled('finish'):

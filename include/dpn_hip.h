@@ -78,6 +78,12 @@ typedef struct DpnSizes {
 int dpn_version(void);
 int dpn_sizes(int64_t n_points, int prec, DpnSizes* out);
 
+/* Measurement aid (bench.py): one-thread kernel that appends the device's constant-rate clock (wall_clock64) to ring[cursor++ % cap].  Capturable:
+ * it brackets a launch INSIDE a replayed hipGraph, where a HIP event pair cannot be used (event records in a capture are dependencies, not timers).
+ * dpn_clock_rate_khz: the counter's rate (hipDeviceAttributeWallClockRate). */
+int dpn_clock_stamp(unsigned long long* ring, unsigned int* cursor, unsigned int cap, void* stream);
+int dpn_clock_rate_khz(int* khz);
+
 /* fp32 tables: freq32 = 2**linspace(0,4,32), freq16 = 2**linspace(0,4,16) formed in fp32 exactly as
  * utils/position_encoding.py:27 does.  Copied to the device by the caller (8 + 4 = 48 floats: [32 | 16]). */
 

@@ -348,6 +348,16 @@ def test_bench_step_with_rccl_collectives_on_one_rank():
     for k, b in outs[1]['pde_losses'].items():                            # after the same number of optimiser steps (--no-prewarm: a fixed count)
         a = outs[0]['pde_losses'][k]
         assert np.isfinite(a) and abs(a - b) <= 1e-5 * abs(b), (k, a, b)
+    # roofline durations come from INSIDE the replayed step (device-clock stamps around the launches, point_path.KernelClock) in both step forms,
+    # and agree with the event pair around an eager launch of the same kernel to the extent two clock / cache states can
+    for o in outs:
+        r = o['roofline']
+        ins = r['in_step']
+        assert ins and 'error' not in ins, ins
+        assert ins['replays'] == 40 and ins['clock_khz'] > 0 and 0.0 < ins['stamp_pair_us'] < 20.0, ins
+        assert abs(r['kernel_ms'] * 1e3 - ins['fwd_us']) < 1e-6 and r['kernel_ms_source'].startswith('device-clock stamps')
+        assert 0.7 < ins['fwd_us'] / (r['kernel_ms_eager_pair'] * 1e3) < 1.3, (ins, r['kernel_ms_eager_pair'])
+        assert ins['bwd_us'] > 0 and ins['wgrad_us'] > 0
 
 
 def test_run_train_interface_drives_steps_and_resumes(tmp_path):
