@@ -1045,6 +1045,20 @@ struct ResArgs {
     float *g_out, *g_jxi;
 };
 
+// the criterion's per-element value rho(r) and slope rho'(r) (DpnPhysics.criterion): every criterion the reference's builder offers is a function of
+// input - target alone, so `loss(lhs, 0)` (:104) and the gas law's `loss(p, rho R T)` (:179) are both mean(rho(r))
+DEV float crit_value(const float r, const int kind, const float beta) {
+    const float ar = fabsf(r);
+    if (kind == DPN_CRIT_L1) return ar;
+    return ar < beta ? 0.5f * r * r / beta : ar - 0.5f * beta;             // nn.SmoothL1Loss
+}
+DEV float crit_slope(const float r, const int kind, const float beta) {
+    if (kind == DPN_CRIT_MSE) return 2.0f * r;
+    const float sg = r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f);
+    if (kind == DPN_CRIT_L1) return sg;
+    return fabsf(r) < beta ? r / beta : sg;
+}
+
 DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1096,7 +1110,8 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
         __shared__ double wsum[4][6];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
-            double s = valid ? (double)r[e] * (double)r[e] : 0.0;
+            double s = 0.0;
+            if (valid) s = a.ph.criterion == DPN_CRIT_MSE ? (double)r[e] * (double)r[e] : (double)crit_value(r[e], a.ph.criterion, a.ph.beta);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
             if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][e] = s;
@@ -1113,7 +1128,7 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
     for (int e = 0; e < 6; ++e) {
         // upstream weight of loss e: cotangent of losses[e] plus cotangent of the in-kernel total (1 when neither is given)
         const float w = (a.gl || a.gtot) ? ((a.gl ? a.gl[e] : 0.f) + (a.gtot ? a.gtot[0] : 0.f)) : 1.f;
-        g[e] = 2.0f * a.ph.factor[e] * w * r[e] * inv_n;     // d(factor*mean(r^2))/dr
+        g[e] = a.ph.factor[e] * w * crit_slope(r[e], a.ph.criterion, a.ph.beta) * inv_n;     // d(factor*mean(rho(r)))/dr ; MSE: 2 r
     }
     const float ir = 1.f / rho, ire = 1.f / (rho + EPS);
     float gv[6], gJ[6][3];
@@ -1346,10 +1361,9 @@ constexpr int wgrad_lds_bytes() {
 }
 
 template <int NS, int PROD>
-DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
+DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int net) {
     using S = WgradShape<NS, PROD>;
     constexpr int nct = S::nct, nsx = S::nsx, kSlot = S::kSlot, RING = S::RING, PER_TILE = S::PER_TILE, ncol = nct * 32;
-    const int net = blockIdx.y;
     const int64_t tiles = a.n_pad / 32;
     const int64_t per = (tiles + a.splits[PROD] - 1) / a.splits[PROD];
     const int64_t t0 = (int64_t)split * per;
@@ -1542,7 +1556,7 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
     }
 #ifdef DPN_WGRAD_PHASES
     if (a.phases && lane == 0) {
-        unsigned* o = a.phases + (((int64_t)net * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        unsigned* o = a.phases + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
         o[0] = ph_wait; o[1] = ph_bar; o[2] = ph_issue; o[3] = ph_comp; o[4] = (unsigned)(t1 - t0); o[5] = PROD;
     }
 #endif
@@ -1589,11 +1603,15 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split) {
 template <int NS>
 __global__ __launch_bounds__(512, 2) void dpn_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[wgrad_lds_bytes<NS>()];
-    int prod = 1, split = blockIdx.x;                                   // workgroup -> (product, point range): uniform scalar walk
+    // workgroup -> (product, point range): uniform scalar walk.  (Round 5 tried an XCD-aware placement -- the six nets' product-2 workgroups of one range on
+    // ONE XCD, so that its L2 serves the per-point pe6 table to five of them: 186.7 / 186.1 us against 184.7 / 188.6 us for this linear walk on one box.
+    // No difference: the table's re-reads are served by the memory-side cache either way.)
+    int prod = 1, split = blockIdx.x;
+    const int net = blockIdx.y;
     while (prod < 3 && split >= a.splits[prod]) { split -= a.splits[prod]; ++prod; }
-    if (prod == 1) wgrad_body<NS, 1>(a, lds, split);
-    else if (prod == 2) wgrad_body<NS, 2>(a, lds, split);
-    else wgrad_body<NS, 3>(a, lds, split);
+    if (prod == 1) wgrad_body<NS, 1>(a, lds, split, net);
+    else if (prod == 2) wgrad_body<NS, 2>(a, lds, split, net);
+    else wgrad_body<NS, 3>(a, lds, split, net);
 }
 
 // ------------------------------------------------------------------------------------------------ backward, stage 3
@@ -2607,6 +2625,7 @@ int dpn_contract_gpe(const float* g_out, const float* gpe, int64_t n, float* g_p
 int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t n, const DpnGeometry* geo, const DpnPhysics* phys,
                  const float* gl, const float* gtot, double* loss_sums, float* g_out, float* g_jxi, void* stream) {
     if (!out_n || !jac_n || !f || !geo || !phys || n <= 0 || (g_out && !g_jxi)) return -1;
+    if (phys->criterion < DPN_CRIT_MSE || phys->criterion > DPN_CRIT_SMOOTH_L1 || (phys->criterion == DPN_CRIT_SMOOTH_L1 && !(phys->beta > 0.f))) return -1;
     ResArgs a{out_n, jac_n, f, n, *geo, *phys, gl, gtot, loss_sums, g_out, g_jxi};
     hipLaunchKernelGGL(dpn_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return ck(hipGetLastError());

@@ -596,6 +596,12 @@ def check_enc_status():
                                'range of the f16 hi+lo operand split of dpn_enc_fwd / dpn_enc_bwd')
 
 
+def reset_enc_status():
+    """Clear the (sticky) status words: a caller that has handled the condition -- bench.py discarding a run whose trajectory went non-finite."""
+    for t in _enc_status.values():
+        t.zero_()
+
+
 def enc_pack(mats):
     """MFMA-fragment images (x W^T and g W forms) of the [256, 256] fp32 matrices `mats` (dpn_enc_pack): one launch."""
     lib = L.load()

@@ -45,21 +45,36 @@ class InterfacePhysics(nn.Module):
         self._cfg_cache = None
 
     # ------------------------------------------------------------------ configuration of the HIP path
-    def point_config(self, loss_factor=None) -> PointConfig:
+    def point_config(self, loss_factor=None, criterion=None) -> PointConfig:
+        crit_kind, crit_beta = self._check_pde_criterion(criterion if criterion is not None else self.train_cfg['losses'].get('pde_loss', {'name': 'MSELoss'}))
+        # inverse_norm (:232-262) as one affine map + optional clip per variable: mean_norm v * nf[1] + nf[0]; min_max v * (nf[1] - nf[0]) + nf[0];
+        # use_norm False: the identity and no clip (the reference clips inside its `if use_norm`).  The three-factor min_max form (v ** 2 + nf[2]) is
+        # not affine and stays with the torch expression of `inverse_norm`
+        mean, std, clipv = [], [], []
         for k in OBS_ORDER:
             c = self.obs_norm_cfg[k]
-            if not c.get('use_norm', True) or c.get('norm_type', 'mean_norm').lower() == 'min_max':
-                raise NotImplementedError('only mean/std de-normalisation is implemented (the shipped config, cfg:64-76)')
+            if not c.get('use_norm', True):
+                mean.append(0.0), std.append(1.0), clipv.append(False)
+                continue
+            nf = c['norm_factor']
+            if c.get('norm_type', 'mean_norm').lower() == 'min_max':
+                if len(nf) != 2:
+                    raise NotImplementedError('min_max de-normalisation with a third factor (v ** 2 + nf[2], :247-249) is not an affine map: the fused '
+                                              'residual kernel implements the two-factor form and mean/std')
+                mean.append(float(nf[0])), std.append(float(nf[1]) - float(nf[0]))
+            else:
+                mean.append(float(nf[0])), std.append(float(nf[1]))
+            clipv.append(True)
         lf = loss_factor or self.train_cfg['losses']['loss_factor']
         key = (self.dx, self.dy, self.lon_size, self.lat_size, self.pred_t_span, bool(self.with_clip), self.precision,
-               tuple(float(lf[k]) for k in LOSS_ORDER))
+               tuple(float(lf[k]) for k in LOSS_ORDER), tuple(mean), tuple(std), tuple(clipv), crit_kind, crit_beta)
         if self._cfg_cache is None or self._cfg_cache[0] != key:
+            bound = lambda k, i: float(self.obs_norm_cfg[k]['bound'][i]) if 'bound' in self.obs_norm_cfg[k] else (0.0, 0.0)[i]
             cfg = PointConfig(dx=self.dx, dy=self.dy, lon_size=self.lon_size, lat_size=self.lat_size, pred_t_span=self.pred_t_span,
-                              mean=tuple(self.obs_norm_cfg[k]['norm_factor'][0] for k in OBS_ORDER),
-                              std=tuple(self.obs_norm_cfg[k]['norm_factor'][1] for k in OBS_ORDER),
-                              clip_lo=tuple(self.obs_norm_cfg[k]['bound'][0] for k in OBS_ORDER),
-                              clip_hi=tuple(self.obs_norm_cfg[k]['bound'][1] for k in OBS_ORDER),
-                              with_clip=bool(self.with_clip), factors=key[-1], prec=self.precision)
+                              mean=tuple(mean), std=tuple(std),
+                              clip_lo=tuple(bound(k, 0) for k in OBS_ORDER), clip_hi=tuple(bound(k, 1) for k in OBS_ORDER),
+                              with_clip=bool(self.with_clip), clip_vars=tuple(clipv), factors=key[7], prec=self.precision,
+                              criterion=crit_kind, beta=crit_beta)
             self._cfg_cache = (key, cfg)
         self.physics_net.point_cfg = self._cfg_cache[1]
         return self._cfg_cache[1]
@@ -162,23 +177,41 @@ class InterfacePhysics(nn.Module):
 
     # ------------------------------------------------------------------ fused HIP path
     def _check_pde_criterion(self, criterion):
-        if not (isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean'):
-            raise NotImplementedError('the fused residual kernel implements nn.MSELoss(reduction="mean") (cfg:137); got %r' % (criterion,))
+        """The PDE criterion (`builder_loss(**train_cfg.losses.pde_loss)`, :384; every equation calls it as loss(residual, 0), :104 ... :179) as the
+        fused residual kernel's (kind, beta).  The three the reference's losses/builder.py can build for it are implemented: MSELoss (cfg:137),
+        L1Loss, WeightSmoothL1Loss(beta); given as a module or as the config's dict."""
+        from .. import _lib as L
+        from ..losses import WeightSmoothL1Loss
+        if isinstance(criterion, dict):
+            name = criterion.get('name', 'MSELoss')
+            known = {'MSELoss': (L.CRIT_MSE, 0.0), 'L1Loss': (L.CRIT_L1, 0.0), 'WeightSmoothL1Loss': (L.CRIT_SMOOTH_L1, float(criterion.get('beta', 0.1)))}
+            extra = set(criterion) - {'name'} - ({'beta'} if name == 'WeightSmoothL1Loss' else set())
+            if name in known and not extra and known[name][1] >= 0.0 and (name != 'WeightSmoothL1Loss' or known[name][1] > 0.0):
+                return known[name]
+        elif isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean':
+            return L.CRIT_MSE, 0.0
+        elif isinstance(criterion, nn.L1Loss) and criterion.reduction == 'mean':
+            return L.CRIT_L1, 0.0
+        elif isinstance(criterion, WeightSmoothL1Loss) and criterion.beta > 0:
+            return L.CRIT_SMOOTH_L1, float(criterion.beta)
+        elif isinstance(criterion, nn.SmoothL1Loss) and criterion.reduction == 'mean' and criterion.beta > 0:
+            return L.CRIT_SMOOTH_L1, float(criterion.beta)
+        raise NotImplementedError('the fused residual kernel implements the PDE criteria of the reference\'s loss builder -- nn.MSELoss (cfg:137), nn.L1Loss, '
+                                  'WeightSmoothL1Loss(beta > 0), reduction "mean"; got %r' % (criterion,))
 
-    def pde_loss_terms(self, x, y, t, f, field_data, input_data, forecast_h, loss_factor=None, use_cache=False, with_total=False):
+    def pde_loss_terms(self, x, y, t, f, field_data, input_data, forecast_h, loss_factor=None, use_cache=False, with_total=False, criterion=None):
         """The six scaled residual losses as a [6] tensor (motion_u, motion_v, continuous, energy, vapor, gas)."""
-        cfg = self.point_config(loss_factor)
+        cfg = self.point_config(loss_factor, criterion)
         heads, evec, statics = self.physics_net.field_weights(field_data, forecast_h, use_cache=use_cache)
         return pde_losses(cfg, x, y, t, f, input_data, heads, evec, statics, with_total=with_total)
 
     def place_one_batch(self, x, y, t, f, field_data, input_data, forecast_h, criterion, loss_factor, global_step, local_rank, device,
                         summary=None, prefix='inter', log_step=100, use_cache=False):
         """:271-320.  Same arguments and return value; the fields, the Jacobian, the residuals and their backward run in HIP."""
-        self._check_pde_criterion(criterion)
         f, x, y, t = f.to(device), x.to(device), y.to(device), t.to(device)
         # train_loss = mu + mv + en + co + va + ga in the reference's order of additions (:301), formed inside the residual kernel
         terms, train_loss = self.pde_loss_terms(x, y, t, f, field_data, input_data, forecast_h, loss_factor, use_cache=use_cache,
-                                                with_total=True)
+                                                with_total=True, criterion=criterion)
         if summary is not None and global_step % log_step == 1 and local_rank == 0:
             names = ('montion_u_loss', 'montion_v_loss', 'continous_loss', 'energy_loss', 'vapor_loss', 'gas_loss')
             vals = terms.detach().cpu().tolist()
@@ -194,8 +227,7 @@ class InterfacePhysics(nn.Module):
         (:271-320), the B totals averaged ('mean') or added ('sum'); the encoder runs once over all B samples and the point kernels
         field after field.  Returns (loss, terms [B, 6])."""
         from ..point_path import pde_losses_batch
-        self._check_pde_criterion(criterion)
-        cfg = self.point_config(loss_factor)
+        cfg = self.point_config(loss_factor, criterion)
         heads, evec, statics = self.physics_net.field_weights(field_data, forecast_h)
         B = field_data.shape[0]
         heads, evec = heads.reshape(B, 256, -1), evec.reshape(B, 6, 256)
@@ -367,17 +399,31 @@ class InterfacePhysics(nn.Module):
         return src(epoch) if callable(src) else src
 
     @staticmethod
-    def _shard_samples(samples, rank, world):
+    def _shard_samples(samples, rank, world, shuffle_seed=None):
         """DistributedSampler semantics (:936, drop_last=False): every rank takes ceil(n / world) samples of the epoch -- rank r the samples
         r, r + world, ... -- and the tail wraps around to the epoch's first samples, so that all ranks run the same number of steps (and
-        of all-reduces).  A sequence is indexed (a rank touches only its own samples); any other iterable is consumed round by round."""
-        if world == 1:
-            yield from samples
-            return
+        of all-reduces).  A sequence is indexed (a rank touches only its own samples); any other iterable is consumed round by round.
+        shuffle_seed (sequences only): the order is `torch.randperm(n)` drawn from a generator seeded with it, as DistributedSampler(shuffle=True,
+        seed=0) does; the reference never calls `set_epoch`, so every epoch walks the SAME seed-0 permutation (torch/utils/data/distributed.py)."""
         if hasattr(samples, '__len__') and hasattr(samples, '__getitem__'):
             n = len(samples)
-            for k in range(-(-n // world) if n else 0):
-                yield samples[(rank + k * world) % n]
+            if n == 0:
+                return
+            if shuffle_seed is not None:
+                g = torch.Generator()
+                g.manual_seed(int(shuffle_seed))
+                order = torch.randperm(n, generator=g).tolist()
+            else:
+                order = list(range(n))
+            if world == 1:
+                for i in order:
+                    yield samples[i]
+                return
+            for k in range(-(-n // world)):
+                yield samples[order[(rank + k * world) % n]]
+            return
+        if world == 1:
+            yield from samples
             return
         head, buf = [], []
         for smp in samples:
@@ -394,16 +440,20 @@ class InterfacePhysics(nn.Module):
                 k += 1
             yield buf[rank]
 
-    def _epoch_samples(self, kwargs, epoch, rank, world):
-        """The epoch's samples of this rank.  `samples` may be a callable samples(epoch) -> all samples, sharded here like DistributedSampler
-        WITHOUT its shuffle (:936 shuffles a seed-0 permutation per epoch; here rank r takes samples r, r + world, ... in the given order:
-        shuffle in the source if wanted).  With samples_per_rank=True (keyword, or attribute `samples.per_rank = True`) the callable is
-        samples(epoch, rank, world) -> this rank's samples only (nothing is drawn for the other ranks)."""
+    def _epoch_samples(self, kwargs, epoch, rank, world, dist_mode=False):
+        """The epoch's samples of this rank.  `samples` may be a callable samples(epoch) -> all samples, sharded here like DistributedSampler.
+        The distributed loop shuffles an indexable source the way the reference's sampler does (:936: DistributedSampler's defaults = a seed-0
+        permutation, the same every epoch because `set_epoch` is never called); keyword `shuffle=False` keeps the given order, `shuffle_seed`
+        changes the seed.  The single-process loop takes the samples in the given order (the reference's DataLoader(shuffle=True), :419, draws an
+        unseeded permutation per epoch: shuffle in the source if wanted).  Iterables that cannot be indexed are consumed in their own order.
+        With samples_per_rank=True (keyword, or attribute `samples.per_rank = True`) the callable is samples(epoch, rank, world) -> this rank's
+        samples only (nothing is drawn for the other ranks)."""
         src = kwargs.get('samples', self.train_cfg.get('train_data', {}).get('samples'))
         per_rank = kwargs.get('samples_per_rank', getattr(src, 'per_rank', False))
         if callable(src) and per_rank:                   # explicit protocol (keyword samples_per_rank=True or attribute samples.per_rank)
             return src(epoch, rank, world)
-        return self._shard_samples(self._train_samples(kwargs, epoch), rank, world)
+        seed = int(kwargs.get('shuffle_seed', 0)) if (dist_mode and kwargs.get('shuffle', True)) else None
+        return self._shard_samples(self._train_samples(kwargs, epoch), rank, world, shuffle_seed=seed)
 
     def _run_train(self, dist_mode, **kwargs):
         tc = self.train_cfg
@@ -445,7 +495,7 @@ class InterfacePhysics(nn.Module):
         self.physics_net.train()
         last = None
         for epoch in range(current_epoch, num_epoch):
-            for batch in self._epoch_samples(kwargs, epoch, rank, world):        # DistributedSampler (:936): one field sample per rank per step
+            for batch in self._epoch_samples(kwargs, epoch, rank, world, dist_mode):   # DistributedSampler (:936): one field sample per rank per step
                 with_pde = with_pde_cfg and global_step >= pde_start
                 self.with_clip = True
                 global_step += 1

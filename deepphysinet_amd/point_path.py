@@ -42,8 +42,12 @@ class PointConfig:
     clip_lo: Sequence[float] = (-500.0, -500.0, 10000.0, 50.0, 1e-6, 1e-6)
     clip_hi: Sequence[float] = (500.0, 500.0, 500000.0, 500.0, 10.0, 10.0)
     with_clip: bool = True
+    clip_vars: Sequence[bool] = (False, False, True, True, True, True)      # which variables torch.clip applies to when with_clip (never u, v; not a variable
+                                                                            # whose obs_norm_cfg says use_norm: False -- interface_physics.py:236-257)
     factors: Sequence[float] = (1.e3, 1.e3, 1.e10, 1e1, 1.e14, 1.e-7)
     prec: int = L.PREC_BF16X2
+    criterion: int = L.CRIT_MSE            # the PDE criterion (train_cfg.losses.pde_loss): MSELoss | L1Loss | WeightSmoothL1Loss(beta)
+    beta: float = 0.0
 
     def geometry(self) -> L.DpnGeometry:
         return L.DpnGeometry(float(self.dx), float(self.dy), float(self.lon_size - 1), float(self.lat_size - 1), float(self.pred_t_span))
@@ -53,8 +57,9 @@ class PointConfig:
         for k in range(L.NETS):
             ph.mean[k], ph.std[k] = float(self.mean[k]), float(self.std[k])
             ph.clip_lo[k], ph.clip_hi[k] = float(self.clip_lo[k]), float(self.clip_hi[k])
-            ph.clip_on[k] = int(bool(self.with_clip) and k >= 2)       # u, v are never clipped (interface_physics.py:256-257)
+            ph.clip_on[k] = int(bool(self.with_clip) and k >= 2 and bool(self.clip_vars[k]))     # u, v are never clipped (interface_physics.py:256-257)
             ph.factor[k] = float(self.factors[k])
+        ph.criterion, ph.beta = int(self.criterion), float(self.beta)
         return ph
 
 

@@ -63,7 +63,12 @@ typedef struct DpnPhysics {
     float clip_lo[DPN_NETS], clip_hi[DPN_NETS];
     int   clip_on[DPN_NETS];              /* with_clip && bounds apply to this field (u,v: never)  */
     float factor[DPN_NETS];               /* motion_u, motion_v, continuous, energy, vapor, gas     */
+    int   criterion;                      /* the PDE criterion `loss(residual, 0)` (train_cfg.losses.pde_loss, interface_physics.py:384; the reference's
+                                           * losses/builder.py offers these three): DPN_CRIT_MSE nn.MSELoss, DPN_CRIT_L1 nn.L1Loss, DPN_CRIT_SMOOTH_L1
+                                           * WeightSmoothL1Loss(beta) = mean of nn.SmoothL1Loss(beta, reduction='none') (weights_loss.py:12-21)        */
+    float beta;                           /* DPN_CRIT_SMOOTH_L1 only (> 0)                                                                        */
 } DpnPhysics;
+enum { DPN_CRIT_MSE = 0, DPN_CRIT_L1 = 1, DPN_CRIT_SMOOTH_L1 = 2 };
 
 /* Byte sizes of the caller-allocated work buffers for n_points collocation points. */
 typedef struct DpnSizes {

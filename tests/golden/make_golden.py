@@ -81,6 +81,38 @@ def write_f10(m, run_pde):
     np.savez_compressed(os.path.join(HERE, 'f10_grid_nodes_h336_fp32.npz'), x=inp['x'].numpy(), y=inp['y'].numpy(), **rec)
 
 
+def f12_norm_cfg(base):
+    """F12's de-normalisation table: u10 not normalised at all (use_norm False), pres in the two-factor min_max form, the rest as shipped."""
+    import copy
+    c = copy.deepcopy(base)
+    c['u10']['use_norm'] = False
+    m_, s_ = c['pres']['norm_factor']
+    c['pres']['norm_type'] = 'min_max'
+    c['pres']['norm_factor'] = [m_ - 0.5 * s_, m_ + 0.5 * s_]
+    return c
+
+
+def write_f12(m, run_pde, builder_loss, inter):
+    """F12: the branches of the PDE path the shipped config does not take, run on the reference itself -- the two other criteria its loss builder
+    offers for `pde_loss` (L1Loss, WeightSmoothL1Loss(beta), interface_physics.py:384 + losses/builder.py), and inverse_norm's other branches
+    (use_norm False, two-factor min_max, :238-243).  256 interior points, clip on, fp32; parameter gradients' norms for the criteria."""
+    import copy
+    base = copy.deepcopy(m.obs_norm_cfg)
+    out = {}
+    for tag, crit, ncfg in (('l1', builder_loss(name='L1Loss'), None), ('sl1', builder_loss(name='WeightSmoothL1Loss', beta=0.1), None),
+                            ('sl1_b2', builder_loss(name='WeightSmoothL1Loss', beta=2.0), None), ('norm', None, f12_norm_cfg(base))):
+        m.physics_net.zero_grad()
+        rec, total = run_pde(m, inter, True, torch.float32, crit=crit, norm_cfg=ncfg if ncfg is not None else copy.deepcopy(base))
+        total.backward()
+        g = {k: p.grad.detach() for k, p in m.physics_net.named_parameters()}
+        out[tag + '.parts'], out[tag + '.total'] = rec['parts'], rec['total']
+        out[tag + '.fields_phys'] = rec['fields_phys']
+        out[tag + '.grad_norms'] = np.array([float(v.double().norm()) for v in g.values()])
+        out[tag + '.grad_names'] = np.array(list(g.keys()))
+    m.obs_norm_cfg = base
+    np.savez_compressed(os.path.join(HERE, 'f12_criteria_and_norm_branches.npz'), **out)
+
+
 def write_f11():
     """F11: get_coriolis (dataset/physics_dataset.py:521-526) called on the reference class itself (it never touches `self`): the
     latitude forms its two callers build -- margin points `begin_lat + y_rand * 0.25` with integer node indices (:336-337, :418) and
@@ -149,14 +181,16 @@ def main():
             f2['meta_out_h%d' % int(h)] = net.meta_net(inter['field_data'], fh).numpy()
     np.savez_compressed(os.path.join(HERE, 'f2_encoder.npz'), **f2)
 
-    def run_pde(model, inputs, with_clip, dtype):
+    def run_pde(model, inputs, with_clip, dtype, crit=None, norm_cfg=None):
         model.with_clip = with_clip
+        if norm_cfg is not None:
+            model.obs_norm_cfg = norm_cfg
         cast = lambda v: v.to(dtype)
         x = cast(inputs['x']).clone().requires_grad_(True)
         y = cast(inputs['y']).clone().requires_grad_(True)
         t = cast(inputs['t']).clone().requires_grad_(True)
         f = cast(inputs['f'])
-        crit = builder_loss(name='MSELoss')
+        crit = crit if crit is not None else builder_loss(name='MSELoss')
         lf = cfg.config['train_cfg']['losses']['loss_factor']
         rec = {}
         pe = model.encoding_coord(x, y, t, model.pred_t_span)
@@ -188,6 +222,10 @@ def main():
     if only_f10:                               # add the one fixture without rewriting (re-zipping) the others
         write_f10(m, run_pde)
         print('f10 written')
+        return
+    if '--only-f12' in sys.argv:
+        write_f12(m, run_pde, builder_loss, inter)
+        print('f12 written')
         return
 
     # ---- F3/F4/F5: VariableNet outputs, Jacobian, residuals (a6-a16), fp32, clip on/off

@@ -249,6 +249,12 @@ def test_sample_sharding_pads_like_distributed_sampler():
                 assert got_seq == want and got_gen == want, (n, world, rank, got_seq, got_gen, want)
                 assert touched == want                      # nothing drawn for the other ranks
                 counts.add(len(got_seq))
+                # the distributed loop's default: the reference's `DistributedSampler(train_dataset)` (:936) = shuffle=True, seed 0, and no set_epoch
+                # call anywhere -> the same seed-0 permutation every epoch
+                want_sh = list(DistributedSampler(list(range(n)), num_replicas=world, rank=rank, drop_last=False))
+                touched.clear()
+                assert list(InterfacePhysics._shard_samples(Seq(), rank, world, shuffle_seed=0)) == want_sh, (n, world, rank)
+                assert touched == want_sh
             assert len(counts) == 1                         # every rank runs the same number of steps
 
 
@@ -265,6 +271,15 @@ def test_rank_aware_sample_callable_is_used_as_is():
     assert list(d._epoch_samples({'samples': own, 'samples_per_rank': True}, 3, 1, 4)) == ['r1'] and calls == [(3, 1, 4)]
     own.per_rank = True
     assert list(d._epoch_samples({'samples': own}, 5, 0, 2)) == ['r0'] and calls[-1] == (5, 0, 2)
+    # sharding inside the loop: the distributed loop shuffles like DistributedSampler's defaults in every epoch, `shuffle=False` keeps the order,
+    # the single-process loop never shuffles
+    from torch.utils.data.distributed import DistributedSampler
+    seq = list('abcdefg')
+    for epoch in (0, 3):
+        want = [seq[i] for i in DistributedSampler(seq, num_replicas=2, rank=1)]
+        assert list(d._epoch_samples({'samples': seq}, epoch, 1, 2, True)) == want
+    assert list(d._epoch_samples({'samples': seq, 'shuffle': False}, 0, 1, 2, True)) == ['b', 'd', 'f', 'a']
+    assert list(d._epoch_samples({'samples': seq}, 0, 1, 2)) == ['b', 'd', 'f', 'a']
     every = lambda epoch: ['a', 'b', 'c']
     assert list(d._epoch_samples({'samples': every}, 0, 1, 2)) == ['b', 'b'] or list(d._epoch_samples({'samples': every}, 0, 1, 2)) == ['b', 'a']
 

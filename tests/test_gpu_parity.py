@@ -133,6 +133,56 @@ def test_place_one_batch_matches_reference_golden(golden_dir):
     assert np.all(np.abs(terms - d['parts']) <= 1e-4 * np.abs(d['parts']))
 
 
+@pytest.mark.parametrize('case', ['l1', 'sl1', 'sl1_b2', 'norm'])
+def test_other_pde_criteria_and_norm_branches_match_reference_golden(golden_dir, case):
+    """Fixture F12 -- the REFERENCE run on the branches its shipped config does not take: `pde_loss` = L1Loss / WeightSmoothL1Loss(beta) (the other two
+    criteria its loss builder offers, interface_physics.py:384) and inverse_norm's use_norm False / two-factor min_max branches (:238-243).
+    place_one_batch's scalar and the six terms at 1e-4, the gradient of every parameter against the oracle's (pinned to the same fixture on CPU)."""
+    from deepphysinet_amd.losses import builder_loss
+    d = np.load(os.path.join(golden_dir, 'f12_criteria_and_norm_branches.npz'))
+    inp = synthetic_inputs(256, tag='inter')
+    m = _model('bf16x2')
+    g = _gpu(inp)
+    lf = m.train_cfg['losses']['loss_factor']
+    crit_cfg = {'l1': dict(name='L1Loss'), 'sl1': dict(name='WeightSmoothL1Loss', beta=0.1), 'sl1_b2': dict(name='WeightSmoothL1Loss', beta=2.0)}.get(case)
+    crit = builder_loss(**crit_cfg) if crit_cfg else torch.nn.MSELoss()
+    norm_cfg = None
+    if case == 'norm':
+        norm_cfg = O.f12_norm_cfg()
+        for name, c in zip(('u10', 'v10', 'pres', 't2', 'q2', 'rio'), norm_cfg):
+            m.obs_norm_cfg[name].update(norm_type=c['norm_type'], norm_factor=c['norm_factor'], use_norm=c['use_norm'])
+    m.physics_net.zero_grad()
+    total = m.place_one_batch(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'], crit, lf, global_step=2,
+                              local_rank=0, device=_dev())
+    total.backward()
+    assert abs(float(total.detach()) - float(d[case + '.total'])) <= 1e-4 * abs(float(d[case + '.total'])), (float(total.detach()), float(d[case + '.total']))
+    # the config-file route (`builder_loss(**train_cfg.losses.pde_loss)`) gives the same kernel configuration as the module
+    if crit_cfg:
+        m.train_cfg['losses']['pde_loss'] = crit_cfg
+    terms = m.pde_loss_terms(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h']).detach().cpu().numpy()
+    assert np.all(np.abs(terms - d[case + '.parts']) <= 1e-4 * np.abs(d[case + '.parts'])), (terms, d[case + '.parts'])
+    # gradients: the oracle on the same branch (tests/test_oracle_golden.py holds it to F12's gradient norms)
+    st = O.make_state(requires_grad=True)
+    x, y, t = (inp[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
+    o_total = O.place_one_batch(st, x, y, t, inp['f'], inp['field_data'], inp['coord_data'], inp['forecast_h'], GEO,
+                                crit=O.pde_criterion(crit_cfg['name'], beta=crit_cfg.get('beta', 0.1)) if crit_cfg else None, norm_cfg=norm_cfg)
+    names = O.param_names(st)
+    ref = dict(zip(names, torch.autograd.grad(o_total, [st[n] for n in names])))
+    worst = 0.0
+    for name, p in m.physics_net.named_parameters():
+        if name.endswith('key_projection.bias'):
+            continue
+        r = ref[name]
+        diff = (p.grad.cpu() - r).abs()
+        # the slope of |r| and of SmoothL1 is discontinuous / steep in r: a residual within rounding of 0 (or of +-beta) moves one point's whole
+        # contribution, so the bound is on the tensor's L2 norm, with 5x on the single worst element (as for the mask flips of the plain-bf16 mode)
+        l2 = float(diff.pow(2).mean().sqrt() / (r.pow(2).mean().sqrt() + 1e-30))
+        err = float(diff.max() / (r.abs().max() + 1e-30))
+        worst = max(worst, err)
+        assert l2 < TOL['bf16x2']['grad'] and err < 5.0 * TOL['bf16x2']['grad'], (case, name, l2, err)
+    print('F12 %s: total %.6e (reference %.6e), worst gradient element error %.2e' % (case, float(total.detach()), float(d[case + '.total']), worst))
+
+
 def test_grid_node_points_longest_lead_match_reference_golden(golden_dir):
     """Fixture F10 -- the REFERENCE on 200 grid-node points (x, y exact multiples of the cell size, both domain corners: xi = 0 and 1)
     at the longest lead time (336 h): the six losses and their sum within the north-star 1e-4, fields and Jacobian within the mode's bars."""

@@ -154,8 +154,34 @@ def test_point_config_follows_the_config_file(model):
     model.with_clip = False
     assert list(model.point_config().physics().clip_on) == [0] * 6
     model.with_clip = True
-    with pytest.raises(NotImplementedError):
-        model._check_pde_criterion(torch.nn.L1Loss())
+    # the PDE criterion: the three the reference's loss builder offers (module or config dict) map onto the kernel's (kind, beta); anything else raises
+    from deepphysinet_amd import _lib as L
+    from deepphysinet_amd.losses import builder_loss
+    assert (ph.criterion, ph.beta) == (L.CRIT_MSE, 0.0)
+    assert model._check_pde_criterion(torch.nn.L1Loss()) == (L.CRIT_L1, 0.0)
+    assert model._check_pde_criterion(builder_loss('WeightSmoothL1Loss', beta=0.25)) == (L.CRIT_SMOOTH_L1, 0.25)
+    assert model._check_pde_criterion(dict(name='WeightSmoothL1Loss', beta=0.5)) == (L.CRIT_SMOOTH_L1, 0.5)
+    assert model.point_config(criterion=torch.nn.L1Loss()).physics().criterion == L.CRIT_L1
+    for bad in (torch.nn.MSELoss(reduction='sum'), torch.nn.HuberLoss(), dict(name='CrossEntropyLoss'), dict(name='MSELoss', reduction='sum')):
+        with pytest.raises(NotImplementedError):
+            model._check_pde_criterion(bad)
+    # inverse_norm's other branches as the kernel's affine map (:238-243): use_norm False = identity without clip, two-factor min_max
+    import copy
+    keep = copy.deepcopy(model.obs_norm_cfg)
+    try:
+        model.obs_norm_cfg['u10']['use_norm'] = False
+        model.obs_norm_cfg['q2']['use_norm'] = False
+        model.obs_norm_cfg['pres'].update(norm_type='min_max', norm_factor=[80000.0, 100000.0])
+        ph2 = model.point_config().physics()
+        assert (ph2.mean[0], ph2.std[0], ph2.mean[2], ph2.std[2]) == (0.0, 1.0, 80000.0, 20000.0)
+        assert list(ph2.clip_on) == [0, 0, 1, 1, 0, 1]
+        model.obs_norm_cfg['pres']['norm_factor'] = [80000.0, 100000.0, 3.0]
+        with pytest.raises(NotImplementedError):
+            model.point_config()
+    finally:
+        model.obs_norm_cfg.clear()
+        model.obs_norm_cfg.update(keep)
+        model.point_config()
 
 
 # ------------------------------------------------------------------------------------------------ round 2: loops, launcher, arena
