@@ -344,6 +344,7 @@ def main():
         # Adam moments, step counter as they were after the capture), restored OUTSIDE the timed bracket, and is checked to have stayed finite.
         snap = None
         blocks_finite = []
+        local_times = []                           # this rank's own clock per block (block_time returns the MAX over the ranks)
 
         def take_snapshot():
             return ([p_.detach().clone() for p_ in opt.params], opt._m_flat.clone(), opt._v_flat.clone(), opt.step_count.clone())
@@ -371,6 +372,13 @@ def main():
             if world > 1:
                 torch.distributed.barrier()
             dt_ = time.perf_counter() - t0
+            local_times.append(dt_)
+            if world > 1:
+                # every decision taken on a block time (leave the pre-warm loop, stop timing blocks) must be the SAME on all ranks -- a rank that
+                # runs one block more than its peers waits in a collective nobody else enters: the MAX over the ranks is what everybody sees
+                t_ = torch.tensor([dt_], dtype=torch.float64, device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu')
+                torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MAX)
+                dt_ = float(t_.item())
             if snap is not None:
                 blocks_finite.append(bool(torch.isfinite(opt._m_flat).all()) and bool(all(bool(torch.isfinite(p_).all()) for p_ in opt.params)))
             return dt_
@@ -458,13 +466,10 @@ def main():
         while len(times) < blocks and (len(times) < min(3, blocks) or sum(times) < 8.0):
             times.append(block_time(fn, steps))
         tt = torch.tensor([first] + times, dtype=torch.float64)
-        mine = sorted(times)[len(times) // 2] / steps * 1e3
+        own = local_times[-len(times):]            # the timed blocks as this rank's clock saw them
+        mine = sorted(own)[len(own) // 2] / steps * 1e3
         per_rank = None
-        if world > 1:
-            on = dev if torch.distributed.get_backend() == 'nccl' else 'cpu'
-            tt = tt.to(on)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            tt = tt.cpu()
+        if world > 1:                              # (first / times are already the MAX over the ranks, block by block)
             every = [None] * world
             torch.distributed.all_gather_object(every, mine)
             per_rank = {'ms_per_step': [round(v, 4) for v in every], 'min': min(every), 'max': max(every), 'slowest_rank': int(max(range(world), key=lambda r: every[r])),

@@ -675,7 +675,7 @@ def test_error_behaviour_matches_the_reference_convention():
     g = _gpu(synthetic_inputs(64, GEO.lon, GEO.lat, GEO.dx, GEO.dy))
     lf = m.train_cfg['losses']['loss_factor']
     with pytest.raises(NotImplementedError):
-        m.place_one_batch(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'], torch.nn.L1Loss(), lf, 0, 0, _dev())
+        m.place_one_batch(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'], torch.nn.HuberLoss(), lf, 0, 0, _dev())
     with pytest.raises(RuntimeError):                       # zero collocation points: the C ABI refuses n <= 0
         e = torch.empty(0, device=_dev())
         m.place_one_batch(e, e, e, e, g['field_data'], torch.empty(0, 6, device=_dev()), g['forecast_h'], torch.nn.MSELoss(), lf, 0, 0, _dev())

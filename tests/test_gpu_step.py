@@ -608,7 +608,7 @@ smp = CollocationSampler(SamplerConfig(), cube, labels, seed=11)
 field = synthetic_inputs(1)['field_data'].to(dev)
 drawn = []
 
-class Samples:                                   # THREE samples for two ranks: rank 0 takes 0 and 2, rank 1 takes 1 and (wrapped) 0
+class Samples:                                   # THREE samples for two ranks, in DistributedSampler's seed-0 permutation: padded with its first sample
     def __len__(self): return 3
     def __getitem__(self, i):
         if not 0 <= i < 3: raise IndexError(i)
@@ -617,7 +617,9 @@ class Samples:                                   # THREE samples for two ranks: 
         return smp.training_batch(field * (1.0 + 0.1 * i), fh, n_margin=1024, n_inter=256)
 out = m.run_train_interface_dist(samples=Samples(), pde_start_step=0, backend='gloo', device=0)
 assert out['global_step'] == 2, out['global_step']
-assert drawn == ([0, 2] if rank == 0 else [1, 0]), drawn
+from torch.utils.data.distributed import DistributedSampler
+want = list(DistributedSampler(list(range(3)), num_replicas=2, rank=rank))     # the reference's sampler (:936): shuffle=True, seed 0, no set_epoch
+assert drawn == want and len(want) == 2, (drawn, want)
 np.savez({out!r} % rank, **{{k: v.detach().cpu().numpy() for k, v in m.physics_net.state_dict().items()}})
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
