@@ -18,9 +18,19 @@ Default precision: bf16x2 (hi+lo split bf16 MFMA operands), the mode whose PDE l
 (--prec bf16) are reported under `other_precision_mode`.
 --leads B: BASELINE configs[2], B field samples x 37 265 points in one step (place_lead_batch).
 
-Prints ONE JSON line on rank 0: the contract keys, `roofline` (dpn_fwd_kernel, MFMA-bound; duration from a HIP event pair around every
-launch inside a pre-queued replay of the point path), `roofline_hbm_kernel` (dpn_wgrad_kernel), `pde_losses` (the six scalars of the
-workload), `other_precision_mode`, `cpu_baseline` (the oracle on the host cores, reference schedule + shared-derivative variant).
+Protocol: `first_block_ms` (the `warmup` + `steps` replays straight after the capture), a pre-warm to a steady clock, then `--blocks` (10) blocks of
+`steps` replays, each bracketed by barrier + synchronize; `ms_per_step` is the median block, every block time the MAX over the ranks.  Lead batches
+start every block from a restored state and check that it stayed finite (a draw of the fields that hits the reference formula's NaN is discarded).
+N > 1 over RCCL: the measurement runs as segment graphs + host-issued all-reduces; at the END the one-graph form (all-reduces captured) is tried
+and reported if faster -- a stall of that trial keeps the finished line (exit code 0).  Environment: DPN_BENCH_WATCHDOG_S (300), DPN_PG_TIMEOUT_S (600),
+DPN_BENCH_TRIAL_WATCHDOG_S (90), DPN_BENCH_TRY_FORMS (1 when N > 1), DPN_BENCH_CAPTURE_COLLECTIVES=0|1 (pin the form), DPN_BENCH_RCCL_ONE_RANK=1 /
+DPN_BENCH_ONE_DEVICE=1 + DPN_BENCH_BACKEND=gloo (exercise the N > 1 code path on a one-GPU box), DPN_BENCH_SPLIT_STEP=1.
+
+Prints ONE JSON line on rank 0: the contract keys, `roofline` (the fused forward + Jacobian kernel, MFMA-bound; duration from device-clock stamp
+nodes around its launch INSIDE the replayed step graph, `roofline.in_step`; `kernel_ms_eager_pair` = a HIP event pair around eager launches),
+`roofline_hbm_kernel` (dpn_wgrad_kernel, backward stage 1), `pde_losses` (the six scalars of the workload), `switches` (every DPN_* variable and
+non-default frozen switch), `collective` (devices, buckets, per-rank times, exposed all-reduce time, step-form trial), `other_precision_mode`,
+`lead_batch_probe` (8 fields in one step), `cpu_baseline` (the oracle on the host cores, reference schedule + shared-derivative variant).
 """
 import argparse
 import json
@@ -408,38 +418,6 @@ def main():
                 graphs = None
                 rec['capture_error'] = rec['capture_error'] or 'another rank failed to capture'
         fn = eager if graphs is None else replayer(graphs)
-        # N > 1 over RCCL: pick between "segment graphs + host-issued collectives" and "one graph with the collectives captured" by a 20-replay
-        # self-measurement (the two forms swap places from box to box on a one-rank group and nobody has timed them on
-        # xGMI).  Every failure on any rank keeps the segment form.  DPN_BENCH_CAPTURE_COLLECTIVES=0/1 pins the choice.
-        if (graphs is not None and split_step and not one_graph_collectives and os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') is None
-                and sync is not None and torch.distributed.get_backend() == 'nccl' and (world > 1 or os.environ.get('DPN_BENCH_TRY_FORMS') == '1')):
-            trial = {'segments_ms': None, 'one_graph_ms': None, 'error': None}
-            one = None
-            try:
-                one = capture_one_graph()
-            except Exception as e:                 # noqa
-                trial['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
-                torch.cuda.synchronize()
-            if all_agree(one is not None):
-                f2 = replayer(one)
-                for f_ in (fn, f2):
-                    for _ in range(5):
-                        f_()
-                t_seg, t_one = block_time(fn, 20), block_time(f2, 20)
-                both = torch.tensor([t_seg, t_one], dtype=torch.float64, device=dev)
-                if world > 1:
-                    torch.distributed.all_reduce(both, op=torch.distributed.ReduceOp.MAX)
-                t_seg, t_one = float(both[0]), float(both[1])
-                trial['segments_ms'], trial['one_graph_ms'] = t_seg / 20 * 1e3, t_one / 20 * 1e3
-                if t_one < 0.99 * t_seg:
-                    graphs, fn = one, f2
-                    rec['step_form'] = 'one graph, collectives captured (chosen by the start-up trial)'
-                else:
-                    rec['step_form'] += ' (kept by the start-up trial)'
-            elif trial['error'] is None:
-                trial['error'] = 'another rank failed to capture the collectives'
-            rec['step_form_trial'] = trial
-
         if n_leads > 1:
             torch.cuda.synchronize()
             snap = take_snapshot()
@@ -479,7 +457,8 @@ def main():
         rec.update({'model': m, 'optimizer': opt, 'dt': med, 'graphed': graphs is not None, 'fn': fn, 'first_block_s': first, 'block_s': times,
                     'prewarm_s': prewarm_s, 'prewarm_replays': prewarm_replays, 'per_rank': per_rank, 'staged': staged, 'graphs': graphs,
                     'n_reduce': n_reduce, 'replayer': replayer, 'blocks_finite': blocks_finite if snap is not None else None,
-                    'recapture': (lambda: capture_one_graph() if (split_step and len(graphs) == 1) else capture_segments()) if graphs is not None else None})
+                    'recapture': (lambda: capture_one_graph() if (split_step and len(graphs) == 1) else capture_segments()) if graphs is not None else None,
+                    'capture_one_graph': capture_one_graph, 'block_time': block_time, 'all_agree': all_agree, 'local_times': local_times, 'sync': sync})
         return rec
 
     def in_step_kernel_times(rec, reps=40):
@@ -841,12 +820,105 @@ def main():
         except RuntimeError as e:
             out['encoder_weights_in_range'] = False
             out['warning'] = (out.get('warning', '') + ' ' + str(e)).strip()
+
+    # ---- N > 1 over RCCL: "segment graphs + host-issued collectives" (measured above: the form that needs nothing of RCCL but ordinary stream-ordered
+    # collectives) against "ONE graph with the collectives captured" (the two swap places from box to box on a one-rank group and
+    # nobody has timed them on xGMI).  Tried LAST, with the finished line of the segment form in hand: a capture error keeps the segment form; a STALL of
+    # the captured collectives (RCCL kernels replayed from a graph across N processes have never run here) makes every rank's watchdog print what it
+    # has -- rank 0 the finished line, `step_form_trial.error` saying where it stalled -- and end the process with exit code 0.  If the one-graph form is
+    # more than 1 % faster over 20 replays, the ten blocks are timed again in it and the line reports it (the segment form's numbers stay in
+    # `collective.step_form_trial`).  DPN_BENCH_CAPTURE_COLLECTIVES=0/1 pins the form, DPN_BENCH_TRY_FORMS=0 skips the trial.
+    stash = {'line': None, 'printed': False}
+    tdog = None
+    want_trial = (rec.get('graphed') and split_step and not one_graph_collectives and os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') is None
+                  and rec.get('sync') is not None and torch.distributed.get_backend() == 'nccl' and rec.get('graphs') is not None and len(rec['graphs']) > 1
+                  and os.environ.get('DPN_BENCH_TRY_FORMS', '1' if world > 1 else '0') == '1')
+    if want_trial:
+        trial = {'segments_ms': None, 'one_graph_ms': None, 'error': None, 'segment_form_result': None}
+        phase = ['start']
+        torch.distributed.barrier()                # rank 0 comes from the roofline measurements: the trial's clock starts when everybody is here
+        if rank == 0:
+            trial['error'] = 'stalled'             # what the stashed line says if it is ever printed
+            coll['step_form_trial'] = trial
+            stash['line'] = json.dumps(out)
+            trial['error'] = None
+
+        def on_stall(msg):
+            if rank == 0 and not stash['printed']:
+                line = json.loads(stash['line'])
+                line['collective']['step_form_trial']['error'] = 'stalled in: %s -- the segment form\'s line is reported' % phase[0]
+                print(json.dumps(line), flush=True)
+            print('[bench] rank %d: the one-graph trial stalled (%s); the segment form\'s result stands' % (rank, phase[0]), file=sys.stderr, flush=True)
+            os._exit(0)
+        tdog = D.Watchdog(float(os.environ.get('DPN_BENCH_TRIAL_WATCHDOG_S', '90')), rank, sync=rec['sync'], on_stall=on_stall)
+        fn_seg, block_time, all_agree = rec['fn'], rec['block_time'], rec['all_agree']
+        one = None
+        try:
+            phase[0] = 'capture of the step with its all-reduces'
+            tdog.beat(phase[0])
+            if os.environ.get('DPN_BENCH_TRIAL_TEST_STALL') == 'capture':
+                time.sleep(1e6)
+            one = rec['capture_one_graph']()
+        except Exception as e:                     # noqa
+            trial['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+            torch.cuda.synchronize()
+        phase[0] = 'agreement of the ranks on the capture'
+        tdog.beat(phase[0])
+        if all_agree(one is not None):
+            f2 = rec['replayer'](one)
+            phase[0] = 'first replays of the one-graph form'
+            tdog.beat(phase[0])
+            if os.environ.get('DPN_BENCH_TRIAL_TEST_STALL') == 'replay':
+                time.sleep(1e6)
+            for f_ in (fn_seg, f2):
+                for _ in range(5):
+                    f_()
+            torch.cuda.synchronize()
+            phase[0] = 'timing 20 replays of each form'
+            tdog.beat(phase[0])
+            t_seg, t_one = block_time(fn_seg, 20), block_time(f2, 20)
+            trial['segments_ms'], trial['one_graph_ms'] = t_seg / 20 * 1e3, t_one / 20 * 1e3
+            if t_one < 0.99 * t_seg:
+                phase[0] = 'timing the blocks in the one-graph form'
+                n0 = len(rec['local_times'])
+                times2 = []
+                for _ in range(max(1, len(rec['block_s']))):
+                    tdog.beat(phase[0])
+                    times2.append(block_time(f2, args.steps))
+                med2 = sorted(times2)[len(times2) // 2]
+                own = rec['local_times'][n0:]
+                every = [None] * world
+                torch.distributed.all_gather_object(every, sorted(own)[len(own) // 2] / args.steps * 1e3)
+                if rank == 0:
+                    trial['segment_form_result'] = {'ms_per_step': out['ms_per_step'], 'value': out['value'], 'block_ms_per_step': out['block_ms_per_step']}
+                    scale = (dt / args.steps) / (med2 / args.steps)
+                    out['ms_per_step'] = med2 / args.steps * 1e3
+                    out['value'] = args.points * args.leads * world * args.steps / med2
+                    out['timed_seconds'], out['timed_blocks'] = sum(times2), len(times2)
+                    out['block_ms_per_step'] = [round(b_ / args.steps * 1e3, 5) for b_ in times2]
+                    out['algorithmic_tflops_step'] = out['value'] * ALG_FLOP_STEP / 1e12
+                    out['roofline']['step_frac_of_peak'] *= scale
+                    out['config'].update(step_form='one graph, collectives captured (chosen by the trial at the end of the run)', step_segments=1, collectives_in_graph=True)
+                    coll['per_rank'] = {'ms_per_step': [round(v, 4) for v in every], 'min': min(every), 'max': max(every),
+                                        'slowest_rank': int(max(range(world), key=lambda r: every[r])), 'fastest_rank': int(min(range(world), key=lambda r: every[r]))}
+                    coll.pop('exposed_us', None)
+                    coll.pop('exposed_us_note', None)
+            elif rank == 0:
+                out['config']['step_form'] += ' (kept by the trial at the end of the run)'
+        elif trial['error'] is None:
+            trial['error'] = 'another rank failed to capture the collectives'
+        phase[0] = 'the final barrier'
+        tdog.beat(phase[0])
+    if rank == 0:
         print(json.dumps(out), flush=True)
+        stash['printed'] = True
         if not out['encoder_weights_in_range'] and args.leads == 1:
             raise SystemExit('bench.py: ' + out['warning'])          # the line above is printed for the record; the run is not a measurement
     if world > 1 or one_rank_rccl:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if tdog is not None:
+        tdog.stop()
 
 
 if __name__ == '__main__':

@@ -81,12 +81,13 @@ class Watchdog:
     the PROCESS with exit code 13 -- the launcher (torch.distributed.run) then tears the other ranks down.  It never re-executes anything
     (a process that has touched the GPU must not exec on this platform); it only exits."""
 
-    def __init__(self, timeout_s=300.0, rank=0, sync=None, out=None):
+    def __init__(self, timeout_s=300.0, rank=0, sync=None, out=None, on_stall=None):
         import sys
         import threading
         import time
         self.timeout_s, self.rank, self.sync = float(timeout_s), rank, sync
         self.out = out or sys.stderr
+        self.on_stall = on_stall                   # callable(message): replaces the exit with code 13 (it is expected to end the process itself)
         self._last, self._what, self._stop = time.monotonic(), 'start', threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
@@ -104,10 +105,13 @@ class Watchdog:
             idle = time.monotonic() - self._last
             if idle > self.timeout_s:
                 bucket = getattr(self.sync, 'last_queued', None)
-                print('[deepphysinet_amd.distributed] rank %d made no progress for %.0f s (last: %s; last all-reduce queued: %s) -- a collective '
-                      'is not completing; exiting with code 13' % (self.rank, idle, self._what,
-                                                                    'buckets %s of the flat gradient buffer' % (bucket,) if bucket else 'none'),
-                      file=self.out, flush=True)
+                msg = ('[deepphysinet_amd.distributed] rank %d made no progress for %.0f s (last: %s; last all-reduce queued: %s) -- a collective '
+                       'is not completing' % (self.rank, idle, self._what, 'buckets %s of the flat gradient buffer' % (bucket,) if bucket else 'none'))
+                if self.on_stall is not None:
+                    print(msg, file=self.out, flush=True)
+                    self.on_stall(msg)
+                    return
+                print(msg + '; exiting with code 13', file=self.out, flush=True)
                 os._exit(13)
 
 

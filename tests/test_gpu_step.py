@@ -360,6 +360,34 @@ def test_bench_step_with_rccl_collectives_on_one_rank():
         assert ins['bwd_us'] > 0 and ins['wgrad_us'] > 0
 
 
+def test_bench_trial_of_the_one_graph_form_keeps_the_segment_forms_line_when_it_stalls():
+    """`bench.py --gpus N` over RCCL tries the one-graph form (all-reduces captured) at the END of the run, with the finished line of the segment form in
+    hand.  A stall of the captured collectives -- simulated here: DPN_BENCH_TRIAL_TEST_STALL=replay parks the rank in front of the first replay -- must
+    end with exit code 0 and the segment form's line, saying where it stalled; without the stall the trial reports both forms' times."""
+    env = dict(os.environ, DPN_BENCH_RCCL_ONE_RANK='1', DPN_BENCH_TRY_FORMS='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'DPN_BENCH_BACKEND', 'DPN_BENCH_ONE_DEVICE', 'DPN_BENCH_CAPTURE_COLLECTIVES'):
+        env.pop(k, None)
+    args = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--points', '4096', '--no-cpu-baseline', '--no-alt',
+            '--no-prewarm', '--blocks', '2', '--no-lead-probe', '--no-power']
+    r = subprocess.run(args, env=dict(env, MASTER_PORT=str(_free_port()), DPN_BENCH_TRIAL_TEST_STALL='replay', DPN_BENCH_TRIAL_WATCHDOG_S='5'),
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out['config']['step_segments'] == 4 and out['value'] > 0
+    assert out['collective']['step_form_trial']['error'].startswith('stalled in: first replays of the one-graph form'), out['collective']['step_form_trial']
+    assert 'the one-graph trial stalled' in r.stderr
+    r = subprocess.run(args, env=dict(env, MASTER_PORT=str(_free_port())), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    t = out['collective']['step_form_trial']
+    assert t['error'] is None and t['segments_ms'] > 0 and t['one_graph_ms'] > 0, t
+    assert out['config']['step_segments'] == (1 if t['one_graph_ms'] < 0.99 * t['segments_ms'] else 4)
+    if out['config']['step_segments'] == 1:
+        assert t['segment_form_result']['ms_per_step'] > 0 and out['config']['collectives_in_graph']
+
+
 def test_run_train_interface_drives_steps_and_resumes(tmp_path):
     """The reference's train.py calls run_train_interface(checkpoint_path=..., log_path=...) (train.py:47): three steps through the loop
     (data loss only, then PDE losses on), an epoch-end checkpoint + schedule step, and a resume from physics_latest.pth."""

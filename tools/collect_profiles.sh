@@ -2,7 +2,7 @@
 # box's missing-file notice (amdgpu.ids); a file that is absent is reported, not silently skipped.
 S=gpurun_out/r5; D=profiles
 for f in bench_bf16x2.json bench_bf16x2_driver_protocol.json bench_bf16.json bench_cfg2_61leads_bf16x2.json bench_cfg2_61leads_bf16.json bench_cfg4_encoder_fp8_mx.json \
-         bench_bf16x2_rccl_one_rank.json bench_bf16x2_rccl_one_rank_one_graph.json bench_bf16x2_rccl_one_rank_startup_trial.json \
+         bench_bf16x2_rccl_one_rank.json bench_bf16x2_rccl_one_rank_one_graph.json bench_bf16x2_rccl_one_rank_form_trial.json bench_bf16x2_rccl_one_rank_trial_stall_fallback.json \
          bench_2ranks_one_device_gloo.json bench_2ranks_one_device_gloo_3leads.json bench_8ranks_one_device_gloo_4096pts.json \
          fwd_tiles_kernel_timeline.txt bwd_tiles_timeline_full.txt encoder_vs_fp64.txt cfg2_61leads_kernel_stats_bf16x2.txt phase_times_bf16x2.txt phase_times_bf16.txt \
          reference_shaped_step_bf16x2.json reference_shaped_step_bf16.json kernel_trace_stats_bench_bf16x2.txt kernel_trace_stats_bench_bf16.txt \

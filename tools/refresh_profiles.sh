@@ -17,7 +17,8 @@ timeout 600 python bench.py --leads 61 --steps 10 --warmup 2 --prec bf16 --no-cp
 timeout 600 python bench.py --encoder-fp8 --no-cpu-baseline --no-alt --no-power --no-lead-probe > $R/bench_cfg4_encoder_fp8_mx.json 2> $R/bench_cfg4.err
 DPN_BENCH_RCCL_ONE_RANK=1 DPN_BENCH_CAPTURE_COLLECTIVES=0 MASTER_PORT=29581 timeout 600 python bench.py --steps 200 --no-cpu-baseline --no-alt --no-power --no-lead-probe 2> $R/bench_rccl1.err | grep '^{' > $R/bench_bf16x2_rccl_one_rank.json
 DPN_BENCH_RCCL_ONE_RANK=1 DPN_BENCH_CAPTURE_COLLECTIVES=1 MASTER_PORT=29582 timeout 600 python bench.py --steps 200 --no-cpu-baseline --no-alt --no-power --no-lead-probe 2>> $R/bench_rccl1.err | grep '^{' > $R/bench_bf16x2_rccl_one_rank_one_graph.json
-DPN_BENCH_RCCL_ONE_RANK=1 DPN_BENCH_TRY_FORMS=1 MASTER_PORT=29583 timeout 600 python bench.py --steps 200 --no-cpu-baseline --no-alt --no-power --no-lead-probe 2>> $R/bench_rccl1.err | grep '^{' > $R/bench_bf16x2_rccl_one_rank_startup_trial.json
+DPN_BENCH_RCCL_ONE_RANK=1 DPN_BENCH_TRY_FORMS=1 MASTER_PORT=29583 timeout 600 python bench.py --steps 200 --no-cpu-baseline --no-alt --no-power --no-lead-probe 2>> $R/bench_rccl1.err | grep '^{' > $R/bench_bf16x2_rccl_one_rank_form_trial.json
+DPN_BENCH_RCCL_ONE_RANK=1 DPN_BENCH_TRY_FORMS=1 DPN_BENCH_TRIAL_TEST_STALL=replay DPN_BENCH_TRIAL_WATCHDOG_S=5 MASTER_PORT=29584 timeout 600 python bench.py --steps 50 --no-cpu-baseline --no-alt --no-power --no-lead-probe 2>> $R/bench_rccl1.err | grep '^{' > $R/bench_bf16x2_rccl_one_rank_trial_stall_fallback.json
 DPN_BENCH_ONE_DEVICE=1 DPN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --no-alt --no-power --no-lead-probe 2> $R/bench_2ranks.err | grep '^{' > $R/bench_2ranks_one_device_gloo.json
 DPN_BENCH_ONE_DEVICE=1 DPN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --leads 3 --steps 10 --warmup 2 --no-cpu-baseline --no-alt --no-power 2>> $R/bench_2ranks.err | grep '^{' > $R/bench_2ranks_one_device_gloo_3leads.json
 DPN_BENCH_ONE_DEVICE=1 DPN_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --points 4096 --steps 10 --warmup 2 --blocks 3 --no-cpu-baseline --no-alt --no-power --no-lead-probe 2>> $R/bench_2ranks.err | grep '^{' > $R/bench_8ranks_one_device_gloo_4096pts.json

@@ -19,6 +19,9 @@ steps_ = [(a, b) for a, b in steps_ if not any('dpn_clock_stamp' in r[2] for r i
 from collections import Counter
 common = Counter(b - a for a, b in steps_).most_common(1)[0][0]
 steps_ = [(a, b) for a, b in steps_ if b - a == common]
+# ... and not one that straddles a block boundary of the bench (barrier + synchronize: milliseconds of idle host time inside the "step")
+spans = [rows[b - 1][1] - rows[a][0] for a, b in steps_]
+steps_ = [ab for ab, sp in zip(steps_, spans) if sp <= 1.1 * min(spans)]
 a_, b_ = steps_[-back]
 step = rows[a_:b_]
 t0 = step[0][0]
