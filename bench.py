@@ -21,9 +21,9 @@ Default precision: bf16x2 (hi+lo split bf16 MFMA operands), the mode whose PDE l
 Protocol: `first_block_ms` (the `warmup` + `steps` replays straight after the capture), a pre-warm to a steady clock, then `--blocks` (10) blocks of
 `steps` replays, each bracketed by barrier + synchronize; `ms_per_step` is the median block, every block time the MAX over the ranks.  Lead batches
 start every block from a restored state and check that it stayed finite (a draw of the fields that hits the reference formula's NaN is discarded).
-N > 1 over RCCL: the measurement runs as segment graphs + host-issued all-reduces; at the END the one-graph form (all-reduces captured) is tried
-and reported if faster -- a stall of that trial keeps the finished line (exit code 0).  Environment: DPN_BENCH_WATCHDOG_S (300), DPN_PG_TIMEOUT_S (600),
-DPN_BENCH_TRIAL_WATCHDOG_S (90), DPN_BENCH_TRY_FORMS (1 when N > 1), DPN_BENCH_CAPTURE_COLLECTIVES=0|1 (pin the form), DPN_BENCH_RCCL_ONE_RANK=1 /
+N > 1 over RCCL: the measurement runs as segment graphs + host-issued all-reduces; with DPN_BENCH_TRY_FORMS=1 the one-graph form (all-reduces
+captured) is tried at the END and reported if faster -- a stall of that trial keeps the finished line (exit code 0).  Environment: DPN_BENCH_WATCHDOG_S (300), DPN_PG_TIMEOUT_S (600),
+DPN_BENCH_TRIAL_WATCHDOG_S (90), DPN_BENCH_TRY_FORMS=1 (the end-of-run trial: opt-in), DPN_BENCH_CAPTURE_COLLECTIVES=0|1 (pin the form), DPN_BENCH_RCCL_ONE_RANK=1 /
 DPN_BENCH_ONE_DEVICE=1 + DPN_BENCH_BACKEND=gloo (exercise the N > 1 code path on a one-GPU box), DPN_BENCH_SPLIT_STEP=1.
 
 Prints ONE JSON line on rank 0: the contract keys, `roofline` (the fused forward + Jacobian kernel, MFMA-bound; duration from device-clock stamp
@@ -305,6 +305,7 @@ def main():
             # the whole step INCLUDING its bucket all-reduces as one hipGraph (RCCL kernels are capturable; ProcessGroupNCCL forks its
             # communication stream off the capture stream, so each all-reduce becomes a parallel branch behind its segment and joins in
             # front of the optimiser): one replay per step instead of four replays + three host-issued collectives
+            D.quiesce_for_capture()           # the process group's watchdog must have reaped every eager collective before its stream is captured
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 for i, seg in enumerate(segments):
@@ -827,12 +828,14 @@ def main():
     # the captured collectives (RCCL kernels replayed from a graph across N processes have never run here) makes every rank's watchdog print what it
     # has -- rank 0 the finished line, `step_form_trial.error` saying where it stalled -- and end the process with exit code 0.  If the one-graph form is
     # more than 1 % faster over 20 replays, the ten blocks are timed again in it and the line reports it (the segment form's numbers stay in
-    # `collective.step_form_trial`).  DPN_BENCH_CAPTURE_COLLECTIVES=0/1 pins the form, DPN_BENCH_TRY_FORMS=0 skips the trial.
+    # `collective.step_form_trial`).  DPN_BENCH_CAPTURE_COLLECTIVES=0/1 pins the form.  OPT-IN (DPN_BENCH_TRY_FORMS=1) since the end of round 5: a capture that
+    # contains collectives can take the whole process down from ProcessGroupNCCL's watchdog thread (distributed.quiesce_for_capture: found, reproduced and
+    # worked around here), and nothing of that kind may stand between an 8-GPU run and its line.
     stash = {'line': None, 'printed': False}
     tdog = None
     want_trial = (rec.get('graphed') and split_step and not one_graph_collectives and os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') is None
                   and rec.get('sync') is not None and torch.distributed.get_backend() == 'nccl' and rec.get('graphs') is not None and len(rec['graphs']) > 1
-                  and os.environ.get('DPN_BENCH_TRY_FORMS', '1' if world > 1 else '0') == '1')
+                  and os.environ.get('DPN_BENCH_TRY_FORMS', '0') == '1')
     if want_trial:
         trial = {'segments_ms': None, 'one_graph_ms': None, 'error': None, 'segment_form_result': None}
         phase = ['start']

@@ -75,6 +75,20 @@ def _all_reduce_mean(flat, world, group, async_op):
     return None
 
 
+def quiesce_for_capture(seconds=0.5):
+    """Call before a stream capture that will CONTAIN collectives of an RCCL ('nccl') group.  ProcessGroupNCCL's watchdog thread polls the end events of
+    the collectives it has not reaped yet (every ~100 ms); those events live on the group's RCCL stream, and once that stream is part of a capture HIP
+    refuses to query them ("operation not permitted on an event last recorded in a capturing stream") -- the watchdog thread then terminates the whole
+    process (exit code 134).  Reproduced 3 / 3 with `tools/pg_capture_probe.py 0`, 0 / 3 with a 0.5-s pause (profiles/round5_pg_watchdog_capture_race.txt).
+    So: finish the eager collectives, then give the watchdog a few polls to drop them from its list.  (Collectives issued INSIDE the capture are never put
+    on that list.)"""
+    import time
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'):
+        return
+    torch.cuda.synchronize()
+    time.sleep(float(seconds))
+
+
 class Watchdog:
     """Host-side progress watchdog of a multi-rank loop: `beat(what)` after every unit of progress; when no beat arrives for `timeout_s`
     the thread prints which rank is stuck, in what (the label of the last beat and the last bucket a GradientAllReduce queued), and ends
