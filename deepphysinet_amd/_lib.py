@@ -119,8 +119,6 @@ EXPORTS = {
     'dpn_residual': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(DpnGeometry), POINTER(DpnPhysics), c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p]),
     'dpn_residual_finish': (c_int, [c_void_p, c_int64, POINTER(DpnPhysics), c_void_p, c_void_p]),
-    'dpn_residual_losses': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(DpnGeometry), POINTER(DpnPhysics), c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_bwd_points': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_bwd_points_scaled': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,

@@ -1043,8 +1043,6 @@ struct ResArgs {
     const float *gl, *gtot;
     double* loss_sums;
     float *g_out, *g_jxi;
-    unsigned* ticket;        // dpn_residual_losses: the block that finishes LAST adds the block rows up (what dpn_residual_finish does in a launch of its
-    float* losses;           // own) and writes losses[7]; *ticket is zero before the launch and zero again after it
 };
 
 // the criterion's per-element value rho(r) and slope rho'(r) (DpnPhysics.criterion): every criterion the reference's builder offers is a function of
@@ -1122,34 +1120,6 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
         if (threadIdx.x < 6)
             a.loss_sums[(int64_t)blockIdx.x * 6 + threadIdx.x] =
                 ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-        if (a.ticket) {
-            // the finish stage without a launch of its own (4.5 us on the step's chain): every block publishes its row and takes a ticket; the block
-            // that draws the last one adds the rows in dpn_residual_finish's order -- lane l the rows l, l + 64, ..., then the xor tree -- so the six
-            // losses carry the same bits whichever block that is
-            __shared__ int s_last;
-            __shared__ float s_l[6];
-            __threadfence();
-            __syncthreads();
-            if (threadIdx.x == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
-            __syncthreads();
-            if (s_last) {
-                __threadfence();
-                const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-                const int64_t nblk = gridDim.x;
-                for (int e = wv; e < 6; e += 4) {
-                    double s = 0.0;
-                    for (int64_t b = lane; b < nblk; b += 64) s += a.loss_sums[b * 6 + e];
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-                    if (lane == 0) { s_l[e] = (float)((double)(float)(s / (double)a.n) * (double)a.ph.factor[e]); a.losses[e] = s_l[e]; }
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    a.losses[6] = ((((s_l[0] + s_l[1]) + s_l[3]) + s_l[2]) + s_l[4]) + s_l[5];
-                    *a.ticket = 0u;
-                }
-            }
-        }
     }
     if (!a.g_out || !valid) return;
     float g[6];
@@ -2365,7 +2335,7 @@ DEV int adam_find(const Table& t, int blk) {
 template <class Table>
 __global__ __launch_bounds__(256) void dpn_gradnorm_kernel(Table t, double* partial, int* step, int bump_step) {
     // one fp64 partial per block (no atomics: 2.7k serialised fp64 atomics on one address cost more than reading the gradients);
-    // dpn_adam_kernel adds them in a fixed order (every block for itself) -> the clip coefficient is run-to-run deterministic
+    // dpn_gradnorm_reduce_kernel adds them in a fixed order -> the clip coefficient is run-to-run deterministic
     if (bump_step && blockIdx.x == 0 && threadIdx.x == 0) *step += 1;       // device-side step counter: graph replays advance it
     const int ti = adam_find(t, blockIdx.x);
     const int base = (blockIdx.x - t.chunk_start[ti]) * kAdamChunk;
@@ -2390,30 +2360,25 @@ __global__ __launch_bounds__(256) void dpn_gradnorm_kernel(Table t, double* part
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-template <class Table>
-__global__ __launch_bounds__(256) void dpn_adam_kernel(Table t, double* sumsq, const double* partial, int n_partial, const int* step, float lr, float b1,
-                                                       float b2, float eps, float wd, float max_norm, float* out_norm, const float* hyper) {
-    // the sum of the gradient-norm partials, by EVERY block for itself in one fixed order (a launch of its own, dpn_gradnorm_reduce_kernel, until
-    // round 5: 4.6 us on the step's chain for 21 KB of L2-resident doubles): lane-strided sums, xor tree, the four waves in order -- the same bits in
-    // every block and in every run
-    double total_sq;
-    {
-        double d = 0.0;
-        for (int i = threadIdx.x; i < n_partial; i += 256) d += partial[i];
+__global__ __launch_bounds__(256) void dpn_gradnorm_reduce_kernel(const double* partial, int n, double* sumsq) {
+    double d = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) d += partial[i];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        __shared__ double red[4];
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
-        __syncthreads();
-        total_sq = (red[0] + red[1]) + (red[2] + red[3]);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *sumsq = total_sq;           // scratch[0] keeps its meaning for callers that read it
-    }
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) *sumsq = (red[0] + red[1]) + (red[2] + red[3]);
+}
+template <class Table>
+__global__ __launch_bounds__(256) void dpn_adam_kernel(Table t, const double* sumsq, const int* step, float lr, float b1, float b2, float eps,
+                                                       float wd, float max_norm, float* out_norm, const float* hyper) {
     // hyper (optional, device): [lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale] read at run time, so that a step captured in
     // a hipGraph follows a learning-rate schedule (a by-value lr is frozen into the graph); grad_scale multiplies every gradient
     // before the norm and the update (1 / world_size after a SUM all-reduce)
     float gscale = 1.f;
     if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; max_norm = hyper[5]; gscale = hyper[6]; }
-    const float total = (float)sqrt(total_sq) * gscale;
+    const float total = (float)sqrt(*sumsq) * gscale;
     if (out_norm && blockIdx.x == 0 && threadIdx.x == 0) *out_norm = total;
     const float coef = fminf(max_norm / (total + 1e-6f), 1.0f) * gscale;    // clip_grad_norm_'s clamp(max_norm / (norm + 1e-6), max=1)
     const float st = (float)(*step);
@@ -2661,16 +2626,7 @@ int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t
                  const float* gl, const float* gtot, double* loss_sums, float* g_out, float* g_jxi, void* stream) {
     if (!out_n || !jac_n || !f || !geo || !phys || n <= 0 || (g_out && !g_jxi)) return -1;
     if (phys->criterion < DPN_CRIT_MSE || phys->criterion > DPN_CRIT_SMOOTH_L1 || (phys->criterion == DPN_CRIT_SMOOTH_L1 && !(phys->beta > 0.f))) return -1;
-    ResArgs a{out_n, jac_n, f, n, *geo, *phys, gl, gtot, loss_sums, g_out, g_jxi, nullptr, nullptr};
-    hipLaunchKernelGGL(dpn_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
-    return ck(hipGetLastError());
-}
-
-int dpn_residual_losses(const float* out_n, const float* jac_n, const float* f, int64_t n, const DpnGeometry* geo, const DpnPhysics* phys,
-                        const float* gl, const float* gtot, double* loss_sums, unsigned* ticket, float* losses, float* g_out, float* g_jxi, void* stream) {
-    if (!out_n || !jac_n || !f || !geo || !phys || n <= 0 || (g_out && !g_jxi) || !loss_sums || !ticket || !losses) return -1;
-    if (phys->criterion < DPN_CRIT_MSE || phys->criterion > DPN_CRIT_SMOOTH_L1 || (phys->criterion == DPN_CRIT_SMOOTH_L1 && !(phys->beta > 0.f))) return -1;
-    ResArgs a{out_n, jac_n, f, n, *geo, *phys, gl, gtot, loss_sums, g_out, g_jxi, ticket, losses};
+    ResArgs a{out_n, jac_n, f, n, *geo, *phys, gl, gtot, loss_sums, g_out, g_jxi};
     hipLaunchKernelGGL(dpn_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return ck(hipGetLastError());
 }
@@ -2898,7 +2854,6 @@ int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     double* sumsq = scratch_dev;                 // [0]: sum of squares of all gradients; [1 ..]: one partial per 2048-element chunk
     double* partial = scratch_dev + 1;
-    int total_chunks = 0;
     for (int pass = 0; pass < 2; ++pass) {
         int base_chunk = 0;
         for (int t0 = 0; t0 < n_tensors; t0 += kAdamMaxTensors) {
@@ -2914,11 +2869,11 @@ int dpn_clip_adam(int n_tensors, float* const* params, const float* const* grads
             }
             t.chunk_start[t.n] = chunks;
             if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel<AdamTable>, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
-            else hipLaunchKernelGGL(dpn_adam_kernel<AdamTable>, dim3(chunks), dim3(256), 0, s, t, sumsq, (const double*)partial, total_chunks,
-                                    (const int*)step_dev, lr, beta1, beta2, eps, weight_decay, max_norm, out_norm_dev, (const float*)nullptr);
+            else hipLaunchKernelGGL(dpn_adam_kernel<AdamTable>, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr, beta1,
+                                    beta2, eps, weight_decay, max_norm, out_norm_dev, (const float*)nullptr);
             base_chunk += chunks;
         }
-        total_chunks = base_chunk;
+        if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, base_chunk, sumsq);
     }
     return ck(hipGetLastError());
 }
@@ -2937,7 +2892,6 @@ static int clip_adam_flat_impl(int n_tensors, float* const* params, const float*
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     double* sumsq = scratch_dev;
     double* partial = scratch_dev + 1;
-    int total_chunks = 0;
     for (int pass = 0; pass < 2; ++pass) {
         int base_chunk = 0;
         for (int t0 = 0; t0 < n_tensors; t0 += kAdamFlatMaxTensors) {
@@ -2955,11 +2909,11 @@ static int clip_adam_flat_impl(int n_tensors, float* const* params, const float*
             }
             t.chunk_start[t.n] = chunks;
             if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, partial + base_chunk, step_dev, t0 == 0 ? 1 : 0);
-            else hipLaunchKernelGGL(dpn_adam_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, sumsq, (const double*)partial, total_chunks,
-                                    (const int*)step_dev, lr, beta1, beta2, eps, weight_decay, max_norm, out_norm_dev, hyper_dev);
+            else hipLaunchKernelGGL(dpn_adam_kernel<AdamTableFlat>, dim3(chunks), dim3(256), 0, s, t, (const double*)sumsq, (const int*)step_dev, lr,
+                                    beta1, beta2, eps, weight_decay, max_norm, out_norm_dev, hyper_dev);
             base_chunk += chunks;
         }
-        total_chunks = base_chunk;
+        if (pass == 0) hipLaunchKernelGGL(dpn_gradnorm_reduce_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, base_chunk, sumsq);
     }
     return ck(hipGetLastError());
 }

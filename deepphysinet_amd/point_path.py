@@ -111,18 +111,6 @@ def _one(device):
     return _ones[k]
 
 
-_tickets = {}
-
-
-def _ticket(device):
-    """The persistent, zero-initialised device word of dpn_residual_losses (its last workgroup leaves it zero again).  One per device: the calls that
-    share it are ordered on the step's stream."""
-    k = (device.type, device.index)
-    if k not in _tickets:
-        _tickets[k] = torch.zeros(1, dtype=torch.int32, device=device)
-    return _tickets[k]
-
-
 HEADS_COLS = 6 * 193 + 6 * 257          # one GEMM output row: [w1b1 of net 0..5 | w2b2 of net 0..5]
 HEADS_W2_OFF = 6 * 193
 
@@ -404,10 +392,9 @@ class _PdeLossFn(torch.autograd.Function):
             g_out = torch.empty((n, 6), dtype=torch.float32, device=dev)
             g_jxi = torch.empty((n, 6, 3), dtype=torch.float32, device=dev)
             ctx.unit = (g_out, g_jxi)
-        # (one launch: the workgroup that finishes last adds the block rows up -- dpn_residual_finish's sums, bit for bit, without its launch)
-        L.check(lib.dpn_residual_losses(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None,
-                                        _ptr(_one(dev)) if need_grad else None, _ptr(sums), _ptr(_ticket(dev)), _ptr(losses7),
-                                        _ptr(g_out) if need_grad else None, _ptr(g_jxi) if need_grad else None, _stream()), 'dpn_residual_losses')
+        L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_), n, ctypes.byref(geo), ctypes.byref(ph), None, _ptr(_one(dev)) if need_grad else None,
+                                 _ptr(sums), _ptr(g_out) if need_grad else None, _ptr(g_jxi) if need_grad else None, _stream()), 'dpn_residual')
+        L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses7), _stream()), 'dpn_residual_finish')
         ctx.cfg, ctx.ws = cfg, ws
         ctx.keep = (x_, y_, t_, f_, cd_, hd_, ev_, st, out_n, jac_n)
         ctx.stamp = _stamp((heads, evec) + tuple(statics))
@@ -493,9 +480,10 @@ class _PdeLossBatchFn(torch.autograd.Function):
             nets = _net_ptrs(hd_[b], ev_[b], st)
             out_n, jac_n = _forward_points(cfg, ws, nets, x_[b], y_[b], t_[b], None, cd_[b], want_jac=True, want_saved=need_grad)
             # eager: the block sums of the losses AND d total_b / d (out, Jacobian) for a unit cotangent in ONE pass over the points
-            L.check(lib.dpn_residual_losses(_ptr(out_n), _ptr(jac_n), _ptr(f_[b]), n, ctypes.byref(geo), ctypes.byref(ph), None,
-                                            _ptr(one) if eager else None, _ptr(sums), _ptr(_ticket(dev)), _ptr(losses7[b]),
-                                            _ptr(g_out) if eager else None, _ptr(g_jxi) if eager else None, _stream()), 'dpn_residual_losses')
+            L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_[b]), n, ctypes.byref(geo), ctypes.byref(ph), None,
+                                     _ptr(one) if eager else None, _ptr(sums), _ptr(g_out) if eager else None, _ptr(g_jxi) if eager else None,
+                                     _stream()), 'dpn_residual')
+            L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses7[b]), _stream()), 'dpn_residual_finish')
             if eager:                                             # d total_b / d (this field's weights)
                 g_stat = [flat[b, starts[i]:starts[i + 1]].view(STATIC_SHAPES[i % 8]) for i in range(48)]
                 _backward_points(cfg, ws, nets, x_[b], y_[b], t_[b], None, cd_[b], g_out, g_jxi, st, into=(g_heads[b], g_evec[b], g_stat))
@@ -588,8 +576,9 @@ class _StepLossFn(torch.autograd.Function):
         losses = torch.empty((2, 7), dtype=torch.float32, device=dev)
         for gi, (a0, a1) in enumerate(((0, n_inter), (n_inter, n))):
             sums = torch.empty(((a1 - a0 + 255) // 256) * 6, dtype=torch.float64, device=dev)
-            L.check(lib.dpn_residual_losses(_ptr(out_n[a0:]), _ptr(jac_n[a0:]), _ptr(f_[a0:]), a1 - a0, ctypes.byref(geo), ctypes.byref(ph), None, None,
-                                            _ptr(sums), _ptr(_ticket(dev)), _ptr(losses[gi]), None, None, _stream()), 'dpn_residual_losses')
+            L.check(lib.dpn_residual(_ptr(out_n[a0:]), _ptr(jac_n[a0:]), _ptr(f_[a0:]), a1 - a0, ctypes.byref(geo), ctypes.byref(ph), None, None,
+                                     _ptr(sums), None, None, _stream()), 'dpn_residual')
+            L.check(lib.dpn_residual_finish(_ptr(sums), a1 - a0, ctypes.byref(ph), _ptr(losses[gi]), _stream()), 'dpn_residual_finish')
         dsum = torch.empty((n_m * 6 + 255) // 256, dtype=torch.float64, device=dev)
         L.check(lib.dpn_smooth_l1(_ptr(out_n[n_inter:]), _ptr(lab_), n_m, beta, 1.0, _ptr(dsum), None, 0, None, _stream()), 'dpn_smooth_l1')
         data = (dsum.sum() / (6.0 * n_m)).float() * margin_factor

@@ -140,11 +140,6 @@ int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t
                  const DpnPhysics* phys, const float* gl /*[6] or NULL*/, const float* gtot /*[1] or NULL*/, double* loss_sums,
                  float* g_out, float* g_jxi, void* stream);
 int dpn_residual_finish(const double* loss_sums, int64_t n_points, const DpnPhysics* phys, float* losses, void* stream);
-/* dpn_residual + dpn_residual_finish in ONE launch: the workgroup that finishes last adds the block rows (same order, same bits as dpn_residual_finish).
- * ticket: one device word, zero before the call and zero again behind it; calls sharing a ticket must be ordered on one stream. */
-int dpn_residual_losses(const float* out_n, const float* jac_n, const float* f, int64_t n_points, const DpnGeometry* geo, const DpnPhysics* phys,
-                        const float* gl, const float* gtot, double* loss_sums, unsigned* ticket, float* losses /* [7] */, float* g_out, float* g_jxi,
-                        void* stream);
 
 /* Backward, stage 1: per-point cotangent streams -> the operands of the weight-gradient reductions.
  *   g_out [N][6]; g_jxi [N][6][3] or NULL (value-only loss, e.g. the data loss). */
