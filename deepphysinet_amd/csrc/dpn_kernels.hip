@@ -1074,12 +1074,14 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         float v = a.out_n[ic * 6 + k] * a.ph.std[k] + a.ph.mean[k];       // inverse_norm (interface_physics.py:250)
+        float dv = a.ph.std[k];                                          // d val / d out
+        if (a.ph.sq_on[k]) { dv = 2.f * v * a.ph.std[k]; v = v * v + a.ph.sq_add[k]; }   // three-factor min_max: squared, shifted (:244-247)
         float m = 1.f;
         if (a.ph.clip_on[k]) {                                           // torch.clip: gradient passes where lo <= v <= hi
             m = (v >= a.ph.clip_lo[k] && v <= a.ph.clip_hi[k]) ? 1.f : 0.f;
             v = fminf(fmaxf(v, a.ph.clip_lo[k]), a.ph.clip_hi[k]);
         }
-        val[k] = v; msk[k] = m * a.ph.std[k];
+        val[k] = v; msk[k] = m * dv;
 #pragma unroll
         for (int c = 0; c < 3; ++c) J[k][c] = a.jac_n[(ic * 6 + k) * 3 + c] * msk[k];
     }
@@ -1150,7 +1152,15 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
     const float sc[3] = {1.f / a.geo.lon_m1 / a.geo.dx, 1.f / a.geo.lat_m1 / a.geo.dy, 1.f / a.geo.pred_t_span};
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        a.g_out[i * 6 + k] = gv[k] * msk[k];
+        float go = gv[k] * msk[k];
+        if (a.ph.sq_on[k] && msk[k] != 0.f) {
+            // the squared form is not affine: J = jac * d val / d out depends on `out` as well -- d J / d out = jac * 2 std^2 (inside the clip bounds)
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t = fmaf(gJ[k][c], a.jac_n[(i * 6 + k) * 3 + c], t);
+            go = fmaf(t, 2.f * a.ph.std[k] * a.ph.std[k], go);
+        }
+        a.g_out[i * 6 + k] = go;
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.g_jxi[(i * 6 + k) * 3 + c] = gJ[k][c] * msk[k] * sc[c];
     }

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void dpn_grid_maps_kernel(MapArgs a) {
 #pragma clang fp contract(off)
         const float prod = a.out_n[((int64_t)xx * a.lat + yy) * 6 + k] * a.ph.std[k];
         v = prod + a.ph.mean[k];
+        if (a.ph.sq_on[k]) { const float sq = v * v; v = sq + a.ph.sq_add[k]; }       // three-factor min_max (interface_physics.py:244-247)
     }
     if (a.with_clip && k >= 2) v = v != v ? v : fminf(fmaxf(v, a.ph.clip_lo[k]), a.ph.clip_hi[k]);      // NaN passes through like torch.clip
     a.maps[j] = v;

@@ -47,34 +47,34 @@ class InterfacePhysics(nn.Module):
     # ------------------------------------------------------------------ configuration of the HIP path
     def point_config(self, loss_factor=None, criterion=None) -> PointConfig:
         crit_kind, crit_beta = self._check_pde_criterion(criterion if criterion is not None else self.train_cfg['losses'].get('pde_loss', {'name': 'MSELoss'}))
-        # inverse_norm (:232-262) as one affine map + optional clip per variable: mean_norm v * nf[1] + nf[0]; min_max v * (nf[1] - nf[0]) + nf[0];
-        # use_norm False: the identity and no clip (the reference clips inside its `if use_norm`).  The three-factor min_max form (v ** 2 + nf[2]) is
-        # not affine and stays with the torch expression of `inverse_norm`
-        mean, std, clipv = [], [], []
+        # inverse_norm (:232-262) per variable as (out * std + mean) [squared and shifted] + optional clip: mean_norm v * nf[1] + nf[0]; min_max
+        # v * (nf[1] - nf[0]) + nf[0], with a third factor (v * (nf[1] - nf[0]) + nf[0]) ** 2 + nf[2] (:244-247); use_norm False: the identity and no
+        # clip (the reference clips inside its `if use_norm`: bounds of +-FLT_MAX never bind)
+        mean, std, clipv, sq = [], [], [], []
         for k in OBS_ORDER:
             c = self.obs_norm_cfg[k]
             if not c.get('use_norm', True):
-                mean.append(0.0), std.append(1.0), clipv.append(False)
+                mean.append(0.0), std.append(1.0), clipv.append(False), sq.append(None)
                 continue
             nf = c['norm_factor']
             if c.get('norm_type', 'mean_norm').lower() == 'min_max':
-                if len(nf) != 2:
-                    raise NotImplementedError('min_max de-normalisation with a third factor (v ** 2 + nf[2], :247-249) is not an affine map: the fused '
-                                              'residual kernel implements the two-factor form and mean/std')
                 mean.append(float(nf[0])), std.append(float(nf[1]) - float(nf[0]))
+                sq.append(None if len(nf) == 2 else float(nf[2]))
             else:
-                mean.append(float(nf[0])), std.append(float(nf[1]))
+                mean.append(float(nf[0])), std.append(float(nf[1])), sq.append(None)
             clipv.append(True)
         lf = loss_factor or self.train_cfg['losses']['loss_factor']
         key = (self.dx, self.dy, self.lon_size, self.lat_size, self.pred_t_span, bool(self.with_clip), self.precision,
-               tuple(float(lf[k]) for k in LOSS_ORDER), tuple(mean), tuple(std), tuple(clipv), crit_kind, crit_beta)
+               tuple(float(lf[k]) for k in LOSS_ORDER), tuple(mean), tuple(std), tuple(clipv), crit_kind, crit_beta, tuple(sq))
         if self._cfg_cache is None or self._cfg_cache[0] != key:
-            bound = lambda k, i: float(self.obs_norm_cfg[k]['bound'][i]) if 'bound' in self.obs_norm_cfg[k] else (0.0, 0.0)[i]
+            big = 3.4028234663852886e38
+            bound = lambda k, i: (float(self.obs_norm_cfg[k]['bound'][i]) if ('bound' in self.obs_norm_cfg[k] and self.obs_norm_cfg[k].get('use_norm', True))
+                                  else (-big, big)[i])
             cfg = PointConfig(dx=self.dx, dy=self.dy, lon_size=self.lon_size, lat_size=self.lat_size, pred_t_span=self.pred_t_span,
                               mean=tuple(mean), std=tuple(std),
                               clip_lo=tuple(bound(k, 0) for k in OBS_ORDER), clip_hi=tuple(bound(k, 1) for k in OBS_ORDER),
                               with_clip=bool(self.with_clip), clip_vars=tuple(clipv), factors=key[7], prec=self.precision,
-                              criterion=crit_kind, beta=crit_beta)
+                              criterion=crit_kind, beta=crit_beta, sq_add=tuple(sq))
             self._cfg_cache = (key, cfg)
         self.physics_net.point_cfg = self._cfg_cache[1]
         return self._cfg_cache[1]
@@ -154,7 +154,7 @@ class InterfacePhysics(nn.Module):
             c = obs_norm_cfg[name]
             if c['use_norm']:
                 nf = c['norm_factor']
-                if c['norm_type'].lower() == 'min_max':                 # :242-249 (unused by the shipped config; torch expression only)
+                if c['norm_type'].lower() == 'min_max':                 # :242-249 (unused by the shipped config)
                     val = val * (nf[1] - nf[0]) + nf[0]
                     if len(nf) != 2:
                         val = val ** 2 + nf[2]

@@ -46,6 +46,7 @@ class PointConfig:
                                                                             # whose obs_norm_cfg says use_norm: False -- interface_physics.py:236-257)
     factors: Sequence[float] = (1.e3, 1.e3, 1.e10, 1e1, 1.e14, 1.e-7)
     prec: int = L.PREC_BF16X2
+    sq_add: Sequence[Optional[float]] = (None,) * 6      # three-factor min_max (:244-247): (out * std + mean) ** 2 + sq_add; None: the affine forms
     criterion: int = L.CRIT_MSE            # the PDE criterion (train_cfg.losses.pde_loss): MSELoss | L1Loss | WeightSmoothL1Loss(beta)
     beta: float = 0.0
 
@@ -60,6 +61,8 @@ class PointConfig:
             ph.clip_on[k] = int(bool(self.with_clip) and k >= 2 and bool(self.clip_vars[k]))     # u, v are never clipped (interface_physics.py:256-257)
             ph.factor[k] = float(self.factors[k])
         ph.criterion, ph.beta = int(self.criterion), float(self.beta)
+        for k in range(L.NETS):
+            ph.sq_on[k], ph.sq_add[k] = (0, 0.0) if self.sq_add[k] is None else (1, float(self.sq_add[k]))
         return ph
 
 

@@ -67,6 +67,9 @@ typedef struct DpnPhysics {
                                            * losses/builder.py offers these three): DPN_CRIT_MSE nn.MSELoss, DPN_CRIT_L1 nn.L1Loss, DPN_CRIT_SMOOTH_L1
                                            * WeightSmoothL1Loss(beta) = mean of nn.SmoothL1Loss(beta, reduction='none') (weights_loss.py:12-21)        */
     float beta;                           /* DPN_CRIT_SMOOTH_L1 only (> 0)                                                                        */
+    int   sq_on[DPN_NETS];                /* inverse_norm's three-factor min_max form (interface_physics.py:244-247): v = (out * std + mean)^2 + sq_add,
+                                           * std = nf[1] - nf[0], mean = nf[0], sq_add = nf[2]; 0: the affine forms                                 */
+    float sq_add[DPN_NETS];
 } DpnPhysics;
 enum { DPN_CRIT_MSE = 0, DPN_CRIT_L1 = 1, DPN_CRIT_SMOOTH_L1 = 2 };
 

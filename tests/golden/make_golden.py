@@ -92,6 +92,15 @@ def f12_norm_cfg(base):
     return c
 
 
+def f12_norm_sq_cfg(base):
+    """F12's third table: q2 in the three-factor min_max form (squared and shifted, interface_physics.py:244-247), the rest as shipped."""
+    import copy
+    c = copy.deepcopy(base)
+    c['q2']['norm_type'] = 'min_max'
+    c['q2']['norm_factor'] = [0.08, 0.11, 0.001]
+    return c
+
+
 def write_f12(m, run_pde, builder_loss, inter):
     """F12: the branches of the PDE path the shipped config does not take, run on the reference itself -- the two other criteria its loss builder
     offers for `pde_loss` (L1Loss, WeightSmoothL1Loss(beta), interface_physics.py:384 + losses/builder.py), and inverse_norm's other branches
@@ -100,7 +109,8 @@ def write_f12(m, run_pde, builder_loss, inter):
     base = copy.deepcopy(m.obs_norm_cfg)
     out = {}
     for tag, crit, ncfg in (('l1', builder_loss(name='L1Loss'), None), ('sl1', builder_loss(name='WeightSmoothL1Loss', beta=0.1), None),
-                            ('sl1_b2', builder_loss(name='WeightSmoothL1Loss', beta=2.0), None), ('norm', None, f12_norm_cfg(base))):
+                            ('sl1_b2', builder_loss(name='WeightSmoothL1Loss', beta=2.0), None), ('norm', None, f12_norm_cfg(base)),
+                            ('norm_sq', None, f12_norm_sq_cfg(base))):
         m.physics_net.zero_grad()
         rec, total = run_pde(m, inter, True, torch.float32, crit=crit, norm_cfg=ncfg if ncfg is not None else copy.deepcopy(base))
         total.backward()

@@ -133,7 +133,7 @@ def test_place_one_batch_matches_reference_golden(golden_dir):
     assert np.all(np.abs(terms - d['parts']) <= 1e-4 * np.abs(d['parts']))
 
 
-@pytest.mark.parametrize('case', ['l1', 'sl1', 'sl1_b2', 'norm'])
+@pytest.mark.parametrize('case', ['l1', 'sl1', 'sl1_b2', 'norm', 'norm_sq'])
 def test_other_pde_criteria_and_norm_branches_match_reference_golden(golden_dir, case):
     """Fixture F12 -- the REFERENCE run on the branches its shipped config does not take: `pde_loss` = L1Loss / WeightSmoothL1Loss(beta) (the other two
     criteria its loss builder offers, interface_physics.py:384) and inverse_norm's use_norm False / two-factor min_max branches (:238-243).
@@ -147,8 +147,8 @@ def test_other_pde_criteria_and_norm_branches_match_reference_golden(golden_dir,
     crit_cfg = {'l1': dict(name='L1Loss'), 'sl1': dict(name='WeightSmoothL1Loss', beta=0.1), 'sl1_b2': dict(name='WeightSmoothL1Loss', beta=2.0)}.get(case)
     crit = builder_loss(**crit_cfg) if crit_cfg else torch.nn.MSELoss()
     norm_cfg = None
-    if case == 'norm':
-        norm_cfg = O.f12_norm_cfg()
+    if case in ('norm', 'norm_sq'):
+        norm_cfg = O.f12_norm_cfg() if case == 'norm' else O.f12_norm_sq_cfg()
         for name, c in zip(('u10', 'v10', 'pres', 't2', 'q2', 'rio'), norm_cfg):
             m.obs_norm_cfg[name].update(norm_type=c['norm_type'], norm_factor=c['norm_factor'], use_norm=c['use_norm'])
     m.physics_net.zero_grad()
@@ -181,6 +181,22 @@ def test_other_pde_criteria_and_norm_branches_match_reference_golden(golden_dir,
         worst = max(worst, err)
         assert l2 < TOL['bf16x2']['grad'] and err < 5.0 * TOL['bf16x2']['grad'], (case, name, l2, err)
     print('F12 %s: total %.6e (reference %.6e), worst gradient element error %.2e' % (case, float(total.detach()), float(d[case + '.total']), worst))
+    if norm_cfg is not None:
+        # the full-grid maps kernel (inverse_norm + scatter of the visualisation branch) takes the same table: against the module's torch expression
+        from deepphysinet_amd import _lib as L
+        from deepphysinet_amd.point_path import _ptr, _stream
+        lon, lat = 8, 4
+        out_n = torch.randn(lon * lat, 6, device=_dev())
+        maps = torch.empty((6, lat, lon), dtype=torch.float32, device=_dev())
+        ph = m.point_config().physics()
+        for wc in (0, 1):
+            L.check(L.load().dpn_grid_maps(_ptr(out_n), lon, lat, ctypes.byref(ph), wc, _ptr(maps), _stream()), 'dpn_grid_maps')
+            m.with_clip = bool(wc)
+            ref6 = m.inverse_norm(*[out_n[:, k] for k in range(6)], obs_norm_cfg=m.obs_norm_cfg)
+            m.with_clip = True
+            for k in range(6):
+                want = ref6[k].view(lon, lat).t()                      # node order: x outer, y inner -> [lat][lon]
+                assert torch.allclose(maps[k], want, rtol=2e-7, atol=0.0), (case, wc, k, float((maps[k] - want).abs().max()))
 
 
 def test_grid_node_points_longest_lead_match_reference_golden(golden_dir):

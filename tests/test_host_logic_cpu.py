@@ -175,9 +175,10 @@ def test_point_config_follows_the_config_file(model):
         ph2 = model.point_config().physics()
         assert (ph2.mean[0], ph2.std[0], ph2.mean[2], ph2.std[2]) == (0.0, 1.0, 80000.0, 20000.0)
         assert list(ph2.clip_on) == [0, 0, 1, 1, 0, 1]
-        model.obs_norm_cfg['pres']['norm_factor'] = [80000.0, 100000.0, 3.0]
-        with pytest.raises(NotImplementedError):
-            model.point_config()
+        assert ph2.clip_lo[0] < -3e38 and ph2.clip_hi[4] > 3e38          # un-normalised variables: bounds that never bind (full-grid maps too)
+        model.obs_norm_cfg['pres']['norm_factor'] = [80000.0, 100000.0, 3.0]      # the squared three-factor form (:244-247)
+        ph3 = model.point_config().physics()
+        assert (ph3.sq_on[2], ph3.sq_add[2], ph3.std[2]) == (1, 3.0, 20000.0) and list(ph3.sq_on)[:2] == [0, 0]
     finally:
         model.obs_norm_cfg.clear()
         model.obs_norm_cfg.update(keep)

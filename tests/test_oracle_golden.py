@@ -113,13 +113,13 @@ def test_f10_grid_node_points_longest_lead(golden_dir, state):
 
 
 F12_CASES = {'l1': dict(crit=('L1Loss', 0.0)), 'sl1': dict(crit=('WeightSmoothL1Loss', 0.1)), 'sl1_b2': dict(crit=('WeightSmoothL1Loss', 2.0)),
-             'norm': dict(norm=True)}
+             'norm': dict(norm='f12_norm_cfg'), 'norm_sq': dict(norm='f12_norm_sq_cfg')}
 
 
 @pytest.mark.parametrize('case', sorted(F12_CASES))
 def test_f12_other_criteria_and_norm_branches(golden_dir, case):
     """The branches the shipped config does not take, against the REFERENCE run on them: the loss builder's other PDE criteria (L1Loss,
-    WeightSmoothL1Loss(beta)) and inverse_norm's use_norm False / two-factor min_max branches; six terms, total, all 155 gradient norms."""
+    WeightSmoothL1Loss(beta)) and inverse_norm's use_norm False / two- and three-factor min_max branches; six terms, total, all 155 gradient norms."""
     d = _load(golden_dir, 'f12_criteria_and_norm_branches.npz')
     c = F12_CASES[case]
     st = O.make_state(requires_grad=True)
@@ -127,7 +127,7 @@ def test_f12_other_criteria_and_norm_branches(golden_dir, case):
     x, y, t = (inp[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
     crit = O.pde_criterion(c['crit'][0], beta=c['crit'][1]) if 'crit' in c else None
     total, parts, fn, ph = O.place_one_batch(st, x, y, t, inp['f'], inp['field_data'], inp['coord_data'], inp['forecast_h'], GEO, return_parts=True,
-                                             crit=crit, norm_cfg=O.f12_norm_cfg() if c.get('norm') else None)
+                                             crit=crit, norm_cfg=getattr(O, c['norm'])() if c.get('norm') else None)
     assert _rel(torch.cat(ph, 1).detach().numpy(), d[case + '.fields_phys']) < 2e-6
     mine = np.array([float(p.detach()) for p in parts])
     assert np.all(np.abs(mine - d[case + '.parts']) <= 2e-5 * np.abs(d[case + '.parts'])), (mine, d[case + '.parts'])
