@@ -1381,9 +1381,19 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
     if (t1 < t0) t1 = t0;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    // wave tile: 256-column products (P1) 2 x 4 waves of 128 rows x 64 columns (4 x 2 MFMA tiles); 192-column products (P2, P3) 4 x 2 waves of 64 rows x
+    // 96 columns (2 x 3 tiles).  Until the end of round 5 the 192-column products kept the 2 x 4 arrangement with the wn = 3 waves idle: six waves with
+    // eight tiles each on THREE SIMDs (wave w runs on SIMD w % 4) -- tools/wgrad_phase_probe.py showed the multiply phase of the wm = 1 waves at 4 200
+    // cycles per tile against 2 550 for their SIMD partners and SIMD 3 idle.  Eight waves with six tiles each: 12 tile-products per SIMD instead of 16.
+#ifdef DPN_WGRAD_2X4_ONLY                                                   // A/B build (tools/variant_build.py wg2x4 -DDPN_WGRAD_2X4_ONLY): the former arrangement
+    constexpr bool kWide = true;
+#else
+    constexpr bool kWide = nct == 8;
+#endif
+    constexpr int MT = kWide ? 4 : 2, NT = kWide ? 2 : 3;
+    const int wm = kWide ? wave >> 2 : wave >> 1, wn = kWide ? wave & 3 : wave & 1;
     const int i = lane & 31, h = lane >> 5;
-    const bool active = wn * 2 < nct;                                   // 192-column products leave the wn = 3 waves idle
+    const bool active = wn * NT < nct;                                  // (always true but in the A/B build, whose wn = 3 waves have no columns at 192)
     SavedView sv = saved_view(a.saved, a.n_pad, NS);
     OperandView ov = operand_view(a.operands, a.n_pad, NS);
     const char* xb = (PROD == 3) ? sv.T1.base : sv.M2.base;                                      // 8 column tiles
@@ -1425,10 +1435,19 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
         dma4(reinterpret_cast<const char*>(gnet + tile * 32) + lane * 4, sl + S::kGOff + wave * 256);
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { acc[m][0] = (f32x16)0.f; acc[m][1] = (f32x16)0.f; }
-    float vecA[4] = {0.f, 0.f, 0.f, 0.f}, vecB[2] = {0.f, 0.f}, gsum = 0.f;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < NT; ++n2) acc[m][n2] = (f32x16)0.f;
+    float vecA[MT], vecB[NT], gsum = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) vecA[m] = 0.f;
+#pragma unroll
+    for (int n2 = 0; n2 < NT; ++n2) vecB[n2] = 0.f;
+    // which wave of the waves that hold a row tile's (column tile's) fragments adds up its row-side (column-side) vector
+    auto owns_row = [&](const int m) __attribute__((always_inline)) { return (kWide && nct == 6) ? wn == m % 3 : wn == m; };   // 4 wn for 4 m | 2 wn for 2 m
+    auto owns_col = [&](const int n2) __attribute__((always_inline)) { return wm == n2; };                              // 2 wm for 2 n | 4 wm, three used
 
     // LDS reads by inline asm with a counted wait: a read hipcc can see is ordered behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)
     // in front of the first ds_read of every tile), which serialised fetch and compute -- DMA alone 156 us, compute alone 131 us,
@@ -1441,11 +1460,11 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
         const unsigned buf = lds_base + slot_ * kSlot;
         const unsigned gl = buf + S::kGOff + wave * 256;
         constexpr int KB = (NS == 1) ? 2 : 1;                       // single-bf16 fragments: both k-steps of the tile are read up front
-        u32x4 gqa[KB][2], faa[KB][nsx][4], fba[KB][NS][2];
+        u32x4 gqa[KB][2], faa[KB][nsx][MT], fba[KB][NS][NT];
         // one base register per stream, the fragment index as the instruction's immediate offset (a full address per read costs a VGPR each for its
         // slot-independent part -- ~30 of them, hoisted out of the tile loop -- and spilled once the in-register operand forming of products 2 / 3 came in)
         const unsigned baseG = gl + h * 16;
-        const unsigned baseA = buf + wm * 4096 + lane * 16, baseB = buf + S::kX + wn * 2048 + lane * 16;
+        const unsigned baseA = buf + wm * (MT * 1024) + lane * 16, baseB = buf + S::kX + wn * (NT * 1024) + lane * 16;
         auto rd128o = [&](u32x4& v, const unsigned base, const int off) __attribute__((always_inline)) {
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "i"(off) : "memory");
         };
@@ -1455,36 +1474,40 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
 #pragma unroll
             for (int s2 = 0; s2 < nsx; ++s2)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) rd128o(faa[b][s2][m], baseA, s2 * 16384 + (kk * 8 + m) * 1024);
+                for (int m = 0; m < MT; ++m) rd128o(faa[b][s2][m], baseA, s2 * 16384 + (kk * 8 + m) * 1024);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) rd128o(fba[b][s2][n2], baseB, s2 * S::kYPlane + (kk * nct + n2) * 1024);
+                for (int n2 = 0; n2 < NT; ++n2) rd128o(fba[b][s2][n2], baseB, s2 * S::kYPlane + (kk * nct + n2) * 1024);
         };
-        constexpr int kReads = 2 + 4 * nsx + 2 * NS;                // LDS reads per k-step
+        constexpr int kReads = 2 + MT * nsx + NT * NS;              // LDS reads per k-step
         if constexpr (NS == 1) { issue_reads(0, 0); issue_reads(1, 1); }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int b = (NS == 1) ? kk : 0;
             if constexpr (NS == 2) issue_reads(kk, 0);
-            u32x4 (&fa)[nsx][4] = faa[b];
-            u32x4 (&fb)[NS][2] = fba[b];
+            u32x4 (&fa)[nsx][MT] = faa[b];
+            u32x4 (&fb)[NS][NT] = fba[b];
             u32x4& gq0 = gqa[b][0];
             u32x4& gq1 = gqa[b][1];
             // every value passes through the wait, so no use can be scheduled in front of it (LDS reads retire in order: with the
             // second k-step's reads still behind, the first k-step is complete at lgkmcnt(kReads))
             if (NS == 1 && kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(kReads) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]));
+            asm volatile("" : "+v"(gq0), "+v"(gq1), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]));
+            if constexpr (MT == 4) asm volatile("" : "+v"(fa[0][2]), "+v"(fa[0][3]));
+            if constexpr (NT == 3) asm volatile("" : "+v"(fb[0][2]));
             if constexpr (NS == 2) asm volatile("" : "+v"(fb[1][0]), "+v"(fb[1][1]));
-            if constexpr (nsx == 2) asm volatile("" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]));
+            if constexpr (NS == 2 && NT == 3) asm volatile("" : "+v"(fb[1][2]));
+            if constexpr (nsx == 2) asm volatile("" : "+v"(fa[1][0]), "+v"(fa[1][1]));
+            if constexpr (nsx == 2 && MT == 4) asm volatile("" : "+v"(fa[1][2]), "+v"(fa[1][3]));
             const float gp[8] = {__uint_as_float(gq0[0]), __uint_as_float(gq0[1]), __uint_as_float(gq0[2]), __uint_as_float(gq0[3]),
                                  __uint_as_float(gq1[0]), __uint_as_float(gq1[1]), __uint_as_float(gq1[2]), __uint_as_float(gq1[3])};
             if constexpr (PROD == 2) {
                 // the Y fragments just read are the per-point TABLE pe6 (hi [+ lo]); this net's operand G6 = g pe6 is formed here: element e of a register
                 // pair <-> point e of the lane's eight (gp[e])
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2)
+                for (int n2 = 0; n2 < NT; ++n2)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         float v0 = bf_lo(fb[0][n2][p]), v1 = bf_hi(fb[0][n2][p]);
@@ -1500,8 +1523,8 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
                 for (int e = 0; e < 8; ++e) gsum += gp[e];
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (wn == (nct == 8 ? m : m % 3) && PROD != 2) {         // row-side vector: sum_pt X[pt][row] * g[pt]; the four waves that
+            for (int m = 0; m < MT; ++m) {
+                if (owns_row(m) && PROD != 2) {         // row-side vector: sum_pt X[pt][row] * g[pt]; the four waves that
                                                                          // hold this row tile's fragments take one tile each (all on
                                                                          // the wn = 0 waves it made them the workgroup's critical path:
                                                                          // +700 cycles per tile, everybody else waiting at the barrier);
@@ -1515,7 +1538,7 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
                     vecA[m] += d;
                 }
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) {
+                for (int n2 = 0; n2 < NT; ++n2) {
                     if constexpr (NS == 2) {
                         acc[m][n2] = mfma(as_bf(fa[0][m]), as_bf(fb[1][n2]), acc[m][n2]);
                         if constexpr (nsx == 2) acc[m][n2] = mfma(as_bf(fa[1][m]), as_bf(fb[0][n2]), acc[m][n2]);
@@ -1525,8 +1548,8 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
             }
             if (PROD != 3) {                                             // column-side vector: q = sum_pt Y[pt][col] (Z, Z1, G6), one column tile per wm
 #pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) {
-                    if (wm != n2) continue;
+                for (int n2 = 0; n2 < NT; ++n2) {
+                    if (!owns_col(n2)) continue;
                     float d = 0.f;
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2)
@@ -1577,21 +1600,21 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
     float* out = part + part_off(PROD);
     if (active) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2)
+            for (int n2 = 0; n2 < NT; ++n2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rr = wm * 128 + 32 * m + drow32(r, h);
-                    const int cc = wn * 64 + 32 * n2 + i;
+                    const int rr = wm * (MT * 32) + 32 * m + drow32(r, h);
+                    const int cc = wn * (NT * 32) + 32 * n2 + i;
                     out[rr * ncol + cc] = acc[m][n2][r];
                 }
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
         const float v = vecA[m] + __shfl_xor(vecA[m], 32);
-        if (wn == (nct == 8 ? m : m % 3) && h == 0) {
-            const int rr = wm * 128 + 32 * m + i;
+        if (owns_row(m) && h == 0) {
+            const int rr = wm * (MT * 32) + 32 * m + i;
             if (PROD == 1) part[kPartVec + 2 * 256 + rr] = v;          // mv1 (= mvec again: the hyper-network's half of the reduction does not wait for P0)
             if (PROD == 3) part[kPartVec + 3 * 256 + rr] = v;          // db1
         }
@@ -1603,9 +1626,9 @@ DEV void wgrad_body(const WgradArgs& a, char* lds, const int split, const int ne
     if (PROD != 3 && active) {
         const int qo = kPartVec + (PROD == 1 ? 5 : 6) * 256;                             // q1 = colsum(Z1), q6 = colsum(G6)
 #pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
+        for (int n2 = 0; n2 < NT; ++n2) {
             const float v = vecB[n2] + __shfl_xor(vecB[n2], 32);
-            if (wm == n2 && h == 0) part[qo + wn * 64 + 32 * n2 + i] = v;
+            if (owns_col(n2) && h == 0) part[qo + wn * (NT * 32) + 32 * n2 + i] = v;
         }
     }
 }
