@@ -391,7 +391,9 @@ def main():
                 torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MAX)
                 dt_ = float(t_.item())
             if snap is not None:
-                blocks_finite.append(bool(torch.isfinite(opt._m_flat).all()) and bool(all(bool(torch.isfinite(p_).all()) for p_ in opt.params)))
+                # (the first moments are enough: a non-finite gradient at any step of the block stays in m = b1 m + (1 - b1) g, and finite moments
+                # cannot produce a non-finite parameter -- one reduction instead of one per parameter tensor)
+                blocks_finite.append(bool(torch.isfinite(opt._m_flat).all()))
             return dt_
 
         graphs = None
