@@ -30,7 +30,7 @@ class DpnGeometry(Structure):
 class DpnPhysics(Structure):
     _fields_ = [('mean', c_float * NETS), ('std', c_float * NETS), ('clip_lo', c_float * NETS), ('clip_hi', c_float * NETS),
                 ('clip_on', c_int * NETS), ('factor', c_float * NETS), ('criterion', c_int), ('beta', c_float), ('sq_on', c_int * NETS),
-                ('sq_add', c_float * NETS)]
+                ('sq_add', c_float * NETS), ('reduce_sum', c_int)]
 
 
 CRIT_MSE, CRIT_L1, CRIT_SMOOTH_L1 = 0, 1, 2          # DpnPhysics.criterion (include/dpn_hip.h)

@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
     }
     if (!a.g_out || !valid) return;
     float g[6];
-    const float inv_n = 1.0f / (float)a.n;
+    const float inv_n = a.ph.reduce_sum ? 1.0f : 1.0f / (float)a.n;       // reduction "sum": the criterion does not divide by the number of points
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
         // upstream weight of loss e: cotangent of losses[e] plus cotangent of the in-kernel total (1 when neither is given)
@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(384) void dpn_residual_finish_kernel(const double* 
     for (int64_t b = lane; b < nblk; b += 64) s += partials[b * 6 + e];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) { l[e] = (float)((double)(float)(s / (double)n) * (double)ph.factor[e]); losses[e] = l[e]; }   // .float() * factor (:104)
+    if (lane == 0) { l[e] = (float)((double)(float)(ph.reduce_sum ? s : s / (double)n) * (double)ph.factor[e]); losses[e] = l[e]; }   // .float() * factor (:104)
     __syncthreads();
     if (threadIdx.x == 0) losses[6] = ((((l[0] + l[1]) + l[3]) + l[2]) + l[4]) + l[5];   // montion_u + montion_v + energy + continous + vapor + gas
 }

@@ -46,7 +46,7 @@ class InterfacePhysics(nn.Module):
 
     # ------------------------------------------------------------------ configuration of the HIP path
     def point_config(self, loss_factor=None, criterion=None) -> PointConfig:
-        crit_kind, crit_beta = self._check_pde_criterion(criterion if criterion is not None else self.train_cfg['losses'].get('pde_loss', {'name': 'MSELoss'}))
+        crit_kind, crit_beta, crit_sum = self._check_pde_criterion(criterion if criterion is not None else self.train_cfg['losses'].get('pde_loss', {'name': 'MSELoss'}))
         # inverse_norm (:232-262) per variable as (out * std + mean) [squared and shifted] + optional clip: mean_norm v * nf[1] + nf[0]; min_max
         # v * (nf[1] - nf[0]) + nf[0], with a third factor (v * (nf[1] - nf[0]) + nf[0]) ** 2 + nf[2] (:244-247); use_norm False: the identity and no
         # clip (the reference clips inside its `if use_norm`: bounds of +-FLT_MAX never bind)
@@ -65,7 +65,7 @@ class InterfacePhysics(nn.Module):
             clipv.append(True)
         lf = loss_factor or self.train_cfg['losses']['loss_factor']
         key = (self.dx, self.dy, self.lon_size, self.lat_size, self.pred_t_span, bool(self.with_clip), self.precision,
-               tuple(float(lf[k]) for k in LOSS_ORDER), tuple(mean), tuple(std), tuple(clipv), crit_kind, crit_beta, tuple(sq))
+               tuple(float(lf[k]) for k in LOSS_ORDER), tuple(mean), tuple(std), tuple(clipv), crit_kind, crit_beta, tuple(sq), crit_sum)
         if self._cfg_cache is None or self._cfg_cache[0] != key:
             big = 3.4028234663852886e38
             bound = lambda k, i: (float(self.obs_norm_cfg[k]['bound'][i]) if ('bound' in self.obs_norm_cfg[k] and self.obs_norm_cfg[k].get('use_norm', True))
@@ -74,7 +74,7 @@ class InterfacePhysics(nn.Module):
                               mean=tuple(mean), std=tuple(std),
                               clip_lo=tuple(bound(k, 0) for k in OBS_ORDER), clip_hi=tuple(bound(k, 1) for k in OBS_ORDER),
                               with_clip=bool(self.with_clip), clip_vars=tuple(clipv), factors=key[7], prec=self.precision,
-                              criterion=crit_kind, beta=crit_beta, sq_add=tuple(sq))
+                              criterion=crit_kind, beta=crit_beta, sq_add=tuple(sq), reduce_sum=crit_sum)
             self._cfg_cache = (key, cfg)
         self.physics_net.point_cfg = self._cfg_cache[1]
         return self._cfg_cache[1]
@@ -178,26 +178,26 @@ class InterfacePhysics(nn.Module):
     # ------------------------------------------------------------------ fused HIP path
     def _check_pde_criterion(self, criterion):
         """The PDE criterion (`builder_loss(**train_cfg.losses.pde_loss)`, :384; every equation calls it as loss(residual, 0), :104 ... :179) as the
-        fused residual kernel's (kind, beta).  The three the reference's losses/builder.py can build for it are implemented: MSELoss (cfg:137),
-        L1Loss, WeightSmoothL1Loss(beta); given as a module or as the config's dict."""
+        fused residual kernel's (kind, beta, reduce_sum).  What the reference's losses/builder.py can build for it is implemented: MSELoss (cfg:137),
+        L1Loss -- reduction "mean" or "sum" --, WeightSmoothL1Loss(beta); given as a module or as the config's dict."""
         from .. import _lib as L
         from ..losses import WeightSmoothL1Loss
+        red = {'mean': False, 'sum': True}
         if isinstance(criterion, dict):
             name = criterion.get('name', 'MSELoss')
-            known = {'MSELoss': (L.CRIT_MSE, 0.0), 'L1Loss': (L.CRIT_L1, 0.0), 'WeightSmoothL1Loss': (L.CRIT_SMOOTH_L1, float(criterion.get('beta', 0.1)))}
-            extra = set(criterion) - {'name'} - ({'beta'} if name == 'WeightSmoothL1Loss' else set())
-            if name in known and not extra and known[name][1] >= 0.0 and (name != 'WeightSmoothL1Loss' or known[name][1] > 0.0):
-                return known[name]
-        elif isinstance(criterion, nn.MSELoss) and criterion.reduction == 'mean':
-            return L.CRIT_MSE, 0.0
-        elif isinstance(criterion, nn.L1Loss) and criterion.reduction == 'mean':
-            return L.CRIT_L1, 0.0
+            extra = set(criterion) - {'name'}
+            if name in ('MSELoss', 'L1Loss') and extra <= {'reduction'} and criterion.get('reduction', 'mean') in red:
+                return (L.CRIT_MSE if name == 'MSELoss' else L.CRIT_L1), 0.0, red[criterion.get('reduction', 'mean')]
+            if name == 'WeightSmoothL1Loss' and extra <= {'beta'} and float(criterion.get('beta', 0.1)) > 0.0:
+                return L.CRIT_SMOOTH_L1, float(criterion.get('beta', 0.1)), False
+        elif isinstance(criterion, (nn.MSELoss, nn.L1Loss)) and criterion.reduction in red:
+            return (L.CRIT_MSE if isinstance(criterion, nn.MSELoss) else L.CRIT_L1), 0.0, red[criterion.reduction]
         elif isinstance(criterion, WeightSmoothL1Loss) and criterion.beta > 0:
-            return L.CRIT_SMOOTH_L1, float(criterion.beta)
-        elif isinstance(criterion, nn.SmoothL1Loss) and criterion.reduction == 'mean' and criterion.beta > 0:
-            return L.CRIT_SMOOTH_L1, float(criterion.beta)
+            return L.CRIT_SMOOTH_L1, float(criterion.beta), False
+        elif isinstance(criterion, nn.SmoothL1Loss) and criterion.reduction in red and criterion.beta > 0:
+            return L.CRIT_SMOOTH_L1, float(criterion.beta), red[criterion.reduction]
         raise NotImplementedError('the fused residual kernel implements the PDE criteria of the reference\'s loss builder -- nn.MSELoss (cfg:137), nn.L1Loss, '
-                                  'WeightSmoothL1Loss(beta > 0), reduction "mean"; got %r' % (criterion,))
+                                  'WeightSmoothL1Loss(beta > 0), reduction "mean" or "sum"; got %r' % (criterion,))
 
     def pde_loss_terms(self, x, y, t, f, field_data, input_data, forecast_h, loss_factor=None, use_cache=False, with_total=False, criterion=None):
         """The six scaled residual losses as a [6] tensor (motion_u, motion_v, continuous, energy, vapor, gas)."""

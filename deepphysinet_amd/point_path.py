@@ -49,6 +49,7 @@ class PointConfig:
     sq_add: Sequence[Optional[float]] = (None,) * 6      # three-factor min_max (:244-247): (out * std + mean) ** 2 + sq_add; None: the affine forms
     criterion: int = L.CRIT_MSE            # the PDE criterion (train_cfg.losses.pde_loss): MSELoss | L1Loss | WeightSmoothL1Loss(beta)
     beta: float = 0.0
+    reduce_sum: bool = False               # the criterion's reduction: "mean" (shipped) or "sum"
 
     def geometry(self) -> L.DpnGeometry:
         return L.DpnGeometry(float(self.dx), float(self.dy), float(self.lon_size - 1), float(self.lat_size - 1), float(self.pred_t_span))
@@ -60,7 +61,7 @@ class PointConfig:
             ph.clip_lo[k], ph.clip_hi[k] = float(self.clip_lo[k]), float(self.clip_hi[k])
             ph.clip_on[k] = int(bool(self.with_clip) and k >= 2 and bool(self.clip_vars[k]))     # u, v are never clipped (interface_physics.py:256-257)
             ph.factor[k] = float(self.factors[k])
-        ph.criterion, ph.beta = int(self.criterion), float(self.beta)
+        ph.criterion, ph.beta, ph.reduce_sum = int(self.criterion), float(self.beta), int(bool(self.reduce_sum))
         for k in range(L.NETS):
             ph.sq_on[k], ph.sq_add[k] = (0, 0.0) if self.sq_add[k] is None else (1, float(self.sq_add[k]))
         return ph

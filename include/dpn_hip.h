@@ -70,6 +70,7 @@ typedef struct DpnPhysics {
     int   sq_on[DPN_NETS];                /* inverse_norm's three-factor min_max form (interface_physics.py:244-247): v = (out * std + mean)^2 + sq_add,
                                            * std = nf[1] - nf[0], mean = nf[0], sq_add = nf[2]; 0: the affine forms                                 */
     float sq_add[DPN_NETS];
+    int   reduce_sum;                     /* the criterion's reduction: 0 "mean" (shipped), 1 "sum" (`pde_loss=dict(name='MSELoss', reduction='sum')`)       */
 } DpnPhysics;
 enum { DPN_CRIT_MSE = 0, DPN_CRIT_L1 = 1, DPN_CRIT_SMOOTH_L1 = 2 };
 

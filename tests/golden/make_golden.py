@@ -109,7 +109,8 @@ def write_f12(m, run_pde, builder_loss, inter):
     base = copy.deepcopy(m.obs_norm_cfg)
     out = {}
     for tag, crit, ncfg in (('l1', builder_loss(name='L1Loss'), None), ('sl1', builder_loss(name='WeightSmoothL1Loss', beta=0.1), None),
-                            ('sl1_b2', builder_loss(name='WeightSmoothL1Loss', beta=2.0), None), ('norm', None, f12_norm_cfg(base)),
+                            ('sl1_b2', builder_loss(name='WeightSmoothL1Loss', beta=2.0), None), ('mse_sum', builder_loss(name='MSELoss', reduction='sum'), None),
+                            ('norm', None, f12_norm_cfg(base)),
                             ('norm_sq', None, f12_norm_sq_cfg(base))):
         m.physics_net.zero_grad()
         rec, total = run_pde(m, inter, True, torch.float32, crit=crit, norm_cfg=ncfg if ncfg is not None else copy.deepcopy(base))

@@ -69,7 +69,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.DpnNetPtrs) == 13 * 8
     assert ctypes.sizeof(_lib.DpnNetGradPtrs) == 13 * 8
     assert ctypes.sizeof(_lib.DpnGeometry) == 5 * 4
-    assert ctypes.sizeof(_lib.DpnPhysics) == 6 * 4 * 6 + 2 * 4 + 2 * 6 * 4          # + criterion, beta, sq_on, sq_add (round 5)
+    assert ctypes.sizeof(_lib.DpnPhysics) == 6 * 4 * 6 + 2 * 4 + 2 * 6 * 4 + 4      # + criterion, beta, sq_on, sq_add, reduce_sum (round 5)
     assert ctypes.sizeof(_lib.DpnSampler) == 6 * 4 + 5 * 8 + 2 * 4
 
 

@@ -133,7 +133,7 @@ def test_place_one_batch_matches_reference_golden(golden_dir):
     assert np.all(np.abs(terms - d['parts']) <= 1e-4 * np.abs(d['parts']))
 
 
-@pytest.mark.parametrize('case', ['l1', 'sl1', 'sl1_b2', 'norm', 'norm_sq'])
+@pytest.mark.parametrize('case', ['l1', 'sl1', 'sl1_b2', 'mse_sum', 'norm', 'norm_sq'])
 def test_other_pde_criteria_and_norm_branches_match_reference_golden(golden_dir, case):
     """Fixture F12 -- the REFERENCE run on the branches its shipped config does not take: `pde_loss` = L1Loss / WeightSmoothL1Loss(beta) (the other two
     criteria its loss builder offers, interface_physics.py:384) and inverse_norm's use_norm False / two-factor min_max branches (:238-243).
@@ -144,7 +144,8 @@ def test_other_pde_criteria_and_norm_branches_match_reference_golden(golden_dir,
     m = _model('bf16x2')
     g = _gpu(inp)
     lf = m.train_cfg['losses']['loss_factor']
-    crit_cfg = {'l1': dict(name='L1Loss'), 'sl1': dict(name='WeightSmoothL1Loss', beta=0.1), 'sl1_b2': dict(name='WeightSmoothL1Loss', beta=2.0)}.get(case)
+    crit_cfg = {'l1': dict(name='L1Loss'), 'sl1': dict(name='WeightSmoothL1Loss', beta=0.1), 'sl1_b2': dict(name='WeightSmoothL1Loss', beta=2.0),
+                'mse_sum': dict(name='MSELoss', reduction='sum')}.get(case)
     crit = builder_loss(**crit_cfg) if crit_cfg else torch.nn.MSELoss()
     norm_cfg = None
     if case in ('norm', 'norm_sq'):
@@ -165,7 +166,8 @@ def test_other_pde_criteria_and_norm_branches_match_reference_golden(golden_dir,
     st = O.make_state(requires_grad=True)
     x, y, t = (inp[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
     o_total = O.place_one_batch(st, x, y, t, inp['f'], inp['field_data'], inp['coord_data'], inp['forecast_h'], GEO,
-                                crit=O.pde_criterion(crit_cfg['name'], beta=crit_cfg.get('beta', 0.1)) if crit_cfg else None, norm_cfg=norm_cfg)
+                                crit=O.pde_criterion(crit_cfg['name'], beta=crit_cfg.get('beta', 0.1), reduction=crit_cfg.get('reduction', 'mean')) if crit_cfg else None,
+                                norm_cfg=norm_cfg)
     names = O.param_names(st)
     ref = dict(zip(names, torch.autograd.grad(o_total, [st[n] for n in names])))
     worst = 0.0

@@ -158,11 +158,13 @@ def test_point_config_follows_the_config_file(model):
     from deepphysinet_amd import _lib as L
     from deepphysinet_amd.losses import builder_loss
     assert (ph.criterion, ph.beta) == (L.CRIT_MSE, 0.0)
-    assert model._check_pde_criterion(torch.nn.L1Loss()) == (L.CRIT_L1, 0.0)
-    assert model._check_pde_criterion(builder_loss('WeightSmoothL1Loss', beta=0.25)) == (L.CRIT_SMOOTH_L1, 0.25)
-    assert model._check_pde_criterion(dict(name='WeightSmoothL1Loss', beta=0.5)) == (L.CRIT_SMOOTH_L1, 0.5)
+    assert model._check_pde_criterion(torch.nn.L1Loss()) == (L.CRIT_L1, 0.0, False)
+    assert model._check_pde_criterion(builder_loss('WeightSmoothL1Loss', beta=0.25)) == (L.CRIT_SMOOTH_L1, 0.25, False)
+    assert model._check_pde_criterion(dict(name='WeightSmoothL1Loss', beta=0.5)) == (L.CRIT_SMOOTH_L1, 0.5, False)
+    assert model._check_pde_criterion(dict(name='MSELoss', reduction='sum')) == (L.CRIT_MSE, 0.0, True)
+    assert model.point_config(criterion=torch.nn.MSELoss(reduction='sum')).physics().reduce_sum == 1
     assert model.point_config(criterion=torch.nn.L1Loss()).physics().criterion == L.CRIT_L1
-    for bad in (torch.nn.MSELoss(reduction='sum'), torch.nn.HuberLoss(), dict(name='CrossEntropyLoss'), dict(name='MSELoss', reduction='sum')):
+    for bad in (torch.nn.MSELoss(reduction='none'), torch.nn.HuberLoss(), dict(name='CrossEntropyLoss'), dict(name='MSELoss', reduction='none')):
         with pytest.raises(NotImplementedError):
             model._check_pde_criterion(bad)
     # inverse_norm's other branches as the kernel's affine map (:238-243): use_norm False = identity without clip, two-factor min_max

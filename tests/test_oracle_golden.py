@@ -112,7 +112,7 @@ def test_f10_grid_node_points_longest_lead(golden_dir, state):
     assert abs(float(total.detach()) - float(d['total'])) <= 1e-5 * abs(float(d['total']))
 
 
-F12_CASES = {'l1': dict(crit=('L1Loss', 0.0)), 'sl1': dict(crit=('WeightSmoothL1Loss', 0.1)), 'sl1_b2': dict(crit=('WeightSmoothL1Loss', 2.0)),
+F12_CASES = {'l1': dict(crit=('L1Loss', 0.0)), 'mse_sum': dict(crit=('MSELoss', 0.0, 'sum')), 'sl1': dict(crit=('WeightSmoothL1Loss', 0.1)), 'sl1_b2': dict(crit=('WeightSmoothL1Loss', 2.0)),
              'norm': dict(norm='f12_norm_cfg'), 'norm_sq': dict(norm='f12_norm_sq_cfg')}
 
 
@@ -125,7 +125,7 @@ def test_f12_other_criteria_and_norm_branches(golden_dir, case):
     st = O.make_state(requires_grad=True)
     inp = synthetic_inputs(256, tag='inter')
     x, y, t = (inp[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
-    crit = O.pde_criterion(c['crit'][0], beta=c['crit'][1]) if 'crit' in c else None
+    crit = O.pde_criterion(c['crit'][0], beta=c['crit'][1], reduction=c['crit'][2] if len(c['crit']) > 2 else 'mean') if 'crit' in c else None
     total, parts, fn, ph = O.place_one_batch(st, x, y, t, inp['f'], inp['field_data'], inp['coord_data'], inp['forecast_h'], GEO, return_parts=True,
                                              crit=crit, norm_cfg=getattr(O, c['norm'])() if c.get('norm') else None)
     assert _rel(torch.cat(ph, 1).detach().numpy(), d[case + '.fields_phys']) < 2e-6
