@@ -36,12 +36,15 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch
+
+TRIAL_STALL_EXIT = 14        # exit code of a rank whose opt-in end-of-run one-graph trial stalled (the segment form's line has been printed by rank 0)
 
 ALG_FLOP_FWD_JAC = 11_218_944          # algorithmic FLOP per collocation point, fwd + Jacobian
 ALG_FLOP_STEP = 31_887_360             # fwd + Jacobian + bwd
@@ -182,7 +185,12 @@ def main():
     ap.add_argument('--blocks', type=int, default=10, help='timed blocks of --steps replays each; ms_per_step is the median block')
     ap.add_argument('--no-prewarm', action='store_true', help='skip the untimed replays that bring the clock to a steady state (their number depends on timing: '
                                                               'a run that must do a fixed number of optimiser steps -- tests comparing two runs -- switches them off)')
-    ap.add_argument('--no-lead-probe', action='store_true', help='skip the 8-lead probe of the configs[2] code path (about 1 s of GPU work)')
+    ap.add_argument('--no-lead-probe', action='store_true', help='skip the configs[2] legs of the default run: the full-size 61-lead batch (scaled and default initialisation, '
+                                                                 '15 steps each) and the 8-lead probe (about 6 s of GPU work in all)')
+    ap.add_argument('--init', default=None, choices=['default', 'scaled'],
+                    help='weight initialisation: default = PyTorch\'s (what configs[1] is measured on since round 1), scaled = ~1/sqrt(fan_in) uniform '
+                         '(deepphysinet_amd/utils/init.py: raw outputs O(1), inside the clip bounds).  Unset: default for one field, scaled for --leads > 1 '
+                         '(61 random fields on default-initialised weights run into the reference formula\'s NaN within tens of steps)')
     ap.add_argument('--encoder-fp8', nargs='?', const='mx', default=None, choices=['mx', '1'],
                     help='BASELINE configs[4]: the encoder layers\' forward GEMMs on fp8 (OCP e4m3) MFMA, bf16x2 Jacobian path; OFF by default -- it moves '
                          'the PDE losses by 1e-2 ... 2e-1 (tests/test_gpu_parity.py::test_config4_fp8_encoder_workload) and buys no time.  '
@@ -216,9 +224,15 @@ def main():
     from deepphysinet_amd.configs import ncep_config
     from deepphysinet_amd.interface import builder_models
 
+    weights_init = ['default']                    # 'default': PyTorch's initialisation (configs[1], rounds 1-5); 'scaled': deepphysinet_amd.utils.init (lead batches)
+
     def build(prec):
         torch.manual_seed(1)                      # identical random-init weights on every rank
-        m = builder_models(**ncep_config(), precision=prec).to(dev)
+        m = builder_models(**ncep_config(), precision=prec)
+        if weights_init[0] == 'scaled':
+            from deepphysinet_amd.utils.init import scaled_init_
+            scaled_init_(m.physics_net, seed=1)    # raw outputs O(1): every physical value starts inside its clip bounds (the module's header says why)
+        m = m.to(dev)
         # clip_grad_norm_(2.5e7) + Adam(lr 1e-4, weight_decay 1e-4), cfg:151-155; flat gradient buffer in backward-completion order
         opt = m.build_optimizer(max_norm=2.5e7)
         return m, opt
@@ -420,6 +434,16 @@ def main():
             if world > 1 and not all_agree(graphs is not None):          # one rank failed to capture: everybody runs eager
                 graphs = None
                 rec['capture_error'] = rec['capture_error'] or 'another rank failed to capture'
+                # the rank whose capture failed rebuilt its model from the seed while its peers kept parameters that had taken the two
+                # eager steps above -- the ranks would average gradients of different parameters for the rest of the run.  Everybody starts again
+                # from rank 0's parameters and a fresh optimiser state, and the stall watchdog follows the gradient synchroniser that is in use.
+                torch.cuda.synchronize()
+                m, opt = build(prec)
+                sync = D.GradientAllReduce(opt, single_rank_too=one_rank_rccl)
+                D.broadcast_parameters(m.physics_net)
+                segments, staged = make_step(m, opt, n_leads)
+                if dog is not None:
+                    dog.sync = sync
         fn = eager if graphs is None else replayer(graphs)
         if n_leads > 1:
             torch.cuda.synchronize()
@@ -529,6 +553,7 @@ def main():
     # N > 1: a rank that stops making progress ends the job with its rank and the bucket it last queued named (exit code 13)
     dog = D.Watchdog(float(os.environ.get('DPN_BENCH_WATCHDOG_S', '300')), rank) if world > 1 else None
     from deepphysinet_amd import config as C
+    weights_init[0] = args.init or ('scaled' if args.leads > 1 else 'default')
     rec = run(args.prec, args.steps, args.warmup, not args.no_graph)
     # Lead batches: 61 random fields on default-initialised weights is an ill-conditioned start (losses of 4e13, half the points on clip bounds) and within the
     # first few optimiser steps the reference's own vapour formula can produce a NaN at one of the 2.3 M points (q_s = 0.622 e_s / (p - 0.378 e_s) with an
@@ -571,11 +596,13 @@ def main():
         'data': 'synthetic',
         'config': {'workload': (('configs[1]' if world == 1 else 'configs[3] (configs[1] per GPU, data-parallel over %d GPUs, RCCL bucket all-reduces under the backward)' % world) +
                                 ': 0.25deg grid 257x145 = %d collocation points/GPU/step, one field sample per GPU, six PDE residual losses, '
-                                'encoder+hyper-net+fwd+Jacobian+bwd+clip+Adam' % args.points) if args.leads == 1 else
+                                'encoder+hyper-net+fwd+Jacobian+bwd+clip+Adam; fixed collocation batch, sampler outside the timed graph' % args.points) if args.leads == 1 else
                                (('configs[2]' if world == 1 else 'configs[3] (configs[2] per GPU, data-parallel over %d GPUs, RCCL bucket all-reduces under the backward)' % world) +
                                 ': %d forecast-lead field samples x %d collocation points per GPU per step (one batched encoder pass, '
-                                'point kernels field after field), six PDE residual losses, fwd+Jacobian+bwd+clip+Adam' % (args.leads, args.points)),
-                   'leads': args.leads,
+                                'point kernels field after field), six PDE residual losses, fwd+Jacobian+bwd+clip+Adam; fixed collocation batch, sampler outside the timed graph' % (args.leads, args.points)),
+                   'leads': args.leads, 'weights_init': weights_init[0],
+                   'collocation_batch': 'one fixed synthetic batch per rank, replayed every step; the on-device sampler (SURVEY 8 f1) is OUTSIDE the timed graph '
+                                        '(tools/reference_step.py times it inside)',
                    'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world,
                    'step_segments': n_segments,           # N > 1: three backward segments + the optimiser, or one graph with the collectives captured
                    'step_form': rec['step_form'], 'collectives_in_graph': bool(split_step and graphed and n_segments == 1),
@@ -777,10 +804,49 @@ def main():
             del m2
             rec2.clear()
         if not args.no_lead_probe and world == 1 and args.leads == 1:
-            # BASELINE configs[2]-shaped evidence in the same line: 8 forecast-lead field samples x the same points in ONE
-            # captured step, a few replays -- points/s, whether the parameters stayed finite, the step's fraction of the bf16 peak
+            # BASELINE configs[2] at FULL size in the driver's line: 61 forecast-lead field samples x the same points in ONE captured step,
+            # 3 blocks of 5 replays, every block from the state after the capture; field seed shift 0, no redraw.  `scaled` initialisation (utils/init.py) is
+            # the measurement; the default-initialised variant (what `--leads 61` measured in rounds 3-5 after redraws) runs beside it and says whether it
+            # stayed finite.
             rec.clear()
             torch.cuda.empty_cache()
+            from deepphysinet_amd.encoder_ops import check_enc_status as _ces
+            try:                                   # the status words are sticky and the legs below reset them: the headline run's verdict is taken first
+                _ces()
+            except RuntimeError as e:
+                out['encoder_weights_in_range'] = False
+                out['warning'] = (out.get('warning', '') + ' ' + str(e)).strip()
+            full = {}
+            for init_ in ('scaled', 'default'):
+                keep_init, weights_init[0] = weights_init[0], init_
+                try:
+                    nlf = 61
+                    make_leads(nlf)
+                    recf = run(args.prec, 5, 2, not args.no_graph, leads=nlf, blocks=3, steady=False)
+                    mf, dtf = recf['model'], recf['dt']
+                    vf = args.points * nlf * 5 / dtf
+                    full[init_] = {'leads': nlf, 'points_per_step': args.points * nlf, 'ms_per_step': dtf / 5 * 1e3, 'value': vf, 'unit': 'points/s', 'steps': 5,
+                                   'blocks': len(recf['block_s']), 'block_ms_per_step': [round(b_ / 5 * 1e3, 3) for b_ in recf['block_s']], 'hip_graph': recf['graphed'],
+                                   'weights_init': init_, 'field_seed_shift': 0, 'discarded_attempts': [],
+                                   'blocks_finite': all(recf['blocks_finite']) if recf.get('blocks_finite') else None,
+                                   'parameters_finite': bool(all(bool(torch.isfinite(p_).all()) for p_ in mf.physics_net.parameters())),
+                                   'step_frac_of_peak': vf * ALG_FLOP_STEP / MFMA_PEAK_BF16}
+                    if recf['capture_error']:
+                        full[init_]['capture_error'] = recf['capture_error']
+                    del mf
+                    recf.clear()
+                except Exception as e:             # noqa  (the legs beside the headline must never take the line down)
+                    full[init_] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+                    torch.cuda.synchronize()
+                finally:
+                    weights_init[0] = keep_init
+                    lead_batches.pop(61, None)
+                    torch.cuda.empty_cache()
+                    from deepphysinet_amd.encoder_ops import reset_enc_status
+                    reset_enc_status()             # (sticky: a default-initialised lead batch that went non-finite must not mark the headline run)
+            out['lead_batch_full'] = dict(full.get('scaled', {}), default_init_variant=full.get('default'),
+                                          note='BASELINE configs[2]: 61 leads x %d points in one captured step; `bench.py --leads 61` is the long form of the same run' % args.points)
+            # the same code path at 8 leads, kept for continuity with round 5's line
             nl = 8
             make_leads(nl)
             rec3 = run(args.prec, 3, 1, not args.no_graph, leads=nl, blocks=3, steady=False)
@@ -819,7 +885,7 @@ def main():
         from deepphysinet_amd.encoder_ops import check_enc_status
         try:
             check_enc_status()                     # an encoder weight left the range of the f16 hi+lo operand split during the run (or went non-finite)?
-            out['encoder_weights_in_range'] = True
+            out['encoder_weights_in_range'] = out.get('encoder_weights_in_range', True)
         except RuntimeError as e:
             out['encoder_weights_in_range'] = False
             out['warning'] = (out.get('warning', '') + ' ' + str(e)).strip()
@@ -828,16 +894,21 @@ def main():
     # collectives) against "ONE graph with the collectives captured" (the two swap places from box to box on a one-rank group and
     # nobody has timed them on xGMI).  Tried LAST, with the finished line of the segment form in hand: a capture error keeps the segment form; a STALL of
     # the captured collectives (RCCL kernels replayed from a graph across N processes have never run here) makes every rank's watchdog print what it
-    # has -- rank 0 the finished line, `step_form_trial.error` saying where it stalled -- and end the process with exit code 0.  If the one-graph form is
+    # has -- rank 0 the finished line, `step_form_trial.error` saying where it stalled -- and end the process with exit code 14 (TRIAL_STALL_EXIT: non-zero, so that
+    # torchrun and the driver see a wedged collective; the printed line is the valid segment-form measurement).  If the one-graph form is
     # more than 1 % faster over 20 replays, the ten blocks are timed again in it and the line reports it (the segment form's numbers stay in
     # `collective.step_form_trial`).  DPN_BENCH_CAPTURE_COLLECTIVES=0/1 pins the form.  OPT-IN (DPN_BENCH_TRY_FORMS=1) since the end of round 5: a capture that
     # contains collectives can take the whole process down from ProcessGroupNCCL's watchdog thread (distributed.quiesce_for_capture: found, reproduced and
     # worked around here), and nothing of that kind may stand between an 8-GPU run and its line.
-    stash = {'line': None, 'printed': False}
+    stash = {'line': None, 'printed': False, 'lock': threading.Lock()}
     tdog = None
     want_trial = (rec.get('graphed') and split_step and not one_graph_collectives and os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') is None
                   and rec.get('sync') is not None and torch.distributed.get_backend() == 'nccl' and rec.get('graphs') is not None and len(rec['graphs']) > 1
                   and os.environ.get('DPN_BENCH_TRY_FORMS', '0') == '1')
+    if os.environ.get('DPN_BENCH_TRY_FORMS', '0') == '1' and not want_trial and rank == 0:
+        # asked for and not run must be visible in the line (the default single-rank flow has released the measured step for the other-precision
+        # and lead-batch runs by now: pass --no-alt --no-lead-probe with DPN_BENCH_RCCL_ONE_RANK=1)
+        coll['step_form_trial'] = {'skipped': 'the measured step is no longer held (--no-alt --no-lead-probe keep it) or it was not a captured multi-segment RCCL step'}
     if want_trial:
         trial = {'segments_ms': None, 'one_graph_ms': None, 'error': None, 'segment_form_result': None}
         phase = ['start']
@@ -849,12 +920,14 @@ def main():
             trial['error'] = None
 
         def on_stall(msg):
-            if rank == 0 and not stash['printed']:
-                line = json.loads(stash['line'])
-                line['collective']['step_form_trial']['error'] = 'stalled in: %s -- the segment form\'s line is reported' % phase[0]
-                print(json.dumps(line), flush=True)
+            with stash['lock']:                    # the main thread prints under the same lock: exactly one line leaves the process
+                if rank == 0 and not stash['printed']:
+                    line = json.loads(stash['line'])
+                    line['collective']['step_form_trial']['error'] = 'stalled in: %s -- the segment form\'s line is reported (exit code %d)' % (phase[0], TRIAL_STALL_EXIT)
+                    print(json.dumps(line), flush=True)
+                    stash['printed'] = True
             print('[bench] rank %d: the one-graph trial stalled (%s); the segment form\'s result stands' % (rank, phase[0]), file=sys.stderr, flush=True)
-            os._exit(0)
+            os._exit(TRIAL_STALL_EXIT)             # NON-ZERO: a launcher must be able to tell a wedged collective from a clean run; the line printed above is still the valid segment-form measurement
         tdog = D.Watchdog(float(os.environ.get('DPN_BENCH_TRIAL_WATCHDOG_S', '90')), rank, sync=rec['sync'], on_stall=on_stall)
         fn_seg, block_time, all_agree = rec['fn'], rec['block_time'], rec['all_agree']
         one = None
@@ -915,8 +988,10 @@ def main():
         phase[0] = 'the final barrier'
         tdog.beat(phase[0])
     if rank == 0:
-        print(json.dumps(out), flush=True)
-        stash['printed'] = True
+        with stash['lock']:
+            if not stash['printed']:
+                print(json.dumps(out), flush=True)
+                stash['printed'] = True
         if not out['encoder_weights_in_range'] and args.leads == 1:
             raise SystemExit('bench.py: ' + out['warning'])          # the line above is printed for the record; the run is not a measurement
     if world > 1 or one_rank_rccl:

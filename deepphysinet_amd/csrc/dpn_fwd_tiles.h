@@ -528,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void dpn_fwd_tiles_kernel(FwdArgs a) {
         const int64_t pt = (tile0 + h) * 32 + j;
         if (pt < a.n) {
             const float const0 = vec[kNumVecs * 256];          // wo . bf2 + bo + 2 wo . cvec
+            if (vec[kNumVecs * 256 + 1] != 1.0f) __builtin_trap();     // the packed stream is not in the fused five-GEMM form (its tag sits behind const0): wrong fields otherwise
             const float o = (red[0 * 64 + h * 32 + j] + red[1 * 64 + h * 32 + j]) + (red[2 * 64 + h * 32 + j] + red[3 * 64 + h * 32 + j]);
             a.out_n[pt * 6 + net] = o + const0 + (a.ref ? a.ref : a.coord_data)[pt * 6 + net];           // + ref_data (variable_net.py:86)
         }

@@ -895,6 +895,9 @@ __global__ __launch_bounds__(256, 1) void dpn_fwd_kernel(FwdArgs a) {
     }
     // ---------------- fc1: pre2 = W1 . c + bf1 ; a = relu ; out = u.a + 2 wo.c + const ; t2 = m2 (.) u -> actA ; M2 -> saved
     const float const0 = lds_read_f32(lds_vec + kNumVecs * 256 * 4);
+    // the packed stream carries its form behind const0 (dpn_pack_vectors): this kernel multiplies the seven-GEMM stream.  A buffer packed in the fused
+    // form (or a DPN_FWD_KERNEL switch flipped between pack and launch) would give silently wrong fields: trap instead.
+    if (lds_read_f32(lds_vec + (kNumVecs * 256 + 1) * 4) != 0.f) __builtin_trap();
     float adot = 0.f;
     auto epi3 = [&](const int T) __attribute__((always_inline)) {
         Frag<1> mk0, mk1;

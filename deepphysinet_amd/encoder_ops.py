@@ -343,8 +343,15 @@ class _DataEmbeddingFn(torch.autograd.Function):
         # The stack node's weight-gradient launch has computed dW, db (and the learnable tokens' gradient) from ITS d x0 -- valid only when that is
         # the cotangent arriving here, i.e. x0 had exactly one consumer and no hook rewrote its gradient: otherwise (a second use of
         # `last_embedding`, a tensor hook) the incoming g differs and the gradients are computed from it below.
-        if done is not None and done.get('grads') is not None and done.get('dx0_ptr') != g.data_ptr():
-            done['grads'] = done['g_tok'] = None
+        #  The pointer alone does not prove it: autograd's input buffer may ACCUMULATE a second consumer's gradient in place into d x0 when it
+        # holds the only reference, and an in-place tensor hook keeps the pointer too.  The stack node therefore KEEPS a reference to d x0 (the engine
+        # then never accumulates into it in place: it adds out of place, a new pointer) and records its version counter, which every in-place write
+        # bumps (views share the counter).
+        if done is not None and done.get('grads') is not None:
+            kept = done.pop('dx0', None)
+            same = kept is not None and kept.data_ptr() == g.data_ptr() and g._version == done.get('dx0_version') and kept._version == done.get('dx0_version')
+            if not same:
+                done['grads'] = done['g_tok'] = None
         if done is not None and done.get('grads') is not None:       # computed by the stack node's weight-gradient launch
             dw, db = done['grads']
             done['grads'] = None
@@ -827,7 +834,7 @@ class _EncoderStackFn(torch.autograd.Function):
             batch.append((g_emb, emb['xu'], dwt, dbt))
             keep.append(g_emb)
             emb['grads'] = (dwt, dbt)
-            emb['dx0_ptr'] = dx0.data_ptr()
+            emb['dx0'], emb['dx0_version'] = dx0, dx0._version      # see _DataEmbeddingFn.backward: identity AND version of the cotangent
         # every weight gradient of the stack and the LayerNorm parameter sums: ONE launch (dpn_wgrad16; plus its slice reduction for batches
         # of fields)
         flush(False)

@@ -64,12 +64,13 @@ class InterfacePhysics(nn.Module):
                 mean.append(float(nf[0])), std.append(float(nf[1])), sq.append(None)
             clipv.append(True)
         lf = loss_factor or self.train_cfg['losses']['loss_factor']
+        big = 3.4028234663852886e38
+        bound = lambda k, i: (float(self.obs_norm_cfg[k]['bound'][i]) if ('bound' in self.obs_norm_cfg[k] and self.obs_norm_cfg[k].get('use_norm', True))
+                              else (-big, big)[i])
+        bounds = tuple((bound(k, 0), bound(k, 1)) for k in OBS_ORDER)        # part of the key: a changed clip bound alone must rebuild the configuration
         key = (self.dx, self.dy, self.lon_size, self.lat_size, self.pred_t_span, bool(self.with_clip), self.precision,
-               tuple(float(lf[k]) for k in LOSS_ORDER), tuple(mean), tuple(std), tuple(clipv), crit_kind, crit_beta, tuple(sq), crit_sum)
+               tuple(float(lf[k]) for k in LOSS_ORDER), tuple(mean), tuple(std), tuple(clipv), crit_kind, crit_beta, tuple(sq), crit_sum, bounds)
         if self._cfg_cache is None or self._cfg_cache[0] != key:
-            big = 3.4028234663852886e38
-            bound = lambda k, i: (float(self.obs_norm_cfg[k]['bound'][i]) if ('bound' in self.obs_norm_cfg[k] and self.obs_norm_cfg[k].get('use_norm', True))
-                                  else (-big, big)[i])
             cfg = PointConfig(dx=self.dx, dy=self.dy, lon_size=self.lon_size, lat_size=self.lat_size, pred_t_span=self.pred_t_span,
                               mean=tuple(mean), std=tuple(std),
                               clip_lo=tuple(bound(k, 0) for k in OBS_ORDER), clip_hi=tuple(bound(k, 1) for k in OBS_ORDER),

@@ -308,13 +308,16 @@ def test_watchdog_ends_a_stuck_rank_with_its_name_and_bucket():
              'w.stop(); time.sleep(1.0); print("alive")\n' % ROOT)
     r2 = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, timeout=120)
     assert r2.returncode == 0 and 'alive' in r2.stdout, (r2.returncode, r2.stderr[-500:])
-    # a stall with a handler (bench.py's trial of the one-graph form): the handler decides -- here it prints what it holds and ends the process with 0
+    # a stall with a handler (bench.py's trial of the one-graph form): the handler decides -- it prints what it holds and ends the process with bench.TRIAL_STALL_EXIT = 14:
+    # NON-ZERO, a process that has touched the GPU and gave up on a collective must not look like a clean run
     code3 = ('import os, sys, time; sys.path.insert(0, %r)\n'
              'from deepphysinet_amd.distributed import Watchdog\n'
              'def handler(msg):\n'
-             '    print("stashed line", flush=True); os._exit(0)\n'
+             '    print("stashed line", flush=True); os._exit(14)\n'
              'w = Watchdog(0.4, rank=1, on_stall=handler)\n'
              'w.beat("first replays of the one-graph form")\n'
              'time.sleep(30)\n' % ROOT)
     r3 = subprocess.run([sys.executable, '-c', code3], capture_output=True, text=True, timeout=120)
-    assert r3.returncode == 0 and 'stashed line' in r3.stdout and 'first replays of the one-graph form' in r3.stderr, (r3.returncode, r3.stderr[-500:])
+    assert r3.returncode == 14 and 'stashed line' in r3.stdout and 'first replays of the one-graph form' in r3.stderr, (r3.returncode, r3.stderr[-500:])
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'TRIAL_STALL_EXIT = 14' in src and 'os._exit(0)' not in src          # bench.py's own handler follows the convention

@@ -181,6 +181,10 @@ def test_point_config_follows_the_config_file(model):
         model.obs_norm_cfg['pres']['norm_factor'] = [80000.0, 100000.0, 3.0]      # the squared three-factor form (:244-247)
         ph3 = model.point_config().physics()
         assert (ph3.sq_on[2], ph3.sq_add[2], ph3.std[2]) == (1, 3.0, 20000.0) and list(ph3.sq_on)[:2] == [0, 0]
+        # a changed clip BOUND alone rebuilds the cached configuration (the bounds were missing from the cache key)
+        model.obs_norm_cfg['t2']['bound'] = [150.0, 400.0]
+        ph4 = model.point_config().physics()
+        assert (ph4.clip_lo[3], ph4.clip_hi[3]) == (150.0, 400.0)
     finally:
         model.obs_norm_cfg.clear()
         model.obs_norm_cfg.update(keep)

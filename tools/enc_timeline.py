@@ -7,7 +7,7 @@ usage: enc_timeline.py [variant name, default enctl]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['DPN_LIB'] = os.path.join(ROOT, 'deepphysinet_amd', 'libdpn_hip_%s.so' % (sys.argv[1] if len(sys.argv) > 1 else 'enctl'))
+os.environ['DPN_LIB'] = os.path.join(ROOT, 'tools', '_variants', 'libdpn_hip_%s.so' % (sys.argv[1] if len(sys.argv) > 1 else 'enctl'))
 import numpy as np
 import torch
 from bench import synth_batch

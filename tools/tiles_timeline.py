@@ -7,7 +7,7 @@ split into multiply phases (the five GEMM loops of the fused form), epilogue / f
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['DPN_LIB'] = os.path.join(ROOT, 'deepphysinet_amd', 'libdpn_hip_%s.so' % (sys.argv[2] if len(sys.argv) > 2 else 'tl'))
+os.environ['DPN_LIB'] = os.path.join(ROOT, 'tools', '_variants', 'libdpn_hip_%s.so' % (sys.argv[2] if len(sys.argv) > 2 else 'tl'))
 os.environ['DPN_FWD_KERNEL'] = 'tiles'
 import torch
 from bench import synth_batch

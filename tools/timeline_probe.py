@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-step shader-clock timeline of dpn_fwd_kernel (experiment build with -DDPN_TIMELINE).
 
-    python tools/timeline_probe.py --build          # here (hipcc cross-compiles): deepphysinet_amd/libdpn_hip_timeline.so
+    python tools/timeline_probe.py --build          # here (hipcc cross-compiles): tools/_variants/libdpn_hip_timeline.so
     python tools/timeline_probe.py [bf16|bf16x2]    # on the GPU box: cycles per pipeline step, by stage, for a sample of workgroups
 
 Stamp i of a wave = s_memtime at the start of pipeline step i - 2 (0 = kernel entry, 1 = prologue done, 62 = exit); the steps are the
@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, 'deepphysinet_amd', 'libdpn_hip_timeline.so')
+LIB = os.path.join(ROOT, 'tools', '_variants', 'libdpn_hip_timeline.so')
 
 
 def build(extra=()):
@@ -27,6 +27,7 @@ def build(extra=()):
         cmd = ['hipcc', *B.COMMON, *flags, '-DDPN_TIMELINE', *extra, '-I' + os.path.join(ROOT, 'include'), '-c', src, '-o', o]
         subprocess.run(cmd, check=True)
         objs.append(o)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB], check=True)
     print(LIB)
 

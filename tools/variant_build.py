@@ -1,7 +1,7 @@
 """Experiment builds of the library: only ONE unit (default: the point unit) is recompiled with extra -D flags, the other objects come from
 the product build.
 
-    python tools/variant_build.py NAME [--unit=I] [-DFLAG ...]      ->  deepphysinet_amd/libdpn_hip_NAME.so   (select it with DPN_LIB=<path>)
+    python tools/variant_build.py NAME [--unit=I] [-DFLAG ...]      ->  tools/_variants/libdpn_hip_NAME.so   (select it with DPN_LIB=<path>)
     (--unit=I: index into deepphysinet_amd.build.UNITS; 5 = the row-local encoder nodes, csrc/dpn_encoder_chain.hip)
 """
 import os, subprocess, sys
@@ -20,7 +20,8 @@ def build(name, extra, unit=0):
     src, flags, base = B.UNITS[unit]
     o = os.path.join(obj, 'var_%s_%s' % (name, base))
     subprocess.run(['hipcc', *B.COMMON, *flags, *extra, '-I' + os.path.join(ROOT, 'include'), '-c', src, '-o', o], check=True)
-    lib = os.path.join(B.HERE, 'libdpn_hip_%s.so' % name)
+    os.makedirs(os.path.join(ROOT, 'tools', '_variants'), exist_ok=True)          # experiment libraries stay OUT of the package directory
+    lib = os.path.join(ROOT, 'tools', '_variants', 'libdpn_hip_%s.so' % name)
     subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', o, *[os.path.join(obj, u[2]) for u in others], '-o', lib], check=True)
     return lib
 
