@@ -964,7 +964,7 @@ def test_config2_eight_leads_of_4096_points_vs_the_oracle_loop():
             src = int(torch.nonzero(~flipped).flatten()[0])
             c = {k_: (v.clone() if torch.is_tensor(v) else v) for k_, v in b.items()}
             for k_ in ('x', 'y', 't', 'f', 'coord_data', 'labels'):
-                c[k_][idx] = c[k_][src]
+                c[k_][idx] = c[k_][src].clone()
             b = c
         clean.append(b)
     # (2) the north-star bars on the batch whose flipped points are replaced
