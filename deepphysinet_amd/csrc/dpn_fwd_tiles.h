@@ -95,6 +95,9 @@ DEV void mma3(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16& acc) {
 #ifndef TS_DEFER_SAVES
 #define TS_DEFER_SAVES 1
 #endif
+#ifndef TS_SCHED_GROUPS
+#define TS_SCHED_GROUPS 0
+#endif
 constexpr int kPF = TS_PF;
 template <int NS, int NT> struct Head { u32x4 a[kPF - 1][NT][NS]; };
 
@@ -138,7 +141,7 @@ DEV void gemm_head(const char* wg, const int lane, Head<NS, NT>& H) {
 }
 // side(ks): work of the PREVIOUS layer that nobody waits for (its saved-state transposes and stores), issued k-step by k-step in the shadow
 // of this layer's MFMAs instead of in the serial epilogue between two barriers
-template <int NS, int NK, int NT, bool SWAP = false, class Side = NoSide, bool PIN = true>
+template <int NS, int NK, int NT, bool SWAP = false, class Side = NoSide, bool PIN = true, bool SG = PIN>
 DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>& H, f32x16 (&acc)[2][2], const Side& side = Side()) {
     static_assert(NK >= kPF, "k-steps per chunk");
     WSrc<NS, NK, NT> src;
@@ -165,6 +168,15 @@ DEV void gemm(const char* wg, const char* xl, const int lane, const Head<NS, NT>
     for (int ks = 0; ks < NK; ++ks) {
         if (ks + kPF - 1 < NK) src.next(A[(ks + kPF - 1) % kPF]);
         if (ks + 1 < NK) loadB(ks + 1, (ks + 1) & 1);
+#if TS_SCHED_GROUPS
+        // (SG: the forward kernels; the backward stage-1 kernel lives on 168 registers and spills with the longer live ranges)
+        // the next k-step's B fragments are READ (4 ds_read_b128) in front of this k-step's MFMAs, not behind them where hipcc's scheduler sinks them to
+        // shorten their live ranges (the read latency is then exposed in front of every k-step when no second multiplying wave covers it)
+        if (SG && ks + 1 < NK) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NS, 0);        // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * (NS == 2 ? 3 : 1), 0);   // MFMA
+        }
+#endif
 #if TS_PRIO == 1
         __builtin_amdgcn_s_setprio(1);        // the multiplying wave wins issue arbitration against its SIMD partner's loads / packing
 #endif
@@ -316,6 +328,85 @@ DEV void dpe_tile(float (&d)[16], const Args& a, const int c, const int t, const
         ts_sincos<NS>(xi * fr, s, co);
         d[r] = fr * co;
         d[r + 1] = -fr * s;
+    }
+}
+// ---- Round 6: the same features with their memory operands FRONT-LOADED (used by dpn_fwd_pp_kernel).  pe3_frag / pe6_frag_dot / dpe_tile above fetch the lane's
+// coordinate (through a pointer selected by the wave's k-step) and one frequency per angle INSIDE every fragment; the *_x forms take the coordinate and the
+// four frequencies of a fragment as values, so that the caller issues ALL loads of a phase first, then the arithmetic -- identical operations in identical order
+// (bit-identical results: tools/fwd_dump.py).  Measured: in the ping-pong kernel, where a service interval is ONE wave per SIMD with nothing to hide a latency
+// behind, a fragment of four angles went from 1 350 to ~900 cycles (the arithmetic alone is 4 x 146: tools/microbench/valu_ilp.hip); in dpn_fwd_tiles_kernel and
+// dpn_bwd_tiles_kernel the same change measured neutral to -1 % (the partner workgroup's waves cover the latencies there) and they keep the forms above.
+template <class Args>
+DEV float load_xi(const Args& a, const int c, const int64_t pc) {          // x / dx / (lon-1): two fp32 divisions (interface_physics.py:324-326); t: one
+    // all three coordinates are fetched and the VALUE is selected: a pointer selected by the (wave-uniform, run-time) c makes hipcc index the kernel-argument
+    // block, which then lives in scratch memory (136 bytes of private segment and a scratch load per use -- seen, round 6)
+    const float xr = a.x[pc], yr = a.y[pc], tr = a.t[pc];
+    const float raw = (c == 0) ? xr : (c == 1) ? yr : tr;
+    const float d1 = (c == 0) ? a.geo.dx : (c == 1) ? a.geo.dy : a.geo.pred_t_span;
+    const float d2 = (c == 0) ? a.geo.lon_m1 : (c == 1) ? a.geo.lat_m1 : 1.0f;
+    return raw / d1 / d2;
+}
+DEV f32x4 load_fr4(const float* freqs, const int idx) { return *reinterpret_cast<const f32x4*>(freqs + idx); }     // idx % 4 == 0: 16-byte aligned
+template <int NS>
+DEV void pe3_frag_x(Frag<NS>& f, const float xi, const f32x4 fr) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s, co;
+        ts_sincos<NS>(xi * fr[q], s, co);
+        frag_set2<NS>(f, q, s, co);
+    }
+}
+template <int NS>
+DEV void pe6_frag_x(Frag<NS>& f, const float v, const f32x4 fr, const float g = 1.0f) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s, co;
+        ts_sincos<NS>(v * fr[q], s, co);
+        frag_set2<NS>(f, q, g * s, g * co);
+    }
+}
+template <int NS>
+DEV void pe6_frag_dot_x(Frag<NS>& f, const float v, const f32x4 fr, const float* bv8, float& dot) {      // bv8: the fragment's eight entries of the 192-vector (LDS)
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(bv8);
+    const f32x4 b0 = b4[0], b1 = b4[1];
+    const float bb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s, co;
+        ts_sincos<NS>(v * fr[q], s, co);
+        frag_set2<NS>(f, q, s, co);
+        dot = fmaf(s, bb[2 * q], dot);
+        dot = fmaf(co, bb[2 * q + 1], dot);
+    }
+}
+template <int NS>
+DEV void z0_frag_x(Frag<NS>& f, const float xi, const f32x4 fr4, const float g, const float gjc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float fr = fr4[q];
+        float s, co;
+        ts_sincos<NS>(xi * fr, s, co);
+        const float gf = gjc * fr;
+        frag_set2<NS>(f, q, fmaf(g, s, gf * co), fmaf(g, co, -gf * s));
+    }
+}
+// Jacobian contraction of one gpe tile pair (t = 0, 1) of column tile p with d pe3 / d xi_c: jc += sum_r acc[t][r] * d[r], r ascending, t outer -- the order
+// of dpe_tile + the caller's loop.  fr[kq] = the four frequencies 8 kq + 4 h .. + 3 of the coordinate's k-step kq
+template <int NS>
+DEV void jac_contract_x(float& jc, const f32x16 (&acc_t)[2], const float xi, const f32x4 (&fr)[4]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float d[16];
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+            const float f = fr[(2 * t + (rp >> 2)) & 3][rp & 3];
+            float s, co;
+            ts_sincos<NS>(xi * f, s, co);
+            d[2 * rp] = f * co;
+            d[2 * rp + 1] = -f * s;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) jc = fmaf(acc_t[t][r], d[r], jc);
     }
 }
 }  // namespace ts

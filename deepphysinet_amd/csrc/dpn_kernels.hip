@@ -1303,6 +1303,7 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 
 #if DPN_HAS_POINT
 #include "dpn_fwd_tiles.h"                                       // tile-split forward / backward kernels (the hi+lo mode's default)
+#include "dpn_fwd_pp.h"                                          // round 6: the ping-pong form of the tile-split forward (one persistent 8-wave workgroup per CU)
 #endif
 
 #if DPN_HAS_REST
@@ -2489,6 +2490,22 @@ static inline int order_reversed(const char* knob) {          // read on every l
     const char* e = getenv(knob);
     return e && e[0] == 'r' ? 1 : 0;                     // "reverse"
 }
+#ifndef DPN_FWD_PP_DEFAULT
+#define DPN_FWD_PP_DEFAULT 0
+#endif
+static inline bool use_pp() {
+    const char* e = getenv("DPN_FWD_PP");
+    return e ? (e[0] == '1') : (DPN_FWD_PP_DEFAULT != 0);
+}
+static inline int cu_count() {                          // compute units of the current device (one persistent workgroup each)
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
 static inline bool use_tiles(const char* knob, int prec, bool has_pe_in) {
     const char* force = getenv(knob);
     return (force ? (force[0] == 't') : (prec == 2)) && !has_pe_in;
@@ -2635,6 +2652,15 @@ static int fwd_launch(const float* x, const float* y, const float* t, const floa
     // and the single-bf16 mode stay on the ring kernel (one bf16 product per fragment pair cannot pay for the doubled weight stream).
     // DPN_FWD_KERNEL=ring|tiles overrides (A/B measurements, bitwise comparison of the two kernels in the tests).
     if (use_tiles("DPN_FWD_KERNEL", prec, pe_in != nullptr)) {    // (expects the FUSED packed form: dpn_fwd_form)
+        // Training shape (saved state AND Jacobian wanted) in the hi+lo mode: the ping-pong form (dpn_fwd_pp.h), bit-identical results.  DPN_FWD_PP=0|1
+        // overrides (read per call, like DPN_FWD_KERNEL: the tests compare the two forms inside one process).
+        if (prec == 2 && saved && jac_n && use_pp()) {
+            const int64_t items = (a.n_pad / 128) * n_nets;
+            const int cus = cu_count();
+            const dim3 gridp((unsigned)(items < cus ? items : cus));
+            hipLaunchKernelGGL(dpn_fwd_pp_kernel<2>, gridp, dim3(512), 0, s, a, n_nets);
+            return ck(hipGetLastError());
+        }
         const dim3 grid64((unsigned)(a.n_pad / 64), n_nets);
         if (prec == 1) hipLaunchKernelGGL(dpn_fwd_tiles_kernel<1>, grid64, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(dpn_fwd_tiles_kernel<2>, grid64, dim3(256), 0, s, a);

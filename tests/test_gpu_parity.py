@@ -1353,6 +1353,56 @@ def test_tile_split_kernels_against_the_ring_kernels(n, prec):
 
 
 
+def test_ping_pong_forward_is_bitwise_the_tile_split_forward():
+    """Round 6: dpn_fwd_pp_kernel (csrc/dpn_fwd_pp.h: one persistent 8-wave workgroup per CU, two 4-wave groups in opposite phases; opt-in, DPN_FWD_PP=1)
+    computes exactly what dpn_fwd_tiles_kernel computes, in the same order per output tile: fields, Jacobian and every byte of the saved state are
+    IDENTICAL -- at the full grid (seven items per workgroup, 40 workgroups one item short), at sizes with a ragged last tile, at one item per workgroup
+    and fewer items than compute units, and at a single point."""
+    import deepphysinet_amd as dpn
+    from deepphysinet_amd import _lib as L, point_path as PP
+    dev = _dev()
+    m = _model('bf16x2')
+    cfg = m.point_config()
+    lib = L.load()
+    old = {k: os.environ.get(k) for k in ('DPN_FWD_KERNEL', 'DPN_FWD_PP')}
+    try:
+        os.environ['DPN_FWD_KERNEL'] = 'tiles'
+        for n in (257 * 145, 5197, 1037, 129, 1):
+            inp = _gpu(synthetic_inputs(n, tag='inter'))
+            with torch.no_grad():
+                heads, evec, statics = m.physics_net.field_weights(inp['field_data'], inp['forecast_h'])
+                x_, y_, t_ = (PP._f32c(inp[k]).reshape(-1) for k in ('x', 'y', 't'))
+                cd_ = PP._f32c(inp['coord_data'])
+                st = [PP._f32c(s_) for s_ in statics]
+                ws = PP._Workspace(n, cfg.prec, dev)
+                nets = PP._net_ptrs(PP._f32c(heads), PP._f32c(evec), st)
+                s = PP._stream()
+                L.check(lib.dpn_pack_weights(nets, cfg.prec, PP._ptr(ws.packed), s), 'pack')
+                geo = cfg.geometry()
+                fr = PP._freqs(dev)
+                res = []
+                for pp in ('0', '1'):
+                    os.environ['DPN_FWD_PP'] = pp
+                    out_n = torch.full((n, 6), 7.0, device=dev)
+                    jac_n = torch.full((n, 6, 3), 7.0, device=dev)
+                    saved = torch.full((ws.sizes.saved,), 0x5a, dtype=torch.uint8, device=dev)
+                    L.check(lib.dpn_fwd(PP._ptr(x_), PP._ptr(y_), PP._ptr(t_), None, PP._ptr(cd_), n, PP._ptr(fr), ctypes.byref(geo), PP._ptr(ws.packed),
+                                        cfg.prec, PP._ptr(out_n), PP._ptr(jac_n), PP._ptr(saved), s), 'dpn_fwd')
+                    torch.cuda.synchronize()
+                    res.append((out_n, jac_n, saved))
+                (o0, j0, s0), (o1, j1, s1) = res
+                assert bool(torch.isfinite(o0).all()) and float(o0.abs().max()) != 7.0
+                assert torch.equal(o0, o1), ('fields', n)
+                assert torch.equal(j0, j1), ('jacobian', n)
+                assert torch.equal(s0, s1), ('saved state', n, int((s0 != s1).sum()))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_encoder_guards_of_the_fused_path():
     """(1) a weight outside the f16 hi+lo split's range (|w| >= 32768) raises at the next check_enc_status() -- which the training loop
     and bench.py call where they synchronise anyway -- instead of surfacing later as inf / NaN; (2) a model whose parameters are not fp32 on the
