@@ -124,6 +124,58 @@ def write_f12(m, run_pde, builder_loss, inter):
     np.savez_compressed(os.path.join(HERE, 'f12_criteria_and_norm_branches.npz'), **out)
 
 
+def f13_stride(numel):
+    """Sampling stride of fixture F13: every tensor contributes at most ~128 entries (all of them when it is smaller)."""
+    return max(1, numel // 128)
+
+
+def write_f13(m, net, cfg, builder_loss, inter, margin):
+    """F13: ELEMENT-wise pins where F6 / F8 hold norms only.  (a) every parameter gradient of the data loss (F6's run), sampled
+    with stride f13_stride(numel); (b) one optimiser step of F8's loss (data + PDE(inter) + PDE(margin), clip 2.5e7, Adam(1e-4, wd 1e-4)): the sampled
+    entries of (post - pre) for every parameter, and of the gradient that produced them (so that a test can tell a rounding-level gradient, whose Adam
+    step has an arbitrary sign, from a real one)."""
+    out = {}
+    net.zero_grad()
+    crit_d = builder_loss(name='WeightSmoothL1Loss', beta=0.1)
+    pe = m.encoding_coord(margin['x'], margin['y'], margin['t'], m.pred_t_span)
+    fn = net(margin['field_data'], pe, margin['coord_data'], margin['forecast_h'])
+    dl = crit_d(torch.cat(fn, dim=1), margin['labels']).float() * 1e6
+    dl.backward()
+    names = [k for k, _ in net.named_parameters()]
+    out['names'] = np.array(names)
+    out['dl.loss'] = np.array(float(dl), np.float64)
+    for k, p in net.named_parameters():
+        out['dl.g.' + k] = p.grad.detach().flatten()[::f13_stride(p.numel())].numpy().copy()
+        out['dl.gmax.' + k] = np.array(float(p.grad.detach().abs().max()), np.float64)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=1e-4)
+    net.zero_grad()
+    pe = m.encoding_coord(margin['x'], margin['y'], margin['t'], m.pred_t_span)
+    fn = net(margin['field_data'], pe, margin['coord_data'], margin['forecast_h'])
+    loss = crit_d(torch.cat(fn, dim=1), margin['labels']).float() * 1e6
+    crit = builder_loss(name='MSELoss')
+    lf = cfg.config['train_cfg']['losses']['loss_factor']
+    m.with_clip = True
+    for inp_, pre in ((inter, 'inter'), (margin, 'margin')):
+        x = inp_['x'].clone().requires_grad_(True)
+        y = inp_['y'].clone().requires_grad_(True)
+        t = inp_['t'].clone().requires_grad_(True)
+        loss = loss + m.place_one_batch(x, y, t, inp_['f'], inp_['field_data'], inp_['coord_data'], inp_['forecast_h'],
+                                        crit, lf, global_step=2, local_rank=0, device='cpu', summary=None, prefix=pre)
+    loss.backward()
+    gnorm = torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=2.5e7)
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    opt.step()
+    out['step.loss'], out['step.gnorm'] = np.array(float(loss), np.float64), np.array(float(gnorm), np.float64)
+    for k, p in net.named_parameters():
+        st = f13_stride(p.numel())
+        out['step.delta.' + k] = (p.detach() - sd0[k]).flatten()[::st].numpy().copy()
+        out['step.g.' + k] = grads[k].flatten()[::st].numpy().copy()
+        out['step.gmax.' + k] = np.array(float(grads[k].abs().max()), np.float64)
+    net.load_state_dict(sd0)
+    np.savez_compressed(os.path.join(HERE, 'f13_elementwise_data_loss_and_step.npz'), **out)
+
+
 def write_f11():
     """F11: get_coriolis (dataset/physics_dataset.py:521-526) called on the reference class itself (it never touches `self`): the
     latitude forms its two callers build -- margin points `begin_lat + y_rand * 0.25` with integer node indices (:336-337, :418) and
@@ -238,6 +290,10 @@ def main():
         write_f12(m, run_pde, builder_loss, inter)
         print('f12 written')
         return
+    if '--only-f13' in sys.argv:
+        write_f13(m, net, cfg, builder_loss, inter, synthetic_inputs(N, tag='margin', margin=True))
+        print('f13 written')
+        return
 
     # ---- F3/F4/F5: VariableNet outputs, Jacobian, residuals (a6-a16), fp32, clip on/off
     for wc in (True, False):
@@ -299,6 +355,7 @@ def main():
                         post_norms=np.array([float(v.detach().double().norm()) for v in post.values()]),
                         delta_norms=np.array([float((v.detach() - sd0[k]).double().norm()) for k, v in post.items()]))
     net.load_state_dict(sd0)
+    write_f13(m, net, cfg, builder_loss, inter, margin)
 
     # ---- F5b: fp64 run of the reference (tolerance calibration)
     m64 = m.double()

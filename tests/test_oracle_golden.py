@@ -230,3 +230,56 @@ def test_f8_optimiser_step(golden_dir):
         assert abs(float(st[n].detach().double().norm()) - ref_post[n]) <= 1e-6 * ref_post[n] + 1e-12, n
         dn = float((st[n].detach() - before[n]).double().norm())
         assert abs(dn - ref_delta[n]) <= 2e-3 * ref_delta[n] + 1e-12, n
+
+
+def _f13_stride(numel):
+    return max(1, numel // 128)
+
+
+def _step_deltas_agree(name, mine_delta, ref_delta, ref_g, gmax, lr=1e-4, clear=1e-4, frac_allowed=0.0):
+    """One Adam step from zero moments moves an entry by -lr * g / (|g| + eps'): lr * sign(g) wherever the gradient is clear of zero.  Entries whose
+    reference gradient is above `clear` x the tensor's largest must agree within 2 % of lr; the others (a rounding-level gradient decides the sign of
+    a full-size step) are bounded by the step size itself."""
+    big = np.abs(ref_g) > clear * gmax
+    bad = np.abs(mine_delta - ref_delta)[big] > 0.02 * lr
+    assert bad.mean() <= frac_allowed if big.any() else True, (name, int(bad.sum()), int(big.sum()))
+    assert np.all(np.abs(mine_delta) <= 1.05 * lr), name
+    return int(big.sum())
+
+
+def test_f13_elementwise_data_loss_gradients_and_optimiser_step(golden_dir):
+    """ELEMENT-wise pins where F6 / F8 hold norms: sampled entries of every data-loss gradient, and of every parameter's
+    (post - pre) of one clip + Adam step, against the reference's own."""
+    d = _load(golden_dir, 'f13_elementwise_data_loss_and_step.npz')
+    names = O.param_names(O.make_state())
+    assert [str(n) for n in d['names']] == names
+    # (a) data loss
+    st = O.make_state(requires_grad=True)
+    margin = synthetic_inputs(256, tag='margin', margin=True)
+    loss = O.data_loss(st, margin['x'], margin['y'], margin['t'], margin['field_data'], margin['coord_data'], margin['labels'], margin['forecast_h'], GEO)
+    assert abs(float(loss.detach()) - float(d['dl.loss'])) <= 1e-6 * float(d['dl.loss'])
+    grads = dict(zip(names, torch.autograd.grad(loss, [st[n] for n in names])))
+    for n in names:
+        if n.endswith('key_projection.bias'):
+            continue
+        mine = grads[n].flatten()[::_f13_stride(grads[n].numel())].numpy()
+        assert np.abs(mine - d['dl.g.' + n]).max() <= 2e-4 * float(d['dl.gmax.' + n]) + 1e-30, n
+    # (b) the optimiser step
+    st = O.make_state(requires_grad=True)
+    inter = synthetic_inputs(256, tag='inter')
+    loss = O.data_loss(st, margin['x'], margin['y'], margin['t'], margin['field_data'], margin['coord_data'], margin['labels'], margin['forecast_h'], GEO)
+    for inp in (inter, margin):
+        x, y, t = (inp[k].clone().requires_grad_(True) for k in ('x', 'y', 't'))
+        loss = loss + O.place_one_batch(st, x, y, t, inp['f'], inp['field_data'], inp['coord_data'], inp['forecast_h'], GEO)
+    assert abs(float(loss.detach()) - float(d['step.loss'])) <= 1e-5 * float(d['step.loss'])
+    grads = dict(zip(names, torch.autograd.grad(loss, [st[n] for n in names])))
+    before = {n: st[n].detach().clone() for n in names}
+    O.clip_and_adam_step(st, grads, {})
+    checked = 0
+    for n in names:
+        if n.endswith('key_projection.bias'):
+            continue
+        stride = _f13_stride(before[n].numel())
+        mine = (st[n].detach() - before[n]).flatten()[::stride].numpy()
+        checked += _step_deltas_agree(n, mine, d['step.delta.' + n], d['step.g.' + n], float(d['step.gmax.' + n]))
+    assert checked > 5000

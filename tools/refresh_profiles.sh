@@ -1,12 +1,13 @@
-# One gpurun call that produces every file of profiles/ for the current round (copy gpurun_out/r5/* to profiles/round5_* afterwards:
+# One gpurun call that produces every file of profiles/ for the current round (copy gpurun_out/r6/* to profiles/round6_* afterwards:
 # tools/collect_profiles.sh).  Before the call, HERE (hipcc cross-compiles): rebuild the experiment libraries the probes load --
-#   python tools/variant_build.py tl -DDPN_TIMELINE -DTS_TIMELINE                 (libdpn_hip_tl.so: tiles_timeline.py, bwd_tiles_timeline.py)
+#   python tools/variant_build.py pptl -DDPN_TIMELINE -DPP_TIMELINE               (tools/_variants/libdpn_hip_pptl.so: pp_timeline.py)
+#   python tools/variant_build.py tl -DDPN_TIMELINE -DTS_TIMELINE                 (tools/_variants/libdpn_hip_tl.so: tiles_timeline.py, bwd_tiles_timeline.py)
 #   python -m deepphysinet_amd.build --experiments                                (libdpn_hip_exp.so: the shelved kernels' own tests)
 # (Round 3's / 4's micro-benchmarks, hand-scheduled k-step variants, power / clock tables and encoder timelines concern code this round did not
 # touch: their round3_* / round4_* files stand.)
 set -x
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
-R=gpurun_out/r5; mkdir -p $R
+R=gpurun_out/r6; mkdir -p $R
 export MASTER_ADDR=127.0.0.1
 timeout 2700 python -m pytest tests -q -m gpu > $R/tests_gpu.txt 2>&1; tail -4 $R/tests_gpu.txt
 timeout 900 python bench.py > $R/bench_bf16x2.json 2> $R/bench_bf16x2.err
@@ -24,6 +25,8 @@ DPN_BENCH_ONE_DEVICE=1 DPN_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus
 DPN_BENCH_ONE_DEVICE=1 DPN_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --points 4096 --steps 10 --warmup 2 --blocks 3 --no-cpu-baseline --no-alt --no-power --no-lead-probe 2>> $R/bench_2ranks.err | grep '^{' > $R/bench_8ranks_one_device_gloo_4096pts.json
 timeout 600 python tools/tiles_timeline.py 37265 tl > $R/fwd_tiles_kernel_timeline.txt 2>&1
 timeout 300 python tools/bwd_tiles_timeline.py 37265 tl > $R/bwd_tiles_timeline_full.txt 2>&1
+timeout 300 python tools/pp_ab.py 37265 5197 1037 129 1 > $R/fwd_pp_vs_tiles.txt 2>&1
+timeout 300 python tools/pp_timeline.py 37265 pptl > $R/fwd_pp_kernel_timeline.txt 2>&1
 ( timeout 1200 python tools/soak.py bf16x2 200; timeout 900 python tools/soak.py bf16 200 ) 2>&1 | grep -v "amdgpu.ids" > $R/soak_bitwise.txt || true
 timeout 600 python tools/enc_batch_check.py 1 3 > $R/encoder_vs_fp64.txt 2>&1
 rm -rf $R/prof_cfg2; timeout 900 rocprofv3 --kernel-trace --stats -d $R/prof_cfg2 -o trace -- python3 bench.py --leads 61 --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-power > $R/bench_prof_cfg2.log 2>&1
