@@ -363,7 +363,8 @@ def test_bench_step_with_rccl_collectives_on_one_rank():
 def test_bench_trial_of_the_one_graph_form_keeps_the_segment_forms_line_when_it_stalls():
     """`bench.py --gpus N` over RCCL tries the one-graph form (all-reduces captured) at the END of the run, with the finished line of the segment form in
     hand.  A stall of the captured collectives -- simulated here: DPN_BENCH_TRIAL_TEST_STALL=replay parks the rank in front of the first replay -- must
-    end with exit code 0 and the segment form's line, saying where it stalled; without the stall the trial reports both forms' times."""
+    end with the segment form's line, saying where it stalled, and with exit code 14 (bench.TRIAL_STALL_EXIT: NON-zero since round 6 -- a launcher must be able
+    to tell a wedged collective from a clean run; the line is still the valid measurement); without the stall the trial reports both forms' times."""
     env = dict(os.environ, DPN_BENCH_RCCL_ONE_RANK='1', DPN_BENCH_TRY_FORMS='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'DPN_BENCH_BACKEND', 'DPN_BENCH_ONE_DEVICE', 'DPN_BENCH_CAPTURE_COLLECTIVES'):
         env.pop(k, None)
@@ -371,7 +372,7 @@ def test_bench_trial_of_the_one_graph_form_keeps_the_segment_forms_line_when_it_
             '--no-prewarm', '--blocks', '2', '--no-lead-probe', '--no-power']
     r = subprocess.run(args, env=dict(env, MASTER_PORT=str(_free_port()), DPN_BENCH_TRIAL_TEST_STALL='replay', DPN_BENCH_TRIAL_WATCHDOG_S='5'),
                        capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 14, (r.returncode, r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
