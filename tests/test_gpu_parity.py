@@ -876,9 +876,8 @@ def test_full_grid_all_gradients_vs_oracle():
     the rho >= 1e-6 clip bound where 1 / rho^2 ~ 1e12 enters the gradient, and the fp32 oracle itself is 2e-2 from the fp64 one on the
     rho net: that case is checked on its six losses only, test_default_init_full_grid_losses.)
     Bars: losses 1e-4 against the fp32 oracle (the north-star bar).  Gradients: L2 error per tensor within 1e-3 and the worst element
-    within 5e-3 of the tensor's maximum -- measured against the fp64 oracle, and for tensors where the fp32 oracle is itself further than
-    that from the fp64 one (sums over 37 265 points / 256 channels with cancellation: reference-side rounding, not ours) within twice
-    the fp32 oracle's own distance."""
+    within 2e-3 of the tensor's maximum -- measured against the fp64 oracle; the fp32 oracle's own distance from it is printed beside ours, and
+    (since round 6) no allowance is derived from it."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import synth_batch
@@ -921,8 +920,13 @@ def test_full_grid_all_gradients_vs_oracle():
     rows.sort(reverse=True)
     for l2, mx, o2, ox, name in rows[:6]:
         print('%-58s HIP vs fp64: L2 %.2e max %.2e | fp32 oracle vs fp64: L2 %.2e max %.2e' % (name, l2, mx, o2, ox))
+    worst_mx = max(rows, key=lambda r_: r_[1])
+    print('worst element of any tensor: %-44s HIP vs fp64: max %.2e | fp32 oracle vs fp64: max %.2e' % (worst_mx[4], worst_mx[1], worst_mx[3]))
+    # Round 6: NO allowance derived from the fp32 oracle's own distance any more -- it never bound on these weights (measured: worst L2 5.7e-4,
+    # worst element 1.36e-3; the fp32 oracle 3.1e-4 / 6.0e-4).  The element bar at this size is 2e-3, not 1e-3: nothing is removed here, and ~230 of the 37 265
+    # points carry a switch bit that differs from the oracle arithmetic's (the sizes where such points ARE removed hold 1e-3 per element)
     for l2, mx, o2, ox, name in rows:
-        assert l2 < max(tol['grad'], 2.0 * o2) and mx < max(5.0 * tol['grad'], 2.0 * ox), (name, l2, mx, o2, ox)
+        assert l2 < tol['grad'] and mx < 2.0 * tol['grad'], (name, l2, mx, o2, ox)
 
 
 def test_default_init_full_grid_losses():
