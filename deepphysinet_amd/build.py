@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, 'csrc', 'dpn_kernels.hip'), os.path.join(HERE, 'csrc', 'dpn_encoder.hip'),
         os.path.join(HERE, 'csrc', 'dpn_sampler.hip'), os.path.join(HERE, 'csrc', 'dpn_fp8.hip'),
         os.path.join(HERE, 'csrc', 'dpn_encoder_chain.hip')]
-DEPS = SRCS + [os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(HERE, 'csrc', 'dpn_fwd_tiles.h'), os.path.join(HERE, 'csrc', 'dpn_fwd_pp.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h'),
+DEPS = SRCS + [os.path.join(HERE, 'csrc', 'dpn_layout.h'), os.path.join(HERE, 'csrc', 'dpn_fwd_tiles.h'), os.path.join(HERE, 'csrc', 'dpn_fwd_pp.h'), os.path.join(HERE, 'csrc', 'dpn_fwd_tiles_persist.h'), os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip.h'),
                os.path.join(os.path.dirname(HERE), 'include', 'dpn_hip_experiments.h')]
 LIB = os.path.join(HERE, 'libdpn_hip.so')
 

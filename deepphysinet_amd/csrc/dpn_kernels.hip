@@ -1304,6 +1304,7 @@ __global__ __launch_bounds__(256, 1) void dpn_bwd_kernel(BwdArgs a) {
 #if DPN_HAS_POINT
 #include "dpn_fwd_tiles.h"                                       // tile-split forward / backward kernels (the hi+lo mode's default)
 #include "dpn_fwd_pp.h"                                          // round 6: the ping-pong form of the tile-split forward (one persistent 8-wave workgroup per CU)
+#include "dpn_fwd_tiles_persist.h"                               // round 6: persistent workgroups, the next item's features built by the wave that idles through the last GEMM
 #endif
 
 #if DPN_HAS_REST
@@ -2497,6 +2498,13 @@ static inline bool use_pp() {
     const char* e = getenv("DPN_FWD_PP");
     return e ? (e[0] == '1') : (DPN_FWD_PP_DEFAULT != 0);
 }
+#ifndef DPN_FWD_PERSIST_DEFAULT
+#define DPN_FWD_PERSIST_DEFAULT 0
+#endif
+static inline bool use_persist() {                      // DPN_FWD_PERSIST=0|1, read per call (A/B and bitwise comparison inside one process)
+    const char* e = getenv("DPN_FWD_PERSIST");
+    return e ? (e[0] == '1') : (DPN_FWD_PERSIST_DEFAULT != 0);
+}
 static inline int cu_count() {                          // compute units of the current device (one persistent workgroup each)
     static int n = 0;
     if (n == 0) {
@@ -2654,6 +2662,13 @@ static int fwd_launch(const float* x, const float* y, const float* t, const floa
     if (use_tiles("DPN_FWD_KERNEL", prec, pe_in != nullptr)) {    // (expects the FUSED packed form: dpn_fwd_form)
         // Training shape (saved state AND Jacobian wanted) in the hi+lo mode: the ping-pong form (dpn_fwd_pp.h), bit-identical results.  DPN_FWD_PP=0|1
         // overrides (read per call, like DPN_FWD_KERNEL: the tests compare the two forms inside one process).
+        if (prec == 2 && saved && jac_n && use_persist() && a.n_pad / 64 * n_nets < (1ll << 31)) {
+            const int64_t items = (a.n_pad / 64) * n_nets;
+            const int wgs = 2 * cu_count();                      // two workgroups per CU (72 KB of LDS, <= 256 registers each)
+            const dim3 gridp((unsigned)(items < wgs ? items : wgs));
+            hipLaunchKernelGGL(dpn_fwd_tiles_persist_kernel<2>, gridp, dim3(256), 0, s, a, n_nets);
+            return ck(hipGetLastError());
+        }
         if (prec == 2 && saved && jac_n && use_pp()) {
             const int64_t items = (a.n_pad / 128) * n_nets;
             const int cus = cu_count();

@@ -1436,20 +1436,24 @@ def test_tile_split_kernels_against_the_ring_kernels(n, prec):
 
 
 
-def test_ping_pong_forward_is_bitwise_the_tile_split_forward():
-    """Round 6: dpn_fwd_pp_kernel (csrc/dpn_fwd_pp.h: one persistent 8-wave workgroup per CU, two 4-wave groups in opposite phases; opt-in, DPN_FWD_PP=1)
-    computes exactly what dpn_fwd_tiles_kernel computes, in the same order per output tile: fields, Jacobian and every byte of the saved state are
-    IDENTICAL -- at the full grid (seven items per workgroup, 40 workgroups one item short), at sizes with a ragged last tile, at one item per workgroup
-    and fewer items than compute units, and at a single point."""
+@pytest.mark.parametrize('knob', ['DPN_FWD_PP', 'DPN_FWD_PERSIST'])
+def test_ping_pong_forward_is_bitwise_the_tile_split_forward(knob):
+    """Round 6: the two restructured forms of the forward + Jacobian kernel that were built, measured slower and left opt-in -- dpn_fwd_pp_kernel
+    (csrc/dpn_fwd_pp.h, DPN_FWD_PP=1: one persistent 8-wave workgroup per CU, two 4-wave groups in opposite phases) and dpn_fwd_tiles_persist_kernel
+    (csrc/dpn_fwd_tiles_persist.h, DPN_FWD_PERSIST=1: persistent 4-wave workgroups, the next item's coordinate features built by the wave that idles through
+    the last GEMM) -- compute exactly what dpn_fwd_tiles_kernel computes, in the same order per output tile: fields, Jacobian and every byte of the saved
+    state are IDENTICAL -- at the full grid (seven items per workgroup, some workgroups one item short), at sizes with a ragged last tile, at one item per
+    workgroup and fewer items than compute units, and at a single point."""
     import deepphysinet_amd as dpn
     from deepphysinet_amd import _lib as L, point_path as PP
     dev = _dev()
     m = _model('bf16x2')
     cfg = m.point_config()
     lib = L.load()
-    old = {k: os.environ.get(k) for k in ('DPN_FWD_KERNEL', 'DPN_FWD_PP')}
+    old = {k: os.environ.get(k) for k in ('DPN_FWD_KERNEL', 'DPN_FWD_PP', 'DPN_FWD_PERSIST')}
     try:
         os.environ['DPN_FWD_KERNEL'] = 'tiles'
+        os.environ['DPN_FWD_PP'] = os.environ['DPN_FWD_PERSIST'] = '0'
         for n in (257 * 145, 5197, 1037, 129, 1):
             inp = _gpu(synthetic_inputs(n, tag='inter'))
             with torch.no_grad():
@@ -1465,7 +1469,7 @@ def test_ping_pong_forward_is_bitwise_the_tile_split_forward():
                 fr = PP._freqs(dev)
                 res = []
                 for pp in ('0', '1'):
-                    os.environ['DPN_FWD_PP'] = pp
+                    os.environ[knob] = pp
                     out_n = torch.full((n, 6), 7.0, device=dev)
                     jac_n = torch.full((n, 6, 3), 7.0, device=dev)
                     saved = torch.full((ws.sizes.saved,), 0x5a, dtype=torch.uint8, device=dev)
