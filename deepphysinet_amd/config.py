@@ -29,6 +29,7 @@ class Config:
     # --- shelved experiments (kernels live in the experiment library, tools/variant_build.py; the product library refuses them)
     embed_gemm16: bool = False         # DPN_EMBED_GEMM16=1
     embed_parts: int = 0               # DPN_EMBED_PARTS
+    embed_align: bool = True           # DPN_EMBED_ALIGN=0 : K-slices of the token convolution NOT rounded to whole 64-deep k-tiles (rounds 1-5: sixteen slices of 451)
     conv16: bool = False               # DPN_CONV16=1
 
     @staticmethod
@@ -47,6 +48,7 @@ class Config:
             branches=tuple(b for b in e.get('DPN_BRANCHES', '').split(',') if b) if e.get('DPN_NO_BRANCHES') != '1' else (),
             embed_gemm16=e.get('DPN_EMBED_GEMM16') == '1',
             embed_parts=int(e.get('DPN_EMBED_PARTS', '0')),
+            embed_align=e.get('DPN_EMBED_ALIGN', '1') != '0',
             conv16=e.get('DPN_CONV16') == '1',
         )
 

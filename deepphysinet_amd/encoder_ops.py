@@ -265,7 +265,7 @@ def lead_time_pe(h, freq_bands):
 
 class _DataEmbeddingFn(torch.autograd.Function):
     """DataEmbedding + learnable tokens (model/embed.py:60-64, transformer_net.py:124-126) for B field samples:
-    x0[b] = cat(token, circular_conv3(field[b])) + pos + time_embedding(h[b]).  Four launches forward (im2col, one 16-way split-K MFMA GEMM
+    x0[b] = cat(token, circular_conv3(field[b])) + pos + time_embedding(h[b]).  Four launches forward (im2col, one 19-way split-K MFMA GEMM
     launch, lead-time PE, assemble + split reduction); backward = one GEMM for the conv weight (already in the parameter's [256][C][3]
     layout) with its bias sum."""
 
@@ -290,9 +290,14 @@ class _DataEmbeddingFn(torch.autograd.Function):
             emb_parts = torch.empty((n_parts, B * T, D), dtype=torch.float32, device=dev)
             L.check(L.load_experiments().dpn_conv16(_p(xs), _p(xe), _p(ws), _p(we), B * T, D, Kp, n_parts, _p(emb_parts), _s()), 'dpn_conv16')
         elif not config.FROZEN.embed_gemm16:
-            # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one exact-fp32 MFMA launch (24 us)
-            parts = 16
+            # emb = xu . w2^T with K = 3C = 7215: sixteen K-slices as sixteen problems of one exact-fp32 MFMA launch (24 us).  DPN_EMBED_PARTS overrides the
+            # number of slices (at most 26 problems per launch): round 6 sweep in tools/embed_parts_bench.py
+            # (default since round 6: slices of 384 = six whole 64-deep k-tiles -> 19 slices x 12 output tiles = 228 workgroups, one round of the 256 CUs:
+            # GEMM + assemble 24.8 us against 28.5 us for sixteen slices of 451 whose eighth k-tile is 95 % padding; profiles/round6_embed_split_sweep.txt)
+            parts = min(26, config.FROZEN.embed_parts) if config.FROZEN.embed_parts > 0 else 19
             ks = (K3 + parts - 1) // parts
+            if config.FROZEN.embed_align:                      # slices in whole 64-deep k-tiles of the kernel (no slice ends in a mostly empty tile)
+                ks = (ks + 63) // 64 * 64
             bounds = [(k0, min(k0 + ks, K3)) for k0 in range(0, K3, ks)]
             emb_parts = torch.empty((len(bounds), B * T, D), dtype=torch.float32, device=dev)
             problems = []
