@@ -2047,7 +2047,7 @@ struct SgemmBatch {
 typedef float f32x1;
 DEV f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-template <int BK, int NBUF, int NT = 256>
+template <int BK, int NBUF, int NT = 256, int TM = 1, int TN = 1>
 __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     // one workgroup = one 32x32 output tile.  K is walked in 32-wide tiles that are loaded COALESCED (the fast index follows each
     // operand's contiguous dimension) into double-buffered LDS, two tiles ahead in registers; inside a tile the four waves take
@@ -2057,8 +2057,12 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     // 96-deep: slower, the non-power-of-two index arithmetic).  <256, 1>: the whole K of a 256-wide encoder
     // GEMM is ONE tile -- one LDS stage, one barrier pair, 16 loads per operand in flight (used when every problem is a single tile);
     // it runs with EIGHT waves (NT = 512): half the MFMA chain and half the loads per thread of a latency-bound tile, -15 us per step.
-    constexpr int BM = 32, BN = 32, NL = BK * 32 / NT;    // NL loads per operand per thread per k-tile
-    constexpr int NW = NT / 64;                           // waves: each takes BK / NW k-values of a tile
+    // Round 6: TM x TN 32 x 32 sub-tiles per workgroup (<64, 2, 512, 2, 2>: a 64 x 64 output tile, each of its four quadrants on two waves that split the
+    // k-values of a k-tile): half the L2 -> LDS traffic per MAC of the 32 x 32 form (a 32 x 32 tile loads 2 x 32 x K values for 32 x 32 x K MACs: the token
+    // convolution moved 74 MB through L2 for 12 MB of operands) and four times the MFMA work per barrier.
+    constexpr int BM = 32 * TM, BN = 32 * TN, NLA = BK * BM / NT, NLB = BK * BN / NT;    // loads per operand per thread per k-tile
+    constexpr int NW = NT / 64, NQ = TM * TN, KW = NW / NQ;   // waves; sub-tiles; waves per sub-tile, each taking BK / KW k-values of a k-tile
+    static_assert(NW % NQ == 0 && BK % (2 * KW) == 0 && (BK * BM) % NT == 0 && (BK * BN) % NT == 0, "tile shape");
     if ((int)blockIdx.z >= batch.n) {
         // ride-along job: out_a[c] = sum_b partial[b][c], out_b[c] = sum_b partial[b][256 + c] (fixed order) -- the reduction of
         // dpn_add_ln_bwd's per-block partial sums, finished in the shadow of the GEMM tiles instead of in a launch of its own
@@ -2083,6 +2087,7 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     float (&As)[NBUF][BK][BM + 1] = stage.A;
     float (&Bs)[NBUF][BK][BN + 1] = stage.B;
     float (*part)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(&stage);           // the partial tiles reuse the staging buffers
+    const int wave_q = (threadIdx.x >> 6) % NQ, wave_k = (threadIdx.x >> 6) / NQ, qm = wave_q / TN, qn = wave_q % TN;
     static_assert(sizeof(Stage) >= NW * 32 * 33 * sizeof(float), "partial tiles must fit in the staging buffers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -2092,7 +2097,7 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     int total = 0;
     for (int t = 0; t < a.nterms; ++t) total += (batch.t[a.term0 + t].K + BK - 1) / BK;
     const int ktiles0 = (batch.t[a.term0].K + BK - 1) / BK;
-    float ra[NL], rb[NL];
+    float ra[NLA], rb[NLB];
     int lt = 0, lk0 = 0;                     // load cursor: term, k offset inside the term (terms may have different K)
     auto gload = [&]() __attribute__((always_inline)) {
         const SgemmTerm& T = batch.t[a.term0 + lt];
@@ -2100,28 +2105,32 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
         const float* B = T.B;
         const int lda = T.lda, ldb = T.ldb, K = T.K, k0 = lk0;
 #pragma unroll
-        for (int q = 0; q < NL; ++q) {
+        for (int q = 0; q < NLA; ++q) {
             const int e = threadIdx.x + NT * q;
-            {
-                const int kk = a.ta ? (e >> 5) : (e % BK), mm = a.ta ? (e & 31) : (e / BK);
-                const int gm = m0 + mm, gk = k0 + kk;
-                ra[q] = (gm < a.M && gk < K) ? (a.ta ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
-            }
-            {
-                const int kk = a.tb ? (e % BK) : (e >> 5), nn = a.tb ? (e / BK) : (e & 31);
-                const int gk = k0 + kk, gn = n0 + nn;
-                rb[q] = (gk < K && gn < a.N) ? (a.tb ? B[(int64_t)gn * ldb + gk] : B[(int64_t)gk * ldb + gn]) : 0.f;
-            }
+            const int kk = a.ta ? (e / BM) : (e % BK), mm = a.ta ? (e % BM) : (e / BK);
+            const int gm = m0 + mm, gk = k0 + kk;
+            ra[q] = (gm < a.M && gk < K) ? (a.ta ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NLB; ++q) {
+            const int e = threadIdx.x + NT * q;
+            const int kk = a.tb ? (e % BK) : (e / BN), nn = a.tb ? (e / BK) : (e % BN);
+            const int gk = k0 + kk, gn = n0 + nn;
+            rb[q] = (gk < K && gn < a.N) ? (a.tb ? B[(int64_t)gn * ldb + gk] : B[(int64_t)gk * ldb + gn]) : 0.f;
         }
         lk0 += BK;
         if (lk0 >= K) { lk0 = 0; ++lt; }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < NL; ++q) {
+        for (int q = 0; q < NLA; ++q) {
             const int e = threadIdx.x + NT * q;
-            As[buf][a.ta ? (e >> 5) : (e % BK)][a.ta ? (e & 31) : (e / BK)] = ra[q];
-            Bs[buf][a.tb ? (e % BK) : (e >> 5)][a.tb ? (e / BK) : (e & 31)] = rb[q];
+            As[buf][a.ta ? (e / BM) : (e % BK)][a.ta ? (e % BM) : (e / BK)] = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NLB; ++q) {
+            const int e = threadIdx.x + NT * q;
+            Bs[buf][a.tb ? (e % BK) : (e / BN)][a.tb ? (e / BK) : (e % BN)] = rb[q];
         }
     };
     if constexpr (NBUF == 2) {
@@ -2134,9 +2143,9 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
             if (it + 1 < total) lstore(buf ^ 1);                  // tile it+1 (loaded during the previous iteration) -> other LDS buffer
             if (it + 2 < total) gload();                          // tile it+2 in flight under the MFMAs
 #pragma unroll
-            for (int u = 0; u < BK / (2 * NW); ++u) {
-                const int kk = wave * (BK / NW) + 2 * u + h;
-                acc = mfma_f32(As[buf][kk][i], Bs[buf][kk][i], acc);
+            for (int u = 0; u < BK / (2 * KW); ++u) {
+                const int kk = wave_k * (BK / KW) + 2 * u + h;
+                acc = mfma_f32(As[buf][kk][32 * qm + i], Bs[buf][kk][32 * qn + i], acc);
             }
             if (do_asum && it < ktiles0 && threadIdx.x < BM) {
 #pragma unroll
@@ -2151,9 +2160,9 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
             __syncthreads();
             if (it + 1 < total) gload();                          // next tile in flight under the MFMAs
 #pragma unroll 8
-            for (int u = 0; u < BK / (2 * NW); ++u) {
-                const int kk = wave * (BK / NW) + 2 * u + h;
-                acc = mfma_f32(As[0][kk][i], Bs[0][kk][i], acc);
+            for (int u = 0; u < BK / (2 * KW); ++u) {
+                const int kk = wave_k * (BK / KW) + 2 * u + h;
+                acc = mfma_f32(As[0][kk][32 * qm + i], Bs[0][kk][32 * qn + i], acc);
             }
             if (do_asum && it < ktiles0 && threadIdx.x < BM) {
 #pragma unroll 8
@@ -2162,19 +2171,20 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
             __syncthreads();
         }
     }
-    // ---- fixed-order reduction over the four waves
+    // ---- fixed-order reduction over the waves of a sub-tile (wave = wave_k * NQ + wave_q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave][drow32(r, h) * 33 + i] = acc[r];
     __syncthreads();
 #pragma unroll
-    for (int e = threadIdx.x; e < 1024; e += NT) {
-        const int r = e >> 5, c = e & 31, o = r * 33 + c;
-        if (m0 + r < a.M && n0 + c < a.N) {
-            float v = part[0][o];
+    for (int e = threadIdx.x; e < 1024 * NQ; e += NT) {
+        const int sq = e >> 10, r = (e >> 5) & 31, c = e & 31, o = r * 33 + c;
+        const int gr = m0 + 32 * (sq / TN) + r, gc = n0 + 32 * (sq % TN) + c;
+        if (gr < a.M && gc < a.N) {
+            float v = part[sq][o];
 #pragma unroll
-            for (int w_ = 1; w_ < NW; ++w_) v += part[w_][o];               // fixed order: wave 0, 1, ... (left fold)
-            v += a.bias ? a.bias[n0 + c] : 0.f;
-            const int64_t idx = (int64_t)(m0 + r) * a.ldc + n0 + c;
+            for (int w_ = 1; w_ < KW; ++w_) v += part[w_ * NQ + sq][o];     // fixed order: k-part 0, 1, ... (left fold)
+            v += a.bias ? a.bias[gc] : 0.f;
+            const int64_t idx = (int64_t)gr * a.ldc + gc;
             if (a.epi == DPN_EPI_GELU) { if (a.aux_out) a.aux_out[idx] = v; v = gelu_exact(v); }
             else if (a.epi == DPN_EPI_MUL_GELU_GRAD) v *= gelu_exact_grad(a.aux[idx]);
             else if (a.epi == DPN_EPI_ADD) v += a.aux[idx];
@@ -2891,8 +2901,22 @@ static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, in
         out_tiles += (long)((b.p[i].M + 31) / 32) * ((b.p[i].N + 31) / 32);
     }
     single_tile = single_tile && out_tiles <= kSingleStageMaxOutTiles;
-    if (single_tile) hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1, 512>), dim3(gx, gy, gz), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), b);
-    else hipLaunchKernelGGL((dpn_sgemm_batch_kernel<64, 2, 512>), dim3(gx, gy, gz), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), b);
+    if (single_tile) {
+        hipLaunchKernelGGL((dpn_sgemm_batch_kernel<256, 1, 512>), dim3(gx, gy, gz), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), b);
+        return ck(hipGetLastError());
+    }
+    // Round 6: 64 x 64 output tiles (four 32 x 32 sub-tiles on eight waves: half the L2 -> LDS bytes per MAC) are in the kernel and OFF:
+    // measured slower on every launch of the step -- token convolution + assemble 27.3 against 25.0 us (captured and replayed, tools/embed_parts_bench.py), the
+    // heads' forward 17.7 against 16.3, their backward 34.6 against 26.9 us (rocprofv3): these GEMMs wait for latency, not for L2 bytes, and a quarter of the
+    // workgroups with four times the serial work each is the wrong trade (profiles/round6_sgemm_tile_ab.txt).  DPN_SGEMM_TILE=64 selects it.
+    const char* force = getenv("DPN_SGEMM_TILE");
+    const bool big = force && force[0] == '6';
+    if (big) {
+        const int gx64 = (gx + 1) / 2, gy64 = (gy + 1) / 2;
+        hipLaunchKernelGGL((dpn_sgemm_batch_kernel<64, 2, 512, 2, 2>), dim3(gx64, gy64, gz), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), b);
+    } else {
+        hipLaunchKernelGGL((dpn_sgemm_batch_kernel<64, 2, 512>), dim3(gx, gy, gz), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), b);
+    }
     return ck(hipGetLastError());
 }
 
