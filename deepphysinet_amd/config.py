@@ -56,7 +56,7 @@ class Config:
 # read by the C library itself (csrc): DPN_FWD_KERNEL / DPN_BWD_KERNEL = ring | tiles pick between two bit-identical decompositions of the point
 # kernels (tests compare them), DPN_ENC_NO_HELPERS drops the L2 warm-up workgroups of the encoder launches (a timing switch),
 # DPN_BWD_ORDER / DPN_WGRAD_ORDER = reverse are the cache-residency probes of DESIGN.md section 4c (timing switches, off in the product)
-LIBRARY_KNOBS = ('DPN_FWD_KERNEL', 'DPN_FWD_PP', 'DPN_FWD_PERSIST', 'DPN_SGEMM_TILE', 'DPN_BWD_KERNEL', 'DPN_ENC_NO_HELPERS', 'DPN_LIB', 'DPN_BWD_ORDER', 'DPN_WGRAD_ORDER')
+LIBRARY_KNOBS = ('DPN_FWD_KERNEL', 'DPN_FWD_PP', 'DPN_FWD_PERSIST', 'DPN_SGEMM_TILE', 'DPN_ATTN_BWD_ROLES', 'DPN_BWD_KERNEL', 'DPN_ENC_NO_HELPERS', 'DPN_LIB', 'DPN_BWD_ORDER', 'DPN_WGRAD_ORDER')
 
 FROZEN = Config.from_env()
 

@@ -104,6 +104,7 @@ struct AttnArgs {
     float *out, *P, *dS, *Dv, *dq, *dk, *dv;
     int L;
     float scale;
+    int roles;      // dpn_attn_bwd: roles per field in grid.z (3: dQ | dK | dV; 2: dQ | dK + dV)
 };
 // arguments of field b of a batch: rows [b*L, (b+1)*L) of every [batch*L][256] tensor, P block b of [batch][8][288][288]
 DEV AttnArgs attn_field(AttnArgs a, const int b) {
@@ -264,6 +265,7 @@ DEV void attn_bwd_query_role(const AttnArgs& a, char* smem) {
 
 // role 1, per (key tile, head): dV = P^T gO; then its own 288 x 32 block of dS (same expression, same order of operations as role 0);
 // dK = dS^T Q.  Reductions over all queries.
+template <int WHAT>      // 0: dV and dK (rounds 3-5), 1: dV only, 2: dK only (round 6: the key role was the launch's long pole, 11.4 against 8.1 us for the query role)
 DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
     float (*Rs)[33] = reinterpret_cast<float (*)[33]>(smem);                                  // [288][33]: all rows of gO, later of Q
     float (*Cs)[33] = reinterpret_cast<float (*)[33]>(smem + kLmax * 33 * 4);                 // [288][33]: P[:, key tile], later dS[:, key tile]
@@ -274,17 +276,22 @@ DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     load_head_rows(Rs, a.go, head, 0, kLmax, L);
     load_rows16<kLmax>(Cs, a.P + (int64_t)head * kLmax * kLmax, kLmax, j0, 0, L);
-    load_head_rows(Vt, a.v, head, j0, 32, L);
-    head_rowdot(Dl, a.go, a.o, head, 0, kLmax, L);
+    if constexpr (WHAT != 1) {
+        load_head_rows(Vt, a.v, head, j0, 32, L);
+        head_rowdot(Dl, a.go, a.o, head, 0, kLmax, L);
+    }
     __syncthreads();
     Rows16<kLmax> qreg;                                                                      // Q is needed last: its loads fly under dV and dS
-    rows16_fetch<kLmax>(qreg, a.q, kD, head * kE, 0, L);
+    if constexpr (WHAT != 1) rows16_fetch<kLmax>(qreg, a.q, kD, head * kE, 0, L);
     f32x16 acc = (f32x16)0.f;
-    mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dV[j][e] = sum_i P[i][j] gO[i][e]
-    reduce_tile(acc, part, [&](int r, int c, float v) {
-        if (j0 + r < L) a.dv[(int64_t)(j0 + r) * kD + head * kE + c] = v;
-    });
-    __syncthreads();
+    if constexpr (WHAT != 2) {
+        mma_tile(acc, kLmax / 2, [&](int r, int k) { return Cs[k][r]; }, [&](int k, int c) { return Rs[k][c]; });       // dV[j][e] = sum_i P[i][j] gO[i][e]
+        reduce_tile(acc, part, [&](int r, int c, float v) {
+            if (j0 + r < L) a.dv[(int64_t)(j0 + r) * kD + head * kE + c] = v;
+        });
+        if constexpr (WHAT == 1) return;
+        __syncthreads();
+    }
     for (int rt = wave; rt < kLmax / 32; rt += kAW) {                                            // dS[rows of tile rt][key tile]
         f32x16 dp = (f32x16)0.f;
 #pragma unroll
@@ -307,9 +314,21 @@ DEV void attn_bwd_key_role(const AttnArgs& a, char* smem) {
 
 __global__ __launch_bounds__(kAT) void dpn_attn_bwd_kernel(AttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const AttnArgs a = attn_field(a0, blockIdx.z >> 1);        // grid.z = 2 * field + role
-    if ((blockIdx.z & 1) == 0) attn_bwd_query_role(a, smem);
-    else attn_bwd_key_role(a, smem);
+    // grid.z = 3 * field + role (round 6: the key role's dV and dK are two roles; DPN_ATTN_BWD_ROLES=2 launches rounds 3-5's two: a0.roles)
+    const int roles = a0.roles, role = blockIdx.z % roles;
+    const AttnArgs a = attn_field(a0, blockIdx.z / roles);
+    // (ablation builds, wrong results on purpose: tools/variant_build.py --unit=2 -DATTN_ABL_NOQ | -DATTN_ABL_NOK time one role alone)
+    if (role == 0) {
+#ifndef ATTN_ABL_NOQ
+        attn_bwd_query_role(a, smem);
+#endif
+    } else {
+#ifndef ATTN_ABL_NOK
+        if (roles == 2) attn_bwd_key_role<0>(a, smem);
+        else if (role == 1) attn_bwd_key_role<2>(a, smem);     // (the longer one first)
+        else attn_bwd_key_role<1>(a, smem);
+#endif
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- add + LayerNorm
@@ -473,7 +492,7 @@ int dpn_attn_fwd(const float* q, const float* k, const float* v, int L, int batc
 
 int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* P, const float* go, int L, int batch,
                  float* dq, float* dk, float* dv, void* stream) {
-    if (!q || !k || !v || !o || !P || !go || !dq || !dk || !dv || L <= 0 || L > kLmax || batch <= 0 || batch > 16383) return -1;
+    if (!q || !k || !v || !o || !P || !go || !dq || !dk || !dv || L <= 0 || L > kLmax || batch <= 0 || batch > 16383) return -1;      // (grid.z = 3 * batch <= 65535)
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.o = o; a.go = go; a.P = const_cast<float*>(P); a.dq = dq; a.dk = dk; a.dv = dv; a.L = L;
     a.scale = 1.0f / sqrtf((float)kE);
@@ -481,7 +500,11 @@ int dpn_attn_bwd(const float* q, const float* k, const float* v, const float* o,
     static std::atomic<unsigned long long> done{0};
     unsigned long long bit;
     if (dpn_first_use_on_device(done, bit)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dpn_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds); done.fetch_or(bit, std::memory_order_release); }
-    hipLaunchKernelGGL(dpn_attn_bwd_kernel, dim3((L + 31) / 32, kH, 2 * batch), dim3(kAT), kAttnLds, s, a);
+    // Round 6: three roles per field (dQ | dK | dV) while the launch does not fill the chip -- one field: 216 workgroups, 9.2 against 11.0 us per launch, the step
+    // -7.7 us (profiles/round6_attn_bwd_roles.txt); lead batches keep two (61 fields: 56.4 against 56.5 ms).  DPN_ATTN_BWD_ROLES=2|3 overrides.
+    const char* er = getenv("DPN_ATTN_BWD_ROLES");
+    a.roles = er ? ((er[0] == '2') ? 2 : 3) : (batch <= 2 ? 3 : 2);
+    hipLaunchKernelGGL(dpn_attn_bwd_kernel, dim3((L + 31) / 32, kH, a.roles * batch), dim3(kAT), kAttnLds, s, a);
     return (int)hipGetLastError();
 }
 
