@@ -255,6 +255,12 @@ constexpr int kFusedBlocks = 64 + 48 + 8 + 12 + kVecParts;
 DEV f32x16 pk_mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __global__ __launch_bounds__(256) void dpn_pack_fused_kernel(PackArgs a) {
     const int net = blockIdx.y, bx = blockIdx.x, ns = a.ns;
+#ifdef PACK_ABL_MASK        // ablation builds (wrong results on purpose, timing only: tools/variant_build.py --unit=1 -DPACK_ABL_MASK=m): only the roles in bit mask m run.
+    // Round 6, tools/pack_probe.py (us per launch): all 19.9-20.2; role 0 alone 7.7, 1: 6.5, 2: 8.0, 3: 5.7, 4: 5.1; {0,1} 12.1, {0,1,2} 17.7, {3,4} 6.9, {0,1,3,4} 16.8:
+    // the three MFMA-tile roles do not hide behind each other.  Staging the block's W1 rows through LDS with coalesced loads (each lane fetches 16-byte pieces
+    // of its own row today) was built and changed nothing (21.1-21.9 us): it is not the request pattern.  profiles/round6_pack_fused_roles.txt
+    if (!((PACK_ABL_MASK >> (bx < 64 ? 0 : bx < 112 ? 1 : bx < 120 ? 2 : bx < 132 ? 3 : 4)) & 1)) return;
+#endif
     if (bx >= 132) { pack_vectors(a, net, bx - 132); return; }
     const DpnNetPtrs& P = a.net[net];
     uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
