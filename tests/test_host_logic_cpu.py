@@ -339,3 +339,29 @@ def test_bench_power_sampling_degrades_to_none_without_rocm_smi(monkeypatch, tmp
     fake.write_text('#!/bin/sh\necho \'{"card0": {"sclk clock speed:": "(1977Mhz)", "Current Socket Graphics Package Power (W)": "1395.0"}}\'\n')
     out = bench.sample_power(lambda: calls.append(1), seconds=0.5)
     assert out is not None and out['sclk_mhz'] == 1977.0 and out['socket_w'] == 1395.0 and out['samples'] >= 1
+
+
+def test_scaled_init_is_deterministic_keeps_buffers_and_conditions_the_outputs():
+    """deepphysinet_amd.utils.init.scaled_init_ (round 6: what `bench.py --leads N` trains from, section 6a of DESIGN.md): the same seed gives the same weights,
+    another seed others; every parameter is redrawn with its scale (LayerNorm gains around 1, the hyper-network heads 8 x smaller than a 1/sqrt(fan_in) layer),
+    buffers (the sinusoid table) are untouched -- and the encoder's output, through the heads, gives raw VariableNet weights of the order of 1/sqrt(fan_in): the
+    point of it (PyTorch's default initialisation: raw outputs with a standard deviation of 7-14, half of the physical values on a clip bound)."""
+    from deepphysinet_amd.utils.init import scaled_init_
+    m = builder_models(**ncep_config())
+    net = m.physics_net
+    pe_before = net.meta_net.model.enc_embedding.position_embedding.pe.clone()
+    scaled_init_(net, seed=1)
+    a = {k: v.detach().clone() for k, v in net.named_parameters()}
+    scaled_init_(net, seed=1)
+    assert all(torch.equal(a[k], v.detach()) for k, v in net.named_parameters())
+    scaled_init_(net, seed=2)
+    assert not torch.equal(a['U_net.out_fc.weight'], dict(net.named_parameters())['U_net.out_fc.weight'].detach())
+    assert torch.equal(pe_before, net.meta_net.model.enc_embedding.position_embedding.pe)
+    p = dict(net.named_parameters())
+    g = p['meta_net.model.encoder.norm.weight'].detach()
+    assert 0.9 <= float(g.min()) and float(g.max()) <= 1.1
+    w_fc = p['U_net.cat_fc1.fc.0.weight'].detach()                      # [256, 256]: |w| <= 1.7 / 16
+    w_head = p['U_net.coord_hidden_fc.weight'].detach()                 # [257, 256]: another factor 8 smaller
+    assert float(w_fc.abs().max()) <= 1.7 / 16 + 1e-6 and float(w_fc.abs().max()) > 0.09
+    assert float(w_head.abs().max()) <= 1.7 / 16 / 8 + 1e-6
+    assert float(p['U_net.out_fc.bias'].detach().abs().max()) <= 0.05 + 1e-6
