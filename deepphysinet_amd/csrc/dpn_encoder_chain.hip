@@ -1073,8 +1073,13 @@ struct WgJob { const float* partial; float* out_a; float* out_b; int nblocks, pa
 struct WgArgs {
     WgProblem p[kWgMaxProblems];
     WgJob job[kWgMaxJobs];
-    int n, slices, rows_per_slice;
+    int n, slices, rows_per_slice, n_tiles;
     float* partials;
+    int start[kWgMaxProblems + 1];               // first workgroup of each problem: the grid is the LIST of its tiles (x slices), then one per job
+    float inv_tx[kWgMaxProblems];
+    int per_slice[kWgMaxProblems];
+    int tx[kWgMaxProblems];                      // tiles along N  (int: with a 2-byte table hipcc folded 2 * pi into the BASE of the scalar load of
+                                                 //  start[pi] -- scalar loads drop the low two address bits of the base: every odd problem read start[pi - 1])
 };
 static_assert(sizeof(WgArgs) <= 4096, "kernel arguments");
 
@@ -1097,10 +1102,11 @@ __global__ __launch_bounds__(64 * kWgWaves) void dpn_wgrad16_kernel(WgArgs a) {
     __shared__ __attribute__((aligned(16))) char xf[2][kWgWaves][2][1024];   // [buffer][n-tile][hi | lo][lane x 16 B]
     __shared__ int xe[2][kWgWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int z = blockIdx.z;
-    if (z >= a.n * a.slices) {                   // ride-along job: LayerNorm parameter sums (fixed order over the row blocks)
-        if (blockIdx.x || blockIdx.y) return;
-        const WgJob& j = a.job[z - a.n * a.slices];
+    // One workgroup per tile that exists: a (widest N, tallest M, problems) box around 25 problems of 4 x 4 .. 8 x 4 tiles and ONE of 113 x 4
+    // (the token convolution) was 31 640 workgroups for ~950 tiles.
+    const int bid = blockIdx.x;
+    if (bid >= a.n_tiles) {                      // ride-along job: LayerNorm parameter sums (fixed order over the row blocks)
+        const WgJob& j = a.job[bid - a.n_tiles];
         float s1 = 0.f, s2 = 0.f;
         if (tid >= 256) return;
 #pragma unroll 8
@@ -1109,10 +1115,17 @@ __global__ __launch_bounds__(64 * kWgWaves) void dpn_wgrad16_kernel(WgArgs a) {
         j.out_b[tid] = s2;
         return;
     }
-    const int pi = z / a.slices, sl = z - pi * a.slices;
+    // (decoded on the SCALAR unit: the waves of this kernel are VALU-bound, and a search that stops early is a chain of dependent scalar loads)
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kWgMaxProblems; ++i) pi += (int)((unsigned)(a.start[i] - 1 - bid) >> 31);     // entries behind the last problem hold n_tiles
+    pi = __builtin_amdgcn_readfirstlane(pi);
     const WgProblem& p = a.p[pi];
-    const int m0 = blockIdx.y * kWgTile, n0 = blockIdx.x * kWgTile;
-    if (m0 >= p.M || n0 >= p.N) return;
+    const int tx = a.tx[pi], per_slice = a.per_slice[pi];
+    int rel = bid - a.start[pi], sl = 0;
+    while (rel >= per_slice) { rel -= per_slice; ++sl; }                    // (slices: a handful)
+    const int by = __builtin_amdgcn_readfirstlane((int)(((float)rel + 0.5f) * a.inv_tx[pi])), bx = rel - by * tx;
+    const int m0 = by * kWgTile, n0 = bx * kWgTile;
     const int r_begin = sl * a.rows_per_slice, r_end = min(p.rows, r_begin + a.rows_per_slice);
     const int nk = r_end > r_begin ? (r_end - r_begin + 31) / 32 : 0;
     const int c = lane & 15, g = lane >> 4;
@@ -1189,7 +1202,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void dpn_wgrad16_kernel(WgArgs a) {
 #pragma unroll
     for (int t = 0; t < kWgWaves; ++t) { am[t] = (f32x4)0.f; ac[t] = (f32x4)0.f; ex_seen[t] = 13; }
     float bsum = 0.f;
-    const bool want_b = blockIdx.x == 0 && p.db != nullptr;
+    const bool want_b = bx == 0 && p.db != nullptr;
 #pragma unroll
     for (int d = 0; d < kWgDepth; ++d)
         if (d < nk) fetch(d, gv[d], xv[d]);
@@ -1509,8 +1522,8 @@ static int gemm16_launch(int n, const DpnGemm16Problem* problems, int n_jobs, co
     if (slices < 1 || (slices > 1 && !partials)) return -1;
     WgArgs a{};
     a.n = n; a.slices = slices; a.partials = partials;
-    int gx = 1, gy = 1, max_k = 0;
-    int64_t off = 0, per_max = 0;
+    int max_k = 0;
+    int64_t off = 0, per_max = 0, tiles = 0;
     for (int i = 0; i < n; ++i) {
         const DpnGemm16Problem& q = problems[i];
         if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.ldc < q.N) return -1;
@@ -1518,17 +1531,22 @@ static int gemm16_launch(int n, const DpnGemm16Problem* problems, int n_jobs, co
         const int64_t per = (int64_t)q.M * q.N + (q.asum ? q.M : 0);
         off += (int64_t)slices * per;
         per_max = per_max > per ? per_max : per;
-        gx = gx > (q.N + kWgTile - 1) / kWgTile ? gx : (q.N + kWgTile - 1) / kWgTile;
-        gy = gy > (q.M + kWgTile - 1) / kWgTile ? gy : (q.M + kWgTile - 1) / kWgTile;
+        const int tx = (q.N + kWgTile - 1) / kWgTile, ty = (q.M + kWgTile - 1) / kWgTile;
+        if ((int64_t)tx * ty > (1 << 20) || tiles + (int64_t)tx * ty * slices > (1 << 30)) return -1;   // (1 << 20: the kernel's float division of a tile index by tx is exact below 4e6)
+        a.start[i] = (int)tiles;
+        a.tx[i] = tx; a.per_slice[i] = tx * ty; a.inv_tx[i] = 1.0f / (float)tx;
+        tiles += (int64_t)tx * ty * slices;
         max_k = max_k > q.K ? max_k : q.K;
     }
+    for (int i = n; i <= kWgMaxProblems; ++i) a.start[i] = (int)tiles;
+    a.n_tiles = (int)tiles;
     a.rows_per_slice = ((max_k + slices - 1) / slices + 31) / 32 * 32;
     for (int i = 0; i < n_jobs; ++i) {
         if (!jobs[i].partial || !jobs[i].out_a || !jobs[i].out_b || jobs[i].n_blocks <= 0) return -1;
         a.job[i] = WgJob{jobs[i].partial, jobs[i].out_a, jobs[i].out_b, jobs[i].n_blocks, 0};
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(dpn_wgrad16_kernel, dim3(gx, gy, n * slices + n_jobs), dim3(64 * kWgWaves), 0, s, a);
+    hipLaunchKernelGGL(dpn_wgrad16_kernel, dim3((unsigned)tiles + n_jobs), dim3(64 * kWgWaves), 0, s, a);
     if (slices > 1 && n > 0 && reduce)
         hipLaunchKernelGGL(dpn_wgrad16_reduce_kernel, dim3((unsigned)((per_max + 255) / 256), n), dim3(256), 0, s, a);
     return (int)hipGetLastError();
