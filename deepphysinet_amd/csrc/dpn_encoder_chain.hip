@@ -1104,6 +1104,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void dpn_wgrad16_kernel(WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // One workgroup per tile that exists: a (widest N, tallest M, problems) box around 25 problems of 4 x 4 .. 8 x 4 tiles and ONE of 113 x 4
     // (the token convolution) was 31 640 workgroups for ~950 tiles.
+    // (consecutive tiles go to different XCDs; giving every XCD a contiguous range of the list measured 26.7 -> 31.5 us: profiles/round6_xcd_contiguous.txt)
     const int bid = blockIdx.x;
     if (bid >= a.n_tiles) {                      // ride-along job: LayerNorm parameter sums (fixed order over the row blocks)
         const WgJob& j = a.job[bid - a.n_tiles];

@@ -254,7 +254,15 @@ __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
 constexpr int kFusedBlocks = 64 + 48 + 8 + 12 + kVecParts;
 DEV f32x16 pk_mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __global__ __launch_bounds__(256) void dpn_pack_fused_kernel(PackArgs a) {
+    // Workgroups go to the eight XCDs round-robin in dispatch order: every XCD gets a CONTIGUOUS range of the (net, block) list, so that a net's W1 / w2 / Wd
+    // are fetched into one or two L2s instead of all eight: 20.0 -> 16.2 us per launch (tools/pack_probe.py, profiles/round6_xcd_contiguous.txt).
+#ifdef PACK_NO_XCD_REMAP
     const int net = blockIdx.y, bx = blockIdx.x, ns = a.ns;
+#else
+    const int lin = blockIdx.x + kFusedBlocks * blockIdx.y, virt = (lin & 7) * (kFusedBlocks * kNets / 8) + (lin >> 3);
+    static_assert(kFusedBlocks * kNets % 8 == 0, "remap");
+    const int net = virt / kFusedBlocks, bx = virt - net * kFusedBlocks, ns = a.ns;
+#endif
 #ifdef PACK_ABL_MASK        // ablation builds (wrong results on purpose, timing only: tools/variant_build.py --unit=1 -DPACK_ABL_MASK=m): only the roles in bit mask m run.
     // Round 6, tools/pack_probe.py (us per launch): all 19.9-20.2; role 0 alone 7.7, 1: 6.5, 2: 8.0, 3: 5.7, 4: 5.1; {0,1} 12.1, {0,1,2} 17.7, {3,4} 6.9, {0,1,3,4} 16.8:
     // the three MFMA-tile roles do not hide behind each other.  Staging the block's W1 rows through LDS with coalesced loads (each lane fetches 16-byte pieces
@@ -2069,11 +2077,16 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     constexpr int BM = 32 * TM, BN = 32 * TN, NLA = BK * BM / NT, NLB = BK * BN / NT;    // loads per operand per thread per k-tile
     constexpr int NW = NT / 64, NQ = TM * TN, KW = NW / NQ;   // waves; sub-tiles; waves per sub-tile, each taking BK / KW k-values of a k-tile
     static_assert(NW % NQ == 0 && BK % (2 * KW) == 0 && (BK * BM) % NT == 0 && (BK * BN) % NT == 0, "tile shape");
-    if ((int)blockIdx.z >= batch.n) {
+    // (Round 6: XCD-contiguous renumbering of the workgroups -- every XCD a contiguous range of the (problem, tile) list, as in dpn_pack_fused_kernel -- is SLOWER
+    //  here: the heads' forward 16.2 -> 22.4 us, their backward 27.1 -> 48 us, the token convolution unchanged: a problem's tiles on ONE L2 queue on the same
+    //  lines; spread over eight L2s each serves an eighth of them.  A skew of the column tile by (row tile + 3 problem), so that tiles sharing a B panel
+    //  leave the XCD they share when gridDim.x is a multiple of 8, changes nothing.  profiles/round6_xcd_contiguous.txt)
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (bz >= batch.n) {
         // ride-along job: out_a[c] = sum_b partial[b][c], out_b[c] = sum_b partial[b][256 + c] (fixed order) -- the reduction of
         // dpn_add_ln_bwd's per-block partial sums, finished in the shadow of the GEMM tiles instead of in a launch of its own
-        if (blockIdx.x || blockIdx.y) return;
-        const SgemmColsum& j = batch.job[blockIdx.z - batch.n];
+        if (bx || by) return;
+        const SgemmColsum& j = batch.job[bz - batch.n];
         const int c = threadIdx.x;
         if (c >= 256) return;
         float s1 = 0.f, s2 = 0.f;
@@ -2083,8 +2096,8 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
         j.out_b[c] = s2;
         return;
     }
-    const SgemmProblem& a = batch.p[blockIdx.z];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const SgemmProblem& a = batch.p[bz];
+    const int m0 = by * BM, n0 = bx * BN;
     if (m0 >= a.M || n0 >= a.N) return;
     // 34 KB (<64,2>) or 68 KB (<256,1>) of LDS: four or two workgroups per CU.  The partial tiles of the waves (eight: 33 KB) reuse the
     // staging buffers after the last k-tile.  Both forms run with eight waves: -15 us (<256,1>) and -53 us (<64,2>) per step against four.
@@ -2099,7 +2112,7 @@ __global__ __launch_bounds__(NT) void dpn_sgemm_batch_kernel(SgemmBatch batch) {
     const int i = lane & 31, h = lane >> 5;
     f32x16 acc = (f32x16)0.f;
     float rs = 0.f;
-    const bool do_asum = a.asum != nullptr && blockIdx.x == 0;
+    const bool do_asum = a.asum != nullptr && bx == 0;
     int total = 0;
     for (int t = 0; t < a.nterms; ++t) total += (batch.t[a.term0 + t].K + BK - 1) / BK;
     const int ktiles0 = (batch.t[a.term0].K + BK - 1) / BK;
