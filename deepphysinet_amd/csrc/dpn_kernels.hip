@@ -1785,8 +1785,8 @@ __global__ __launch_bounds__(256) void dpn_finish_rows_kernel(FinishArgs a) {
 // are contiguous along the lane index) and their partial tiles are added in a fixed order through LDS.
 DEV f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 constexpr int kVsideBlocks = 8 * 15;
-DEV void finish_vside_body(const FinishArgs& a, const int bx, float (&red)[4][16][64], float (&qs)[32]) {
-    const int rt = bx & 7, ctile = bx >> 3, net = blockIdx.y;
+DEV void finish_vside_body(const FinishArgs& a, const int bx, const int net, float (&red)[4][16][64], float (&qs)[32]) {
+    const int rt = bx & 7, ctile = bx >> 3;
     const int kind = ctile < 8 ? 0 : ctile == 8 ? 1 : 2;                  // d w2 | vector column | dWd
     const DpnNetPtrs& P = a.net[net];
     const DpnNetGradPtrs& Gd = a.grad[net];
@@ -1832,8 +1832,7 @@ DEV void finish_vside_body(const FinishArgs& a, const int bx, float (&red)[4][16
 // per-tile parts of r[o] = sum_i W1[o][i] G[o][i] (+ bf1 mvec, added by dpn_finish_fc2_kernel).  One workgroup per 32 x 32 tile of G; wave wv
 // takes j in [64 wv, 64 wv + 64) and k in [48 wv, 48 wv + 48); lane (col, kh) holds four consecutive reduction indices per load of its row.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-DEV void finish_gside_body(const FinishArgs& a, const int bx, float (&red)[4][16][64]) {
-    const int net = blockIdx.y;
+DEV void finish_gside_body(const FinishArgs& a, const int bx, const int net, float (&red)[4][16][64]) {
     const int rt = bx & 7, ct = bx >> 3;
     const DpnNetPtrs& P = a.net[net];
     const DpnNetGradPtrs& Gd = a.grad[net];
@@ -1890,8 +1889,16 @@ constexpr int kGsideBlocks = 64;
 __global__ __launch_bounds__(256) void dpn_finish_sides_kernel(FinishArgs a, int n_v) {
     __shared__ float red[4][16][64];
     __shared__ float qs[32];
-    if ((int)blockIdx.x < n_v) finish_vside_body(a, blockIdx.x, red, qs);
-    else finish_gside_body(a, blockIdx.x - n_v, red);
+    // As dispatched, XCD = blockIdx.x mod 8 = the ROW tile (the grid's x extent is a multiple of 8): the 15 x 6 (or 8 x 6) tiles that read the same 32 columns of
+    // W1 (rows of S1: each lane its own row) sat on one L2.  Every XCD takes a contiguous range of the (net, block) list instead, as in dpn_pack_fused_kernel.
+#ifdef FINISH_NO_XCD_REMAP
+    const int net = blockIdx.y, bx = blockIdx.x;
+#else
+    const int gx = gridDim.x, total = gx * kNets, lin = blockIdx.x + gx * blockIdx.y, xcd = lin & 7;
+    const int virt = xcd * (total >> 3) + min(xcd, total & 7) + (lin >> 3), net = virt / gx, bx = virt - net * gx;
+#endif
+    if (bx < n_v) finish_vside_body(a, bx, net, red, qs);
+    else finish_gside_body(a, bx - n_v, net, red);
 }
 
 // one block per (row o', net): r, then dW2 = wo (x) r, dbf2, dwo (with colsum(Z) = w2 q1 + Wd q6 + sum g cvec), dbo, dbf1
