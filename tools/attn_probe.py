@@ -37,3 +37,5 @@ if which in ('fwd', 'both'):
     timed(lambda: L.check(lib.dpn_attn_fwd(_p(q), _p(k), _p(v), 287, 1, _p(o), _p(P), _s()), 'attn'), 'attn_fwd')
 if which in ('bwd', 'both'):
     timed(lambda: L.check(lib.dpn_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(P), _p(go), 287, 1, _p(dq), _p(dk), _p(dv), _s()), 'attn'), 'attn_bwd')
+if which in ('fwd16', 'both'):
+    timed(lambda: L.check(lib.dpn_attn16_fwd(_p(q), _p(k), _p(v), 287, 1, _p(o), _p(P), _s()), 'attn16'), 'attn16_fwd')
