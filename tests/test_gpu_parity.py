@@ -556,6 +556,35 @@ def test_encoder_kernels_gradients_vs_torch():
     assert torch.equal(ya, linear(xa, wa, ba))
 
 
+@pytest.mark.parametrize('rows', [287, 2 * 287, 61 * 287])
+def test_wgrad16_mixed_problem_lists_vs_fp64(rows):
+    """dpn_wgrad16 (dW = G^T X, db = column sums of G; f16 hi+lo MFMA with running power-of-two scales): lists whose problems differ in tile
+    counts -- the launch's grid is the LIST of the tiles that exist (round 6), so every problem of a ragged list must still be decoded to its
+    own tiles: equal 4 x 4 problems, 8 x 4 and 4 x 8 ones among them, the stack's 25 + the token convolution's 4 x 113, the convolution
+    alone; one row slice (a single field), two, and a lead batch's row count (slices joined by the reduce launch).  Bound: 2e-6 of the
+    tensor's maximum (measured 2e-7 .. 6e-7), bias sums 3e-6 of theirs (fp32 sums over the rows: measured 5e-7)."""
+    from deepphysinet_amd.encoder_ops import wgrad16
+    dev = _dev()
+    g = torch.Generator(device='cpu').manual_seed(11)
+    lists = ([(256, 256)] * 6, [(256, 256)] * 4 + [(512, 256), (256, 512)], [(256, 256)] * 25 + [(256, 7215)], [(256, 7215)])
+    if rows > 1000:
+        lists = lists[1:2]                                        # the lead-batch row count: one ragged list (an 8-MB X per 7 215-column problem otherwise)
+    for shapes in lists:
+        G = [torch.randn(rows, m, generator=g).to(dev) for m, n in shapes]
+        X = [torch.randn(rows, n, generator=g).to(dev) for m, n in shapes]
+        dW = [torch.full((m, n), float('nan'), device=dev) for m, n in shapes]
+        db = [torch.full((m,), float('nan'), device=dev) for m, n in shapes]
+        keep = wgrad16(list(zip(G, X, dW, db)))
+        torch.cuda.synchronize()
+        del keep
+        for i, (g_, x_, w_, b_) in enumerate(zip(G, X, dW, db)):
+            ref = g_.double().T @ x_.double()
+            bref = g_.double().sum(0)
+            ew = float((w_.double() - ref).abs().max() / ref.abs().max())
+            eb = float((b_.double() - bref).abs().max() / bref.abs().max())
+            assert ew < 2e-6 and eb < 3e-6, (rows, len(shapes), i, ew, eb)
+
+
 @pytest.mark.parametrize('B', [1, 3])
 def test_fused_encoder_nodes_vs_torch_autograd(B):
     """The hand-scheduled autograd nodes of encoder_ops (whole EncoderLayer, data embedding, hyper-network heads) against the reference's
