@@ -253,7 +253,7 @@ def main():
     # N > 1 (or DPN_BENCH_SPLIT_STEP=1 on one GPU, to time the same code path): three graph segments with a bucket all-reduce behind each
     split_step = world > 1 or one_rank_rccl or os.environ.get('DPN_BENCH_SPLIT_STEP') == '1'
     # DPN_BENCH_CAPTURE_COLLECTIVES=1: capture the bucket all-reduces inside ONE graph with the segments (opt-in: measured with a one-rank
-    # RCCL group on the single-GPU test box, profiles/; the default keeps the collectives host-issued between four segment graphs)
+    # RCCL group on the single-GPU test box, profiles/; the default keeps the collectives host-issued between the segment graphs)
     one_graph_collectives = os.environ.get('DPN_BENCH_CAPTURE_COLLECTIVES') == '1' and split_step and (world > 1 or one_rank_rccl)
 
     def make_step(m, opt, n_leads):
@@ -305,7 +305,7 @@ def main():
         coll['gradient_buckets_mb'] = [round((b - a) * 4 / 2 ** 20, 2) for a, b in opt.bucket_bounds]
         segments, staged = make_step(m, opt, n_leads)
         n_reduce = len(segments) - 1 if split_step else 0     # segment i completes the layout buckets staged.stage_buckets[i]; the last segment is the optimiser
-        rec = {'capture_error': None, 'step_form': None}
+        rec = {'capture_error': None, 'step_form': None, 'n_segments': len(segments)}
 
         def eager():
             for i, seg in enumerate(segments):
@@ -587,7 +587,7 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     pts_per_s = args.points * args.leads * world * args.steps / dt
-    n_segments = len(rec['graphs']) if rec['graphs'] else (4 if split_step else 1)
+    n_segments = len(rec['graphs']) if rec['graphs'] else (rec.get('n_segments', 4) if split_step else 1)
 
     out = {
         'metric': 'collocation-points/sec (fwd+PDE-Jacobian+bwd)', 'value': pts_per_s, 'unit': 'points/s', 'n_gpus': world,
@@ -604,7 +604,7 @@ def main():
                    'collocation_batch': 'one fixed synthetic batch per rank, replayed every step; the on-device sampler (SURVEY 8 f1) is OUTSIDE the timed graph '
                                         '(tools/reference_step.py times it inside)',
                    'points_per_gpu': args.points, 'precision_mode': args.prec, 'hip_graph': graphed, 'parallelism': 'dp%d' % world,
-                   'step_segments': n_segments,           # N > 1: three backward segments + the optimiser, or one graph with the collectives captured
+                   'step_segments': n_segments,           # N > 1: two backward segments (lead batches: three) + the optimiser, or one graph with the collectives captured
                    'step_form': rec['step_form'], 'collectives_in_graph': bool(split_step and graphed and n_segments == 1),
                    'graph_branches': list(C.FROZEN.branches)},
         # ms_per_step is the MEDIAN of `timed_blocks` blocks of `steps` replays each, taken after the clock has settled (`prewarm_*`); the first block

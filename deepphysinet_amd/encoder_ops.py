@@ -378,6 +378,14 @@ class _DataEmbeddingFn(torch.autograd.Function):
         return None, dw.view(ctx.w_shape), db, g_tok, None, None, None, None, None, None
 
 
+def embed_wgrad_rides_with_stack(n_fields=1):
+    """Does the token convolution's weight gradient come out of the encoder stack's ONE weight-gradient launch (_EncoderStackFn.backward:
+    a single field on the fused path) instead of a launch of the embedding's own backward?  Then the data-parallel step has nothing to
+    overlap between the encoder's and the embedding's gradient buckets: they complete together and travel as ONE all-reduce
+    (interface_physics.StagedPdeStep, InterfacePhysics.training_step)."""
+    return n_fields == 1 and not config.FROZEN.embed_own_wgrad and not config.FROZEN.encoder_unfused
+
+
 def _params_ok(params, device):
     """Every parameter the fused kernels read through a raw pointer: fp32, on `device`, contiguous (a .half() / .double() model, or one on another
     GPU, would be read as fp32 words of the wrong size -- silently wrong, or out of bounds): otherwise the per-op path handles or rejects it."""

@@ -329,12 +329,18 @@ class InterfacePhysics(nn.Module):
             grad_sync.reduce_bucket(0, 2)
             x0 = getattr(self.physics_net.meta_net.model, 'last_embedding', None)
             if x0 is not None and x0.requires_grad:
+                from .. import encoder_ops
+                together = encoder_ops.embed_wgrad_rides_with_stack(1)     # (the stack's weight-gradient launch also wrote the token convolution's)
                 g3 = torch.autograd.grad([meta_out], [x0] + buckets[2], grad_outputs=[g2[0]], allow_unused=True)
                 optimizer.place_gradients(buckets[2], g3[1:])
-                grad_sync.reduce_bucket(2)
+                if not together:
+                    grad_sync.reduce_bucket(2)
                 g4 = torch.autograd.grad([x0], buckets[3], grad_outputs=[g3[0]], allow_unused=True)
                 optimizer.place_gradients(buckets[3], g4)
-                grad_sync.reduce_bucket(3)
+                if together:
+                    grad_sync.reduce_bucket(2, 4)
+                else:
+                    grad_sync.reduce_bucket(3)
             else:
                 g3 = torch.autograd.grad([meta_out], buckets[2] + buckets[3], grad_outputs=[g2[0]], allow_unused=True)
                 optimizer.place_gradients(buckets[2] + buckets[3], g3)
@@ -551,6 +557,8 @@ class StagedPdeStep:
         stages[1]  encoder layers + norm + projection backward       -> layout bucket 2: stage_buckets[1] = (2, 3)
         stages[2]  data embedding backward (the token convolution's 7.4 MB gradient: the last to complete, it travels alone so that the
                    other 6.4 MB of the encoder start one launch earlier) -> layout bucket 3: stage_buckets[2] = (3, 4)
+    One field on the fused encoder (round 6): stages[1] and stages[2] are ONE stage and buckets 2, 3 one all-reduce -- the token convolution's gradient is
+    written by the encoder stack's own weight-gradient launch, so both buckets complete together (encoder_ops.embed_wgrad_rides_with_stack).
     Each stage is a plain callable (capturable in a hipGraph of its own, on one capture stream and one memory pool); after stage i the caller
     queues `grad_sync.reduce_bucket(*stage_buckets[i])`.  (Round 2 cut the heads' backward off as a stage of its own: three collectives and
     four graph segments cost 1.80 -> 2.00 ms with a one-rank RCCL group; the heads' backward is two launches, so the statics' all-reduce
@@ -567,6 +575,13 @@ class StagedPdeStep:
         self.loss = None
         self.stages = (self.stage_points_and_heads, self.stage_encoder, self.stage_embedding)
         self.stage_buckets = ((0, 2), (2, 3), (3, 4))
+        from .. import encoder_ops
+        if not self.lead_batch and encoder_ops.embed_wgrad_rides_with_stack(1):
+            # Round 6: one field on the fused encoder -- the token convolution's weight gradient is a problem of the stack's ONE weight-gradient launch,
+            # the embedding's own backward launches nothing: buckets 2 and 3 complete together.  Two all-reduces behind each other (and a graph
+            # segment that is empty) were 73 us of exposed tail on a one-rank RCCL group (gap 21 + 10 + gap 17 + 8 + gap 17); one is gap + 16 + gap.
+            self.stages = (self.stage_points_and_heads, self.stage_encoder_and_embedding)
+            self.stage_buckets = ((0, 2), (2, 4))
         self._seed = None
 
     def _assign(self, params, grads):
@@ -619,6 +634,10 @@ class StagedPdeStep:
         g = torch.autograd.grad([self.meta_out], [self.x0] + params, grad_outputs=[self.g_meta], allow_unused=True)
         self.g_x0 = g[0]
         self._assign(params, g[1:])
+
+    def stage_encoder_and_embedding(self):
+        self.stage_encoder()
+        self.stage_embedding()
 
     def stage_embedding(self):
         if self.g_x0 is not None:

@@ -153,8 +153,9 @@ def test_fused_optimizer_is_a_torch_optimizer_with_device_side_lr():
 
 
 def test_staged_step_equals_the_plain_step():
-    """StagedPdeStep (three backward segments, the layout buckets stage_buckets[i] complete after segment i) gives bit-for-bit the gradients of
-    loss.backward()."""
+    """StagedPdeStep (backward segments; the layout buckets stage_buckets[i] complete after segment i) gives bit-for-bit the gradients of
+    loss.backward().  One field on the fused encoder: TWO segments, the encoder's and the embedding's buckets as one all-reduce (round 6: the
+    token convolution's gradient is written by the stack's own weight-gradient launch, the two buckets complete together)."""
     from deepphysinet_amd.interface.interface_physics import StagedPdeStep
     g = _gpu(synthetic_inputs(700, tag='inter'))
     m = _model()
@@ -164,6 +165,7 @@ def test_staged_step_equals_the_plain_step():
     loss.backward()
     plain = {k: p.grad.clone() for k, p in m.physics_net.named_parameters()}
     st = StagedPdeStep(m, opt, g)
+    assert len(st.stages) == 2 and st.stage_buckets == ((0, 2), (2, 4))
     done = []
     for i, stage in enumerate(st.stages):
         stage()
@@ -197,6 +199,7 @@ def test_staged_lead_batch_step_equals_place_lead_batch():
     loss.backward()
     plain = {k: p.grad.clone() for k, p in m.physics_net.named_parameters()}
     st = StagedPdeStep(m, opt, lead, lead_batch=True)
+    assert len(st.stages) == 3 and st.stage_buckets == ((0, 2), (2, 3), (3, 4))      # (a batch's embedding backward is a launch of its own)
     for i, stage in enumerate(st.stages):
         stage()
         for k in range(*st.stage_buckets[i]):
@@ -289,7 +292,7 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     out = json.loads(line)
-    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['step_segments'] == 4
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['step_segments'] == 3
     assert out['value'] > 0 and np.isfinite(out['ms_per_step'])
     assert out['config']['workload'].startswith('configs[3]') and out['collective']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
 
@@ -321,7 +324,7 @@ def test_bench_eight_ranks_on_one_device_run_the_scaling_benchmarks_code_path():
                         '--no-prewarm', '--no-cpu-baseline', '--no-alt', '--no-power', '--no-lead-probe'], env=env, capture_output=True, text=True, timeout=2400)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    assert out['n_gpus'] == 8 and out['config']['parallelism'] == 'dp8' and out['config']['step_segments'] == 4 and out['config']['hip_graph'] is True
+    assert out['n_gpus'] == 8 and out['config']['parallelism'] == 'dp8' and out['config']['step_segments'] == 3 and out['config']['hip_graph'] is True
     coll = out['collective']
     assert coll['world'] == 8 and len(coll['devices']) == 8 and sorted(d['rank'] for d in coll['devices']) == list(range(8))
     assert len({d['pid'] for d in coll['devices']}) == 8                       # eight processes
@@ -344,7 +347,7 @@ def test_bench_step_with_rccl_collectives_on_one_rank():
                            timeout=1200)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]))
-    assert outs[0]['config']['step_segments'] == 4 and outs[1]['config']['step_segments'] == 1
+    assert outs[0]['config']['step_segments'] == 3 and outs[1]['config']['step_segments'] == 1
     for k, b in outs[1]['pde_losses'].items():                            # after the same number of optimiser steps (--no-prewarm: a fixed count)
         a = outs[0]['pde_losses'][k]
         assert np.isfinite(a) and abs(a - b) <= 1e-5 * abs(b), (k, a, b)
@@ -376,7 +379,7 @@ def test_bench_trial_of_the_one_graph_form_keeps_the_segment_forms_line_when_it_
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
-    assert out['config']['step_segments'] == 4 and out['value'] > 0
+    assert out['config']['step_segments'] == 3 and out['value'] > 0
     assert out['collective']['step_form_trial']['error'].startswith('stalled in: first replays of the one-graph form'), out['collective']['step_form_trial']
     assert 'the one-graph trial stalled' in r.stderr
     r = subprocess.run(args, env=dict(env, MASTER_PORT=str(_free_port())), capture_output=True, text=True, timeout=1200)
@@ -384,7 +387,7 @@ def test_bench_trial_of_the_one_graph_form_keeps_the_segment_forms_line_when_it_
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     t = out['collective']['step_form_trial']
     assert t['error'] is None and t['segments_ms'] > 0 and t['one_graph_ms'] > 0, t
-    assert out['config']['step_segments'] == (1 if t['one_graph_ms'] < 0.99 * t['segments_ms'] else 4)
+    assert out['config']['step_segments'] == (1 if t['one_graph_ms'] < 0.99 * t['segments_ms'] else 3)
     if out['config']['step_segments'] == 1:
         assert t['segment_form_result']['ms_per_step'] > 0 and out['config']['collectives_in_graph']
 
