@@ -40,3 +40,9 @@ for s, e, n in step:
         cur_end = e
 print('kernels %d  span %.1f us  union-busy %.1f us  idle gaps %.1f us  sum of durations %.1f us' %
       (len(step), (cur_end - t0) / 1e3, busy / 1e3, tot_gap / 1e3, sum(e - s for s, e, _ in step) / 1e3))
+# period: start of one step to the start of the next, over the steps that directly follow each other (what a block time divided by its steps measures;
+# period - span = the idle time BETWEEN two replays)
+pairs = [(rows[a2][0] - rows[a1][0]) / 1e3 for (a1, b1), (a2, b2) in zip(steps_, steps_[1:]) if a2 == b1]
+if pairs:
+    pairs.sort()
+    print('period between consecutive steps: median %.1f us (min %.1f, %d pairs)' % (pairs[len(pairs) // 2], pairs[0], len(pairs)))
