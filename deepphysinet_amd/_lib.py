@@ -110,6 +110,7 @@ EXPORTS = {
     'dpn_pack_weights': (c_int, [POINTER(DpnNetPtrs), c_int, c_void_p, c_void_p]),
     'dpn_fwd_form': (c_int, [c_int, c_int]),
     'dpn_pack_weights_form': (c_int, [POINTER(DpnNetPtrs), c_int, c_int, c_void_p, c_void_p]),
+    'dpn_pack_weights_batch': (c_int, [POINTER(DpnNetPtrs), c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
     'dpn_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
                         c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_fwd_ref': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
@@ -120,6 +121,7 @@ EXPORTS = {
     'dpn_residual': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(DpnGeometry), POINTER(DpnPhysics), c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p]),
     'dpn_residual_finish': (c_int, [c_void_p, c_int64, POINTER(DpnPhysics), c_void_p, c_void_p]),
+    'dpn_residual_finish_batch': (c_int, [c_void_p, c_int64, c_int, POINTER(DpnPhysics), c_void_p, c_void_p]),
     'dpn_bwd_points': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dpn_bwd_points_scaled': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, POINTER(DpnGeometry), c_void_p, c_int,

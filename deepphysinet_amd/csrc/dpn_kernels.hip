@@ -126,10 +126,21 @@ struct PackArgs {
     char* packed;
     int ns;
     int form;              // 0: the seven-GEMM stream (ring kernels), 1: the fused five-GEMM stream (dpn_fwd_tiles_kernel; dpn_layout.h)
+    // a batch of fields in ONE launch (grid.y = kNets * n_fields): field f reads the hyper-network outputs of field 0 moved by f * heads_stride /
+    // f * evec_stride floats (w1b1, w2b2 | evec; the static tensors are shared) and writes its packed block at packed + f * packed_stride bytes
+    int n_fields;
+    long heads_stride, evec_stride, packed_stride;
 };
+// the pointer table of (net, field): wave-uniform scalar arithmetic on a copy of the kernel argument
+DEV DpnNetPtrs pack_net(const PackArgs& a, const int net, const int field) {
+    DpnNetPtrs P = a.net[net];
+    P.w1b1 += field * a.heads_stride;
+    P.w2b2 += field * a.heads_stride;
+    P.evec += field * a.evec_stride;
+    return P;
+}
 
-DEV float pack_src(const PackArgs& a, const int net, int kb, int lane, int e) {
-    const DpnNetPtrs& P = a.net[net];
+DEV float pack_src(const DpnNetPtrs& P, int kb, int lane, int e) {
     const int i = lane & 31, h = lane >> 5;
     if (kb < kS1) {                                   // S0: w1, rows o, K = PE3 slots
         const int T = kb / 12, ks = kb % 12;
@@ -161,9 +172,8 @@ DEV float pack_src(const PackArgs& a, const int net, int kb, int lane, int e) {
 // sums the reduction index o over [32 og, 32 og + 32) and the eight partial sums are joined in a fixed order through LDS.  (One block per net walking
 // 256-long chains of dependent loads -- three of them in the fused form -- was the long pole of the launch: 31-40 us.)
 constexpr int kVecParts = 8;
-DEV void pack_vectors(const PackArgs& a, const int net, const int part) {
-    const DpnNetPtrs& P = a.net[net];
-    float* vec = reinterpret_cast<float*>(a.packed + (long)net * pack_bytes_per_net(a.ns) + (long)kPackKB * 1024 * a.ns);
+DEV void pack_vectors(const PackArgs& a, const DpnNetPtrs& P, char* packed_net, const int part) {      // packed_net: this (field, net)'s packed block
+    float* vec = reinterpret_cast<float*>(packed_net + (long)kPackKB * 1024 * a.ns);
     const int tid = threadIdx.x, og = tid >> 5;
     const int idx = 32 * part + (tid & 31);
     const int h = idx >> 7, T = (idx >> 4) & 7, r = idx & 15;
@@ -220,10 +230,12 @@ DEV void pack_vectors(const PackArgs& a, const int net, const int part) {
 #if DPN_HAS_REST
 __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
     const int mcols = gridDim.x - kVecParts;                                          // block columns of matrix fragments, then kVecParts of vector blocks
-    if ((int)blockIdx.x >= mcols) { pack_vectors(a, blockIdx.y, blockIdx.x - mcols); return; }
-    const int net = blockIdx.y;
+    const int field = blockIdx.y / kNets, net = blockIdx.y - field * kNets;
     const int ns = a.ns;
-    uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
+    const DpnNetPtrs P = pack_net(a, net, field);
+    char* packed_net = a.packed + field * a.packed_stride + (long)net * pack_bytes_per_net(ns);
+    if ((int)blockIdx.x >= mcols) { pack_vectors(a, P, packed_net, blockIdx.x - mcols); return; }
+    uint4* dst = reinterpret_cast<uint4*>(packed_net);
     const int total = kPackKB * 64;                   // (kb, lane) pairs (form 0; the fused form has its own kernel, dpn_pack_fused_kernel)
     for (int u = blockIdx.x * 256 + threadIdx.x; u < total; u += mcols * 256) {
         const int kb = u >> 6;
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(256) void dpn_pack_matrices_kernel(PackArgs a) {
         u16 hi[8], lo[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float x = pack_src(a, net, kb, lane, e);
+            const float x = pack_src(P, kb, lane, e);
             hi[e] = f2bf(x);
             lo[e] = f2bf(x - bf2f(hi[e]));
         }
@@ -257,11 +269,12 @@ __global__ __launch_bounds__(256) void dpn_pack_fused_kernel(PackArgs a) {
     // Workgroups go to the eight XCDs round-robin in dispatch order: every XCD gets a CONTIGUOUS range of the (net, block) list, so that a net's W1 / w2 / Wd
     // are fetched into one or two L2s instead of all eight: 20.0 -> 16.2 us per launch (tools/pack_probe.py, profiles/round6_xcd_contiguous.txt).
 #ifdef PACK_NO_XCD_REMAP
-    const int net = blockIdx.y, bx = blockIdx.x, ns = a.ns;
+    const int field = blockIdx.y / kNets, net = blockIdx.y - field * kNets, bx = blockIdx.x, ns = a.ns;
 #else
-    const int lin = blockIdx.x + kFusedBlocks * blockIdx.y, virt = (lin & 7) * (kFusedBlocks * kNets / 8) + (lin >> 3);
+    // (a batch of fields: grid.y = kNets * n_fields, the list is (field, net, block): an XCD then works on whole fields)
+    const int lin = blockIdx.x + kFusedBlocks * blockIdx.y, virt = (lin & 7) * (kFusedBlocks * kNets / 8 * a.n_fields) + (lin >> 3);
     static_assert(kFusedBlocks * kNets % 8 == 0, "remap");
-    const int net = virt / kFusedBlocks, bx = virt - net * kFusedBlocks, ns = a.ns;
+    const int fnet = virt / kFusedBlocks, bx = virt - fnet * kFusedBlocks, ns = a.ns, field = fnet / kNets, net = fnet - field * kNets;
 #endif
 #ifdef PACK_ABL_MASK        // ablation builds (wrong results on purpose, timing only: tools/variant_build.py --unit=1 -DPACK_ABL_MASK=m): only the roles in bit mask m run.
     // Round 6, tools/pack_probe.py (us per launch): all 19.9-20.2; role 0 alone 7.7, 1: 6.5, 2: 8.0, 3: 5.7, 4: 5.1; {0,1} 12.1, {0,1,2} 17.7, {3,4} 6.9, {0,1,3,4} 16.8:
@@ -269,9 +282,10 @@ __global__ __launch_bounds__(256) void dpn_pack_fused_kernel(PackArgs a) {
     // of its own row today) was built and changed nothing (21.1-21.9 us): it is not the request pattern.  profiles/round6_pack_fused_roles.txt
     if (!((PACK_ABL_MASK >> (bx < 64 ? 0 : bx < 112 ? 1 : bx < 120 ? 2 : bx < 132 ? 3 : 4)) & 1)) return;
 #endif
-    if (bx >= 132) { pack_vectors(a, net, bx - 132); return; }
-    const DpnNetPtrs& P = a.net[net];
-    uint4* dst = reinterpret_cast<uint4*>(a.packed + (long)net * pack_bytes_per_net(ns));
+    const DpnNetPtrs P = pack_net(a, net, field);
+    char* packed_net = a.packed + field * a.packed_stride + (long)net * pack_bytes_per_net(ns);
+    if (bx >= 132) { pack_vectors(a, P, packed_net, bx - 132); return; }
+    uint4* dst = reinterpret_cast<uint4*>(packed_net);
     auto put = [&](const int kb, const int lane, const float (&x)[8]) __attribute__((always_inline)) {
         u16 hi[8], lo[8];
 #pragma unroll
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(256) void dpn_pack_fused_kernel(PackArgs a) {
             if (kb >= kS1) kb += kS5 - kS1;
             float x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = pack_src(a, net, kb, lane, e);
+            for (int e = 0; e < 8; ++e) x[e] = pack_src(P, kb, lane, e);
             put(kb, lane, x);
         }
         return;
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(256) void dpn_pack_fused_kernel(PackArgs a) {
     if (role == 2) {                                                      // C2[o] = (W1 cvec)[o] + bf1[o], in the vectors' [h][T][r] order
         if (threadIdx.x < 32) {
             const int o = 32 * To + threadIdx.x, w_ = o & 31;
-            float* vec = reinterpret_cast<float*>(a.packed + (long)net * pack_bytes_per_net(ns) + (long)kPackKB * 1024 * ns);
+            float* vec = reinterpret_cast<float*>(packed_net + (long)kPackKB * 1024 * ns);
             vec[kVecC2 * 256 + ((w_ >> 2) & 1) * 128 + (o >> 5) * 16 + (w_ & 3) + 4 * (w_ >> 3)] = tile[threadIdx.x][0] + P.bf1[o];
         }
         return;
@@ -1184,6 +1198,9 @@ __global__ __launch_bounds__(256) void dpn_residual_kernel(ResArgs a) {
 }
 
 __global__ __launch_bounds__(384) void dpn_residual_finish_kernel(const double* partials, int64_t n, DpnPhysics ph, float* losses) {
+    // (a batch of fields: one workgroup per field, its block rows and its seven outputs side by side)
+    partials += (int64_t)blockIdx.x * ((n + 255) / 256) * 6;
+    losses += (int64_t)blockIdx.x * 7;
     // partials: [ceil(n/256)][6] block rows of dpn_residual.  Wave e adds equation e (lane l takes rows l, l+64, ... in order, then a
     // fixed shuffle tree).  losses[0..5]: the six scaled terms; losses[6]: their sum in the reference's order of additions (:301)
     __shared__ float l[6];
@@ -2634,20 +2651,27 @@ static int sgemm_batch_launch(int n_problems, const DpnGemmProblem* problems, in
 
 // form 0: the seven-GEMM stream of the ring kernels; form 1: the fused five-GEMM stream of dpn_fwd_tiles_kernel (dpn_layout.h) -- ONE launch forms
 // A = W1 w2, B = W1 Wd and C2 = W1 cvec + bf1 on the exact-fp32 matrix instruction and writes them as fragments (dpn_pack_fused_kernel)
-int dpn_pack_weights_form(const DpnNetPtrs nets[DPN_NETS], int prec, int form, void* packed, void* stream) {
-    if (!nets || !packed || (prec != 1 && prec != 2) || (form != 0 && form != 1)) return -1;
+int dpn_pack_weights_batch(const DpnNetPtrs nets[DPN_NETS], int n_fields, int64_t heads_stride, int64_t evec_stride, int prec, int form, void* packed,
+                           int64_t packed_stride, void* stream) {
+    if (!nets || !packed || (prec != 1 && prec != 2) || (form != 0 && form != 1) || n_fields < 1 || n_fields > 65535 / kNets) return -1;
+    if (n_fields > 1 && (heads_stride <= 0 || evec_stride <= 0 || packed_stride < (int64_t)kNets * pack_bytes_per_net(prec) || (packed_stride & 15))) return -1;
     PackArgs a;
     for (int k = 0; k < kNets; ++k) a.net[k] = nets[k];
     a.packed = reinterpret_cast<char*>(packed);
     a.ns = prec;
     a.form = form;
+    a.n_fields = n_fields; a.heads_stride = heads_stride; a.evec_stride = evec_stride; a.packed_stride = packed_stride;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (form == 1) {                                                      // products + packing in one launch (no fp32 scratch)
-        hipLaunchKernelGGL(dpn_pack_fused_kernel, dim3(kFusedBlocks, kNets), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(dpn_pack_fused_kernel, dim3(kFusedBlocks, kNets * n_fields), dim3(256), 0, s, a);
         return ck(hipGetLastError());
     }
-    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(40 + kVecParts, kNets), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dpn_pack_matrices_kernel, dim3(40 + kVecParts, kNets * n_fields), dim3(256), 0, s, a);
     return ck(hipGetLastError());
+}
+
+int dpn_pack_weights_form(const DpnNetPtrs nets[DPN_NETS], int prec, int form, void* packed, void* stream) {
+    return dpn_pack_weights_batch(nets, 1, 0, 0, prec, form, packed, 0, stream);
 }
 
 int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, void* stream) {
@@ -2744,10 +2768,13 @@ int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t
     return ck(hipGetLastError());
 }
 
-int dpn_residual_finish(const double* loss_sums, int64_t n, const DpnPhysics* phys, float* losses, void* stream) {
-    if (!loss_sums || !phys || !losses) return -1;
-    hipLaunchKernelGGL(dpn_residual_finish_kernel, dim3(1), dim3(384), 0, reinterpret_cast<hipStream_t>(stream), loss_sums, n, *phys, losses);
+int dpn_residual_finish_batch(const double* loss_sums, int64_t n, int n_fields, const DpnPhysics* phys, float* losses, void* stream) {
+    if (!loss_sums || !phys || !losses || n <= 0 || n_fields < 1) return -1;
+    hipLaunchKernelGGL(dpn_residual_finish_kernel, dim3(n_fields), dim3(384), 0, reinterpret_cast<hipStream_t>(stream), loss_sums, n, *phys, losses);
     return ck(hipGetLastError());
+}
+int dpn_residual_finish(const double* loss_sums, int64_t n, const DpnPhysics* phys, float* losses, void* stream) {
+    return dpn_residual_finish_batch(loss_sums, n, 1, phys, losses, stream);
 }
 
 int dpn_smooth_l1(const float* out_n, const float* labels, int64_t n, float beta, float scale, double* loss_sum, float* g_out, int accumulate,

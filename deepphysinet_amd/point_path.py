@@ -136,12 +136,14 @@ def _net_ptrs(heads, evec, statics, cls=None):
 class _Workspace:
     """Buffers of one forward call that its backward needs again."""
 
-    def __init__(self, n, prec, device):
+    def __init__(self, n, prec, device, packed=None):
         lib = L.load()
         self.sizes = L.DpnSizes()
         L.check(lib.dpn_sizes(n, prec, ctypes.byref(self.sizes)), 'dpn_sizes')
         self.n, self.prec, self.device = n, prec, device
-        self.packed = torch.empty(self.sizes.packed, dtype=torch.uint8, device=device)
+        # packed: this field's block of a batch packed in ONE launch (_pack_batch); the forward call then has no packing launch of its own
+        self.prepacked = packed is not None
+        self.packed = packed if packed is not None else torch.empty(self.sizes.packed, dtype=torch.uint8, device=device)
         self.saved = None
 
     def alloc_saved(self):
@@ -203,7 +205,8 @@ def _forward_points(cfg: PointConfig, ws: _Workspace, nets, x, y, t, pe_in, coor
     # the packed form the forward launch reads: fused (A = W1 w2, B = W1 Wd: five GEMMs per point and net) for the hi+lo mode's tile-split kernel,
     # the plain matrices for the ring kernels (plain bf16, caller-encoded coordinates)
     form = lib.dpn_fwd_form(cfg.prec, 0 if pe_in is None else 1)
-    L.check(lib.dpn_pack_weights_form(nets, cfg.prec, form, _ptr(ws.packed), _stream()), 'dpn_pack_weights')
+    if not ws.prepacked:
+        L.check(lib.dpn_pack_weights_form(nets, cfg.prec, form, _ptr(ws.packed), _stream()), 'dpn_pack_weights')
     out_n = torch.empty((n, 6), dtype=torch.float32, device=dev)
     # with caller-encoded coordinates the kernel hands back d out / d pe_in [n, 6, 192] in place of the (x, y, t) Jacobian
     jac_n = torch.empty((n, 6, 3 if pe_in is None else 192), dtype=torch.float32, device=dev) if want_jac else None
@@ -431,6 +434,21 @@ class _PdeLossFn(torch.autograd.Function):
         return (None, None, None, None, None, None, ghd, gev, *gst)
 
 
+def _pack_batch(cfg, heads, evec, statics, n):
+    """The packed weight blocks of B fields (heads [B, 256, 2700], evec [B, 6, 256], shared statics) in ONE launch -> uint8 [B, stride]; row b is
+    field b's `_Workspace.packed`.  (Per field the launch is 17 us of latency-bound tiles, 61 of them 1 ms of a 51-ms step: DESIGN.md 6a.)"""
+    lib = L.load()
+    sizes = L.DpnSizes()
+    L.check(lib.dpn_sizes(n, cfg.prec, ctypes.byref(sizes)), 'dpn_sizes')
+    B = heads.shape[0]
+    stride = (int(sizes.packed) + 255) // 256 * 256
+    packed = torch.empty((B, stride), dtype=torch.uint8, device=heads.device)
+    nets = _net_ptrs(heads[0], evec[0], statics)
+    form = lib.dpn_fwd_form(cfg.prec, 0)
+    L.check(lib.dpn_pack_weights_batch(nets, B, heads.stride(0), evec.stride(0), cfg.prec, form, _ptr(packed), stride, _stream()), 'dpn_pack_weights_batch')
+    return packed
+
+
 class _PdeLossBatchFn(torch.autograd.Function):
     """BASELINE configs[2]: B field samples (distinct field / lead time => distinct hyper-network weights) with N collocation points each
     in ONE step.  losses [B, 6] and totals [B]; heads [B, 256, 2700], evec [B, 6, 256], point tensors [B, N(,6)].  The point kernels run
@@ -468,9 +486,11 @@ class _PdeLossBatchFn(torch.autograd.Function):
         need_grad = bool(grad_enabled) and any(v.requires_grad for v in (heads, evec) + tuple(statics))
         eager = need_grad and config.FROZEN.batch_eager_backward
         losses7 = torch.empty((B, 7), dtype=torch.float32, device=dev)
-        sums = torch.empty(((n + 255) // 256) * 6, dtype=torch.float64, device=dev)
+        sums = torch.empty((B, ((n + 255) // 256) * 6), dtype=torch.float64, device=dev)      # per field: block rows, all reduced by ONE launch behind the loop
         geo, ph = cfg.geometry(), cfg.physics()
         fields = []
+        one_launch = config.FROZEN.batch_pack                     # every field's weight block: one launch in front of the loop
+        packed = _pack_batch(cfg, hd_, ev_, st, n) if one_launch else None
         if eager:
             starts = _PdeLossBatchFn._static_layout()
             one = torch.ones(1, dtype=torch.float32, device=dev)
@@ -480,20 +500,23 @@ class _PdeLossBatchFn(torch.autograd.Function):
             g_evec = torch.empty((B, 6, 256), dtype=torch.float32, device=dev)
             flat = torch.empty((B, starts[-1]), dtype=torch.float32, device=dev)
         for b in range(B):
-            ws = _Workspace(n, cfg.prec, dev)
+            ws = _Workspace(n, cfg.prec, dev, packed=packed[b] if one_launch else None)
             nets = _net_ptrs(hd_[b], ev_[b], st)
             out_n, jac_n = _forward_points(cfg, ws, nets, x_[b], y_[b], t_[b], None, cd_[b], want_jac=True, want_saved=need_grad)
             # eager: the block sums of the losses AND d total_b / d (out, Jacobian) for a unit cotangent in ONE pass over the points
             L.check(lib.dpn_residual(_ptr(out_n), _ptr(jac_n), _ptr(f_[b]), n, ctypes.byref(geo), ctypes.byref(ph), None,
-                                     _ptr(one) if eager else None, _ptr(sums), _ptr(g_out) if eager else None, _ptr(g_jxi) if eager else None,
+                                     _ptr(one) if eager else None, _ptr(sums[b]), _ptr(g_out) if eager else None, _ptr(g_jxi) if eager else None,
                                      _stream()), 'dpn_residual')
-            L.check(lib.dpn_residual_finish(_ptr(sums), n, ctypes.byref(ph), _ptr(losses7[b]), _stream()), 'dpn_residual_finish')
             if eager:                                             # d total_b / d (this field's weights)
                 g_stat = [flat[b, starts[i]:starts[i + 1]].view(STATIC_SHAPES[i % 8]) for i in range(48)]
                 _backward_points(cfg, ws, nets, x_[b], y_[b], t_[b], None, cd_[b], g_out, g_jxi, st, into=(g_heads[b], g_evec[b], g_stat))
                 del ws, out_n, jac_n
             elif need_grad:
                 fields.append((ws, out_n, jac_n))
+            if not one_launch:
+                L.check(lib.dpn_residual_finish(_ptr(sums[b]), n, ctypes.byref(ph), _ptr(losses7[b]), _stream()), 'dpn_residual_finish')
+        if one_launch:
+            L.check(lib.dpn_residual_finish_batch(_ptr(sums), n, B, ctypes.byref(ph), _ptr(losses7), _stream()), 'dpn_residual_finish')
         ctx.cfg, ctx.fields = cfg, fields
         ctx.eager = (g_heads, g_evec, flat) if eager else None
         ctx.keep = (x_, y_, t_, f_, cd_, hd_, ev_, st)

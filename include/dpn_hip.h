@@ -106,6 +106,11 @@ int dpn_clock_rate_khz(int* khz);
 int dpn_fwd_form(int prec, int has_pe_in);
 int dpn_pack_weights_form(const DpnNetPtrs nets[DPN_NETS], int prec, int form, void* packed, void* stream);
 int dpn_pack_weights(const DpnNetPtrs nets[DPN_NETS], int prec, void* packed, void* stream);
+/* The same for n_fields field samples in ONE launch (BASELINE configs[2]: a batch of forecast leads, each with its own hyper-network output): nets = the
+ * pointer table of field 0; field f reads w1b1 / w2b2 moved by f * heads_stride floats and evec by f * evec_stride floats (the static tensors are
+ * shared) and writes its packed block at packed + f * packed_stride bytes (>= DpnSizes.packed, a multiple of 16).  n_fields = 1 ignores the strides. */
+int dpn_pack_weights_batch(const DpnNetPtrs nets[DPN_NETS], int n_fields, int64_t heads_stride, int64_t evec_stride, int prec, int form, void* packed,
+                           int64_t packed_stride, void* stream);
 
 /* Forward + coordinate Jacobian (replaces PhysicsNet.forward's six VariableNet calls, physics_net.py:49-54,
  * and the 18 unique autograd.grad derivatives of interface_physics.py:90-95).
@@ -144,6 +149,8 @@ int dpn_residual(const float* out_n, const float* jac_n, const float* f, int64_t
                  const DpnPhysics* phys, const float* gl /*[6] or NULL*/, const float* gtot /*[1] or NULL*/, double* loss_sums,
                  float* g_out, float* g_jxi, void* stream);
 int dpn_residual_finish(const double* loss_sums, int64_t n_points, const DpnPhysics* phys, float* losses, void* stream);
+/* n_fields fields of n_points each in one launch: loss_sums [n_fields][ceil(n_points / 256)][6], losses [n_fields][7]. */
+int dpn_residual_finish_batch(const double* loss_sums, int64_t n_points, int n_fields, const DpnPhysics* phys, float* losses, void* stream);
 
 /* Backward, stage 1: per-point cotangent streams -> the operands of the weight-gradient reductions.
  *   g_out [N][6]; g_jxi [N][6][3] or NULL (value-only loss, e.g. the data loss). */

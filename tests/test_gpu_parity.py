@@ -556,6 +556,57 @@ def test_encoder_kernels_gradients_vs_torch():
     assert torch.equal(ya, linear(xa, wa, ba))
 
 
+@pytest.mark.parametrize('prec', ['bf16x2', 'bf16'])
+def test_batched_weight_packing_and_loss_finish_are_bitwise_the_per_field_launches(prec):
+    """Lead batches (configs[2]) pack the weight blocks of all fields in ONE dpn_pack_weights_batch launch and finish the losses of all fields in ONE
+    dpn_residual_finish_batch launch (round 6; per field before: 61 x (17 + 4.6) us of a 51-ms step).  Same arithmetic, other grid: every field's
+    packed block must equal dpn_pack_weights_form's byte for byte (both packed forms), and pde_losses_batch must give torch.equal losses and
+    gradients with the switch on and off (DPN_BATCH_PACK)."""
+    import ctypes
+    from deepphysinet_amd import _lib as L, config as C, point_path as PP
+    dev = _dev()
+    B, n = 3, 700
+    g = torch.Generator(device='cpu').manual_seed(5)
+    heads = (torch.randn(B, 256, PP.HEADS_COLS, generator=g) * 0.05).to(dev)
+    evec = (torch.randn(B, 6, 256, generator=g) * 0.05).to(dev)
+    statics = [(torch.randn(*PP.STATIC_SHAPES[j % 8], generator=g) * 0.05).to(dev) for j in range(48)]
+    lib = L.load()
+    pr = 2 if prec == 'bf16x2' else 1
+    sizes = L.DpnSizes()
+    L.check(lib.dpn_sizes(n, pr, ctypes.byref(sizes)), 'dpn_sizes')
+    stride = (int(sizes.packed) + 255) // 256 * 256
+    for form in (0, 1):
+        if form == 1 and pr != 2:
+            continue
+        batch = torch.zeros((B, stride), dtype=torch.uint8, device=dev)
+        L.check(lib.dpn_pack_weights_batch(PP._net_ptrs(heads[0], evec[0], statics), B, heads.stride(0), evec.stride(0), pr, form, PP._ptr(batch), stride,
+                                           PP._stream()), 'batch')
+        for b in range(B):
+            one = torch.zeros(int(sizes.packed), dtype=torch.uint8, device=dev)
+            L.check(lib.dpn_pack_weights_form(PP._net_ptrs(heads[b], evec[b], statics), pr, form, PP._ptr(one), PP._stream()), 'one')
+            assert torch.equal(batch[b, :int(sizes.packed)], one), (form, b)
+    # the step on top of it: losses and every parameter gradient with the switch on and off
+    Bm, N = 3, 300
+    m = _model(prec)
+    lf = m.train_cfg['losses']['loss_factor']
+    samples = [_gpu(synthetic_inputs(N, GEO.lon, GEO.lat, GEO.dx, GEO.dy, tag='lead%d' % b, forecast_h=24.0 * b / 360.0)) for b in range(Bm)]
+    stack = lambda k: torch.stack([g_[k].reshape(-1) if g_[k].dim() == 2 and g_[k].shape[1] == 1 else g_[k] for g_ in samples])
+    x, y, t, f = (stack(k) for k in ('x', 'y', 't', 'f'))
+    field = torch.cat([g_['field_data'] for g_ in samples], dim=0)
+    cd = torch.stack([g_['coord_data'] for g_ in samples])
+    fh = torch.cat([g_['forecast_h'] for g_ in samples], dim=0)
+    res = []
+    for on in (True, False):
+        with C.override(batch_pack=on):
+            m.physics_net.zero_grad(set_to_none=True)
+            loss, terms = m.place_lead_batch(x, y, t, f, field, cd, fh, torch.nn.MSELoss(), lf, reduction='sum')
+            loss.backward()
+            res.append((loss.detach().clone(), terms.detach().clone(), {n_: p.grad.detach().clone() for n_, p in m.physics_net.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for n_ in res[0][2]:
+        assert torch.equal(res[0][2][n_], res[1][2][n_]), n_
+
+
 @pytest.mark.parametrize('rows', [287, 2 * 287, 61 * 287])
 def test_wgrad16_mixed_problem_lists_vs_fp64(rows):
     """dpn_wgrad16 (dW = G^T X, db = column sums of G; f16 hi+lo MFMA with running power-of-two scales): lists whose problems differ in tile
