@@ -1731,7 +1731,9 @@ DEV void part_sums_n(const float* partials, const int (&ks)[NQ], int net, const 
     for (int k = 0; k < MAXS; ++k) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            v[k][q] = __builtin_nontemporal_load(partials + ((int64_t)min(k, ks[q] - 1) * kNets + net) * kPartFloats + off[q]);   // read once
+            // (plain loads: with the non-temporal hint -- "read once" -- the partials dpn_wgrad has just written are fetched past the memory-side cache: the finish
+            //  stage's first half 28.8 against 25.4 us alone, dpn_finish_rows 18.5 against 15.7 us in the step; profiles/round6_nontemporal_hints.txt)
+            v[k][q] = partials[((int64_t)min(k, ks[q] - 1) * kNets + net) * kPartFloats + off[q]];
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -2493,6 +2495,7 @@ __global__ __launch_bounds__(256) void dpn_adam_kernel(Table t, const double* su
             // next step reads them first)
             typedef __attribute__((ext_vector_type(4))) float f32x4_t;
             float4 P = *reinterpret_cast<float4*>(p + i);
+            // (round 6 once more, rocprofv3 in the step: the gradient loaded without the hint 27.2, all three loads without 27.6, stores too 28.3 against 25.2 us)
             const f32x4_t Mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(m + i));
             const f32x4_t Vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(v + i));
             const f32x4_t Gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(g + i));
