@@ -634,6 +634,22 @@ def test_wgrad16_mixed_problem_lists_vs_fp64(rows):
             ew = float((w_.double() - ref).abs().max() / ref.abs().max())
             eb = float((b_.double() - bref).abs().max() / bref.abs().max())
             assert ew < 2e-6 and eb < 3e-6, (rows, len(shapes), i, ew, eb)
+    if rows == 287:
+        # the ride-along jobs (LayerNorm parameter sums: out_a[c] = sum_b partial[b][c], out_b[c] = sum_b partial[b][256 + c]) sit BEHIND the list of tiles:
+        # with problems in front of them, and alone (a launch that carries only jobs)
+        nb = 18
+        parts = [torch.randn(nb, 512, generator=g).to(dev) for _ in range(3)]
+        outs = [(torch.full((256,), float('nan'), device=dev), torch.full((256,), float('nan'), device=dev)) for _ in range(3)]
+        G = [torch.randn(rows, 256, generator=g).to(dev) for _ in range(2)]
+        X = [torch.randn(rows, 256, generator=g).to(dev) for _ in range(2)]
+        dW = [torch.empty(256, 256, device=dev) for _ in range(2)]
+        db = [torch.empty(256, device=dev) for _ in range(2)]
+        wgrad16(list(zip(G, X, dW, db)), [(parts[0], outs[0][0], outs[0][1], nb), (parts[1], outs[1][0], outs[1][1], nb)])
+        wgrad16([], [(parts[2], outs[2][0], outs[2][1], nb)])
+        torch.cuda.synchronize()
+        for p_, (oa, ob) in zip(parts, outs):
+            assert torch.allclose(oa, p_[:, :256].sum(0), rtol=1e-5, atol=1e-5) and torch.allclose(ob, p_[:, 256:].sum(0), rtol=1e-5, atol=1e-5)
+        assert float((dW[1].double() - G[1].double().T @ X[1].double()).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize('B', [1, 3])
