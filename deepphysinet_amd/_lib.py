@@ -59,7 +59,9 @@ class DpnEncFwd(Structure):
     """include/dpn_hip.h DpnEncFwd: one row-local forward launch of the encoder (csrc/dpn_encoder_chain.hip)."""
     _fields_ = [('wpack', c_void_p)] + [(n, c_int32) for n in ('n_mats', 'rows', 'row_tiles', 'tail', 'next', 'm_o', 'm_c1', 'm_c2', 'm_n0', 'm_n1', 'm_n2')] + \
                [(n, c_void_p) for n in ('o', 'x', 'xin', 'bo', 'g1', 'be1', 'bc1', 'bc2', 'g2', 'be2', 'gf', 'bef', 'bn0', 'bn1', 'bn2',
-                                        'x1', 'xhat1', 'rstd1', 'pre', 'act', 'x2', 'xhat2', 'rstd2', 'xf', 'xhatf', 'rstdf', 'y0', 'y1', 'y2')]
+                                        'x1', 'xhat1', 'rstd1', 'pre', 'act', 'x2', 'xhat2', 'rstd2', 'xf', 'xhatf', 'rstdf', 'y0', 'y1', 'y2',
+                                        'emb_parts', 'emb_bias', 'emb_pos', 'emb_te', 'emb_token', 'emb_out')] + \
+               [('emb_part_stride', c_int64), ('emb_n_parts', c_int32), ('emb_n_tok', c_int32)]
 
 
 class DpnEncBwd(Structure):

@@ -22,6 +22,7 @@ class Config:
     heads_dmeta_parts: int = 6         # DPN_HEADS_DMETA_PARTS : side-by-side partial problems of the heads' input gradient
     enc_row_tiles: int = 0             # DPN_ENC_ROW_TILES : 16-row tiles per workgroup of dpn_enc_fwd / bwd (0: by problem size)
     embed_own_wgrad: bool = False      # DPN_EMBED_OWN_WGRAD=1 : the token convolution's weight gradient in its own launch
+    embed_defer: bool = True           # DPN_EMBED_DEFER=0 : dpn_embed_assemble as a launch of its own (rounds 1-5) instead of inside the stack's first launch
     batch_eager_backward: bool = True  # DPN_BATCH_EAGER_BACKWARD=0 : park every field's saved state until the backward pass (lead batches)
     batch_pack: bool = True            # DPN_BATCH_PACK=0 : lead batches pack each field's weights and finish its losses in launches of their own (rounds 3-5)
     branches: tuple = ()               # DPN_BRANCHES = comma list of the side branches taken (branch.py): finish (the static half of the point
@@ -45,6 +46,7 @@ class Config:
             heads_dmeta_parts=int(e.get('DPN_HEADS_DMETA_PARTS', '6')),
             enc_row_tiles=int(e.get('DPN_ENC_ROW_TILES', '0')),
             embed_own_wgrad=e.get('DPN_EMBED_OWN_WGRAD') == '1',
+            embed_defer=e.get('DPN_EMBED_DEFER', '1') == '1',
             batch_eager_backward=e.get('DPN_BATCH_EAGER_BACKWARD', '1') == '1',
             batch_pack=e.get('DPN_BATCH_PACK', '1') == '1',
             branches=tuple(b for b in e.get('DPN_BRANCHES', '').split(',') if b) if e.get('DPN_NO_BRANCHES') != '1' else (),

@@ -339,6 +339,10 @@ struct FwdArgs {
     const float *o, *x, *xin;
     const float* vec[kNVecF];
     float *x1, *xhat1, *rstd1, *pre, *act, *x2, *xhat2, *rstd2, *xf, *xhatf, *rstdf, *y0, *y1, *y2;
+    const float *emb_parts, *emb_bias, *emb_pos, *emb_te, *emb_token;       // !TAIL: assemble the input rows here (DpnEncFwd.emb_*)
+    float* emb_out;
+    int64_t emb_part_stride;
+    int emb_n_parts, emb_n_tok;
     ENC_TL_ARG
 };
 template <int NTT>
@@ -351,6 +355,8 @@ struct Lds {
     static constexpr int kBytes = kRed + kWaves * 512 * 4;
 };
 
+constexpr int kEmbAhead = 9;                   // slices of the token convolution fetched at once by the launch that assembles x0 (6 / 9 / 18 measured alike: the 18
+                                               // workgroups pull 311 KB each through their CU's L2 path, +3.9 us on this launch for the 6.9-us launch it replaces)
 template <bool TAIL, int NEXT, int NTT>
 __global__ __launch_bounds__(kThreads) void dpn_enc_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -374,6 +380,38 @@ __global__ __launch_bounds__(kThreads) void dpn_enc_fwd_kernel(FwdArgs a) {
     for (int tt = 0; tt < NTT; ++tt) {
         const int row = row0 + tt * 16 + rl.n16;
         ok[tt] = row < a.rows;
+        if constexpr (!TAIL) {
+            if (a.emb_parts) {
+                // x0 = cat(learnable_token, value_embedding) + positional table + lead-time embedding, assembled HERE from the token convolution's split-K
+                // slices (it was a launch of its own, dpn_embed_assemble: 6.9 us for 0.3 MB of output); same order of additions, every load in flight at once
+                const int c0 = rl.slot * 8;
+                const bool tok = row < a.emb_n_tok;
+                const int64_t po = ((int64_t)(tok ? 0 : row - a.emb_n_tok)) * kD + c0;
+                float v[8];
+                if (tok) load8(v, a.emb_token + (int64_t)row * kD + c0, ok[tt]);
+                else load8(v, a.emb_parts + po, ok[tt]);
+                if (!tok)
+                    for (int p0 = 1; p0 < a.emb_n_parts; p0 += kEmbAhead) {                  // kEmbAhead slices' loads in flight, added in slice order
+                        float t6[kEmbAhead][8];
+#pragma unroll
+                        for (int u = 0; u < kEmbAhead; ++u) load8(t6[u], a.emb_parts + (int64_t)min(p0 + u, a.emb_n_parts - 1) * a.emb_part_stride + po, ok[tt]);
+#pragma unroll
+                        for (int u = 0; u < kEmbAhead; ++u)
+                            if (p0 + u < a.emb_n_parts) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += t6[u][e];
+                            }
+                    }
+                float b8[8], p8[8], e8[8];
+                load8(b8, a.emb_bias + c0, !tok && a.emb_bias != nullptr);
+                load8(p8, a.emb_pos + (int64_t)row * kD + c0, ok[tt]);
+                load8(e8, a.emb_te + c0, true);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vin[tt][e] = ok[tt] ? ((tok ? v[e] : v[e] + b8[e]) + p8[e]) + e8[e] : 0.f;
+                store8(a.emb_out + (int64_t)row * kD + c0, vin[tt], ok[tt]);
+                continue;
+            }
+        }
         load8(vin[tt], (TAIL ? a.o : a.xin) + (int64_t)row * kD + rl.slot * 8, ok[tt]);
         if constexpr (TAIL) load8(res[tt], a.x + (int64_t)row * kD + rl.slot * 8, ok[tt]);
     }
@@ -1662,6 +1700,10 @@ int dpn_enc_fwd(const DpnEncFwd* p, void* stream) {
         if (!p->o || !p->x || !p->bo || !p->g1 || !p->be1 || !p->bc1 || !p->bc2 || !p->g2 || !p->be2) return -1;
         if (!p->x1 || !p->xhat1 || !p->rstd1 || !p->pre || !p->act || !p->x2 || !p->xhat2 || !p->rstd2) return -1;
         a.img[ni++] = img_off(p->m_o, 0); a.img[ni++] = img_off(p->m_c1, 0); a.img[ni++] = img_off(p->m_c2, 0);
+    } else if (p->emb_parts) {
+        if (!p->emb_pos || !p->emb_te || !p->emb_out || p->emb_n_parts < 1 || p->emb_n_tok < 0 || (p->emb_n_tok > 0 && !p->emb_token) || p->emb_part_stride < 0) return -1;
+        a.emb_parts = p->emb_parts; a.emb_bias = p->emb_bias; a.emb_pos = p->emb_pos; a.emb_te = p->emb_te; a.emb_token = p->emb_token; a.emb_out = p->emb_out;
+        a.emb_part_stride = p->emb_part_stride; a.emb_n_parts = p->emb_n_parts; a.emb_n_tok = p->emb_n_tok;
     } else if (!p->xin) return -1;
     if (p->next == 1) {
         if (!mat_ok(p->m_n0) || !mat_ok(p->m_n1) || !mat_ok(p->m_n2) || !p->y0 || !p->y1 || !p->y2) return -1;

@@ -325,8 +325,14 @@ class _DataEmbeddingFn(torch.autograd.Function):
             te = lead_time_pe(h, freq_bands)
         n_tok = token.shape[-2]
         out = torch.empty((B, n_tok + T, D), dtype=torch.float32, device=dev)
-        L.check(lib.dpn_embed_assemble(_p(_c(token)), n_tok, _p(emb_parts), n_parts, T, B, _p(conv_b), _p(_c(pos)), _p(te), _p(out), _s()),
-                'dpn_embed_assemble')
+        pending = dict(token=_c(token), n_tok=n_tok, parts=emb_parts, n_parts=n_parts, T=T, B=B, bias=conv_b, pos=_c(pos), te=te, out=out)
+        if share is not None and B == 1 and getattr(share, 'defer_assemble', False):
+            # one field on the fused path (encoder_forward_fused): the encoder stack's FIRST launch assembles x0 from the split-K slices itself and
+            # writes it here -- no launch for it (it was 6.9 us).  `out` is valid once that launch has run; whoever holds `share.pending` and does
+            # not hand it to that launch calls assemble_pending() (encoder_forward_fused does, when the stack declines).
+            share.pending = pending
+        else:
+            _assemble(pending)
         ctx.save_for_backward(xu)
         ctx.n_tok, ctx.w_shape, ctx.tok_shape, ctx.B = n_tok, conv_w.shape, token.shape, B
         ctx.params = (conv_w, conv_b)
@@ -384,6 +390,20 @@ def embed_wgrad_rides_with_stack(n_fields=1):
     overlap between the encoder's and the embedding's gradient buckets: they complete together and travel as ONE all-reduce
     (interface_physics.StagedPdeStep, InterfacePhysics.training_step)."""
     return n_fields == 1 and not config.FROZEN.embed_own_wgrad and not config.FROZEN.encoder_unfused
+
+
+def _assemble(pd):
+    """dpn_embed_assemble: x0 = cat(learnable_token, value_embedding) + positional table + lead-time embedding from the split-K slices (its own launch)"""
+    L.check(L.load().dpn_embed_assemble(_p(pd['token']), pd['n_tok'], _p(pd['parts']), pd['n_parts'], pd['T'], pd['B'], _p(pd['bias']), _p(pd['pos']),
+                                        _p(pd['te']), _p(pd['out']), _s()), 'dpn_embed_assemble')
+
+
+def assemble_pending(share):
+    """Run a deferred assembly now (nobody took it over)."""
+    pd = getattr(share, 'pending', None) if share is not None else None
+    if pd is not None:
+        share.pending = None
+        _assemble(pd)
 
 
 def _params_ok(params, device):
@@ -696,7 +716,19 @@ class _EncoderStackFn(torch.autograd.Function):
                 setattr(f, k_, _p(v_) if isinstance(v_, torch.Tensor) else v_)
             L.check(lib.dpn_enc_fwd(ctypes.byref(f), stream), 'dpn_enc_fwd')
         q, k, v = new(n, D), new(n, D), new(n, D)
-        fwd(tail=0, next=1, xin=x0, m_n0=0, m_n1=1, m_n2=2, bn0=lay[0][1], bn1=lay[0][3], bn2=lay[0][5], y0=q, y1=k, y2=v)
+        pd = getattr(share, 'pending', None) if share is not None else None
+        if pd is not None:
+            share.pending = None
+        if pd is not None and B == 1 and pd['B'] == 1 and pd['out'].data_ptr() == x0.data_ptr() and n == pd['n_tok'] + pd['T'] and rt == 1:
+            # the data embedding left its assembly to this launch (x0 is written by it, then read by everything below as before)
+            fwd(tail=0, next=1, xin=x0, m_n0=0, m_n1=1, m_n2=2, bn0=lay[0][1], bn1=lay[0][3], bn2=lay[0][5], y0=q, y1=k, y2=v,
+                emb_parts=pd['parts'], emb_bias=pd['bias'], emb_pos=pd['pos'], emb_te=pd['te'], emb_token=pd['token'], emb_out=x0,
+                emb_part_stride=pd['parts'].stride(0), emb_n_parts=pd['n_parts'], emb_n_tok=pd['n_tok'])
+            del pd
+        else:
+            if pd is not None:
+                _assemble(pd)                                            # (another tensor arrived than the one the embedding deferred: assemble it first)
+            fwd(tail=0, next=1, xin=x0, m_n0=0, m_n1=1, m_n2=2, bn0=lay[0][1], bn1=lay[0][3], bn2=lay[0][5], y0=q, y1=k, y2=v)
         x, saved, out = x0, [], None
         xf = xhatf = rstdf = None
         for l in range(nl):
@@ -900,7 +932,7 @@ def _stack_fits(layers, norm, projection, device=None):
 
 class EncoderPrep:
     """dpn_enc_prep's outputs for one forward of the whole encoder: weight images, im2col rows, lead-time encodings."""
-    __slots__ = ('wpack', 'xu', 'te', 'pe_extra', 'embed', 'conv16')
+    __slots__ = ('wpack', 'xu', 'te', 'pe_extra', 'embed', 'conv16', 'defer_assemble', 'pending')
 
 
 def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
@@ -917,6 +949,7 @@ def encoder_prep(field, h, emb_module, extra_freqs, layers, norm, projection):
     hh = _c(h.detach().float().reshape(-1))
     out = EncoderPrep()
     out.embed = None
+    out.defer_assemble, out.pending = False, None
     out.wpack = torch.empty(int(lib.dpn_enc_pack_bytes(len(mats))), dtype=torch.uint8, device=dev)
     out.xu = torch.empty((B * T, 3 * C), dtype=torch.float32, device=dev)
     te = torch.empty((B, 2 * fa.numel()), dtype=torch.float32, device=dev)
@@ -964,11 +997,15 @@ def encoder_forward_fused(net, x_enc, forecast_h):
         return None
     prep = encoder_prep(x_enc, forecast_h, emb, getattr(net, 'extra_lead_freqs', None), layers, enc.norm, net.projection)
     net.extra_lead_pe = (forecast_h, prep.pe_extra) if prep.pe_extra is not None else None
+    # one field: the stack's first launch assembles x0 itself (DPN_EMBED_DEFER=0: the launch of its own, as in rounds 1-5)
+    prep.defer_assemble = bool(config.FROZEN.embed_defer and x_enc.shape[0] == 1 and not config.FROZEN.encoder_fp8 and not config.FROZEN.encoder_unfused)
     x0 = data_embedding_fused(x_enc, emb, net.learnable_token, forecast_h, prep=prep)
     # where a staged backward cuts between the stack and the data embedding -- kept only on request (PhysicsNet.encode_field(keep_embedding=True)):
     # it holds this call's autograd graph
     object.__setattr__(net, 'last_embedding', x0 if getattr(net, 'keep_last_embedding', False) else None)
-    return encoder_stack_fused(x0, layers, enc.norm, net.projection, wpack=prep.wpack, share=prep)
+    out = encoder_stack_fused(x0, layers, enc.norm, net.projection, wpack=prep.wpack, share=prep)
+    assemble_pending(prep)                                           # (only if the stack declined and nobody took the assembly over)
+    return out
 
 
 def encoder_stack_fused(x, layers, norm=None, projection=None, wpack=None, share=None):

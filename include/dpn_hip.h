@@ -284,6 +284,15 @@ typedef struct DpnEncFwd {
     const float *o, *x, *xin;
     const float *bo, *g1, *be1, *bc1, *bc2, *g2, *be2, *gf, *bef, *bn0, *bn1, *bn2;
     float *x1, *xhat1, *rstd1, *pre, *act, *x2, *xhat2, *rstd2, *xf, *xhatf, *rstdf, *y0, *y1, *y2;
+    /* tail = 0, one field (round 6): emb_parts != NULL makes this launch ASSEMBLE its input instead of reading xin -- what dpn_embed_assemble does in a
+     * launch of its own (embed.py:60-64, transformer_net.py:124-126), same order of additions:
+     *   row <  emb_n_tok:  x0[row] = (emb_token[row] + emb_pos[row]) + emb_te
+     *   row >= emb_n_tok:  x0[row] = ((sum_p emb_parts[p][row - emb_n_tok], p = 0 .. emb_n_parts - 1, in order) + emb_bias + emb_pos[row]) + emb_te
+     * emb_parts [emb_n_parts][emb_part_stride floats] (the token convolution's split-K slices, rows of 256), emb_te [256]; x0 is also written to emb_out [rows][256]. */
+    const float *emb_parts, *emb_bias, *emb_pos, *emb_te, *emb_token;
+    float* emb_out;
+    int64_t emb_part_stride;
+    int32_t emb_n_parts, emb_n_tok;
 } DpnEncFwd;
 int dpn_enc_fwd(const DpnEncFwd* p, void* stream);
 

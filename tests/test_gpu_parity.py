@@ -607,6 +607,40 @@ def test_batched_weight_packing_and_loss_finish_are_bitwise_the_per_field_launch
         assert torch.equal(res[0][2][n_], res[1][2][n_]), n_
 
 
+def test_embedding_assembled_inside_the_stacks_first_launch_is_bitwise_the_separate_launch():
+    """Round 6: for one field on the fused path the encoder stack's first launch assembles x0 = cat(learnable_token, token convolution) + positional table +
+    lead-time embedding from the convolution's split-K slices itself (DpnEncFwd.emb_*) instead of reading what dpn_embed_assemble wrote in a launch of its
+    own (DPN_EMBED_DEFER=0).  Same additions in the same order: x0, the encoder output, the loss and every parameter gradient must be torch.equal; the
+    standalone embedding (nobody to take the assembly over) and a batch of fields must not defer."""
+    from deepphysinet_amd import config as C, encoder_ops as E
+    m = _model('bf16x2')
+    net = m.physics_net
+    g = _gpu(synthetic_inputs(300, GEO.lon, GEO.lat, GEO.dx, GEO.dy, tag='inter'))
+    lf = m.train_cfg['losses']['loss_factor']
+    res = []
+    for on in (True, False):
+        with C.override(embed_defer=on):
+            net.zero_grad(set_to_none=True)
+            meta = net.encode_field(g['field_data'], g['forecast_h'], keep_embedding=True)
+            x0 = net.meta_net.model.last_embedding
+            assert x0 is not None
+            x0c, metac = x0.detach().clone(), meta.detach().clone()
+            net.clear_field_cache()
+            loss = m.place_one_batch(g['x'], g['y'], g['t'], g['f'], g['field_data'], g['coord_data'], g['forecast_h'], torch.nn.MSELoss(), lf, 0, 0,
+                                     g['x'].device)
+            loss.backward()
+            res.append((x0c, metac, loss.detach().clone(), {n_: p.grad.detach().clone() for n_, p in net.named_parameters()}))
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for n_ in res[0][3]:
+        assert torch.equal(res[0][3][n_], res[1][3][n_]), n_
+    # the embedding alone: assembled by its own launch whatever the switch says (its output must be valid when it returns)
+    tn = net.meta_net.model
+    with C.override(embed_defer=True):
+        alone = E.data_embedding_fused(g['field_data'], tn.enc_embedding, tn.learnable_token, g['forecast_h'])
+        torch.cuda.synchronize()
+    assert alone is not None and torch.equal(alone.detach().reshape(res[0][0].shape), res[0][0])
+
+
 @pytest.mark.parametrize('rows', [287, 2 * 287, 61 * 287])
 def test_wgrad16_mixed_problem_lists_vs_fp64(rows):
     """dpn_wgrad16 (dW = G^T X, db = column sums of G; f16 hi+lo MFMA with running power-of-two scales): lists whose problems differ in tile
